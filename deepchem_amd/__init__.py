@@ -1,0 +1,15 @@
+"""deepchem_amd: the DeepChem GraphConv training path on MI355X (gfx950).
+
+One hot path -- GraphConv -> GraphPool -> GraphGather -> dense heads, forward and
+backward -- as hand-written HIP kernels behind a C ABI (include/gcmi.h), presented
+through the reference's own class contract:
+
+    import deepchem_amd as dc
+    model = dc.models.torch_models.GraphConvModel(12, number_input_features=[75, 64])
+    model.fit(dataset, nb_epoch=10); model.predict(dataset)
+
+Everything else of DeepChem is out of scope.
+"""
+__version__ = "0.1.0"
+
+from deepchem_amd import data, feat, metrics, models, utils  # noqa: E402,F401

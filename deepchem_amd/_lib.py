@@ -1,0 +1,116 @@
+"""ctypes binding of libgcmi.so (include/gcmi.h).
+
+There is no fallback: if the library cannot be loaded (and cannot be built
+because hipcc is absent) importing a compute entry point raises.  Nothing in
+``deepchem_amd`` computes the hot path with torch ops or on the CPU.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_int64, c_void_p)
+
+from deepchem_amd import _build
+
+GCMI_MAX_DEG = 10
+K_GATHER_SUM, K_GATHER_MAX, K_READOUT, K_SEG_GEMM, K_WGRAD = 0, 1, 2, 3, 4
+
+
+class GcmiGraph(Structure):
+    """struct gcmi_graph (include/gcmi.h)."""
+    _fields_ = [
+        ("n_atoms", c_int32),
+        ("n_edges", c_int32),
+        ("n_mols", c_int32),
+        ("max_deg", c_int32),
+        ("deg_start", c_int32 * (GCMI_MAX_DEG + 2)),
+        ("edge_start", c_int32 * (GCMI_MAX_DEG + 2)),
+        ("d_col_idx", c_void_p),
+        ("d_membership", c_void_p),
+        ("d_mol_runs", c_void_p),
+    ]
+
+
+_P = c_void_p
+_G = POINTER(GcmiGraph)
+_I32P = POINTER(c_int32)
+_I64P = POINTER(c_int64)
+
+# name -> argtypes; every function returns int (status) unless noted
+_SIGNATURES = {
+    "gcmi_collate_sizes": [_P, _P, _P, c_int64, _I64P, _I64P],
+    "gcmi_collate": [_P, c_int64, _P, _P, _P, _P, c_int64, c_int32, _P, c_int64, c_int64, _P, _P,
+                     c_int64, _P, _G],
+    "gcmi_build_mol_runs": [_G, _P, _P, _P],
+    "gcmi_gather_sum_fwd": [_G, _P, c_int64, c_int32, _P, c_int64, c_int32, _P],
+    "gcmi_scatter_add": [_G, _P, c_int64, c_int32, _P, c_int64, _P],
+    "gcmi_gather_max_fwd": [_G, _P, c_int64, c_int32, _P, _P, _P, c_int64, _P, _P],
+    "gcmi_gather_max_bwd": [_G, _P, c_int64, c_int32, _P, _P, c_int64, _P],
+    "gcmi_readout_fwd": [_G, _P, c_int64, c_int32, _P, _P, c_int32, _P, c_int64, _P, _P],
+    "gcmi_readout_bwd": [_G, _P, c_int64, _P, c_int64, c_int32, c_int32, _P, _P, c_int64, _P],
+    "gcmi_bn_stats": [_P, c_int64, c_int64, c_int32, _P, _P, c_float, c_float, _P, _P, _P, _P, _P,
+                      _P, _P, _P],
+    "gcmi_bn_fold_eval": [_P, _P, _P, _P, c_float, c_int32, _P, _P, _P],
+    "gcmi_bn_apply": [_P, c_int64, c_int64, c_int32, _P, _P, _P, c_int64, _P],
+    "gcmi_bn_bwd": [_P, c_int64, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, c_int64,
+                    _P, _P],
+    "gcmi_seg_gemm": [c_int32, _I32P, _I32P, _P, c_int64, c_int32, _P, _I64P, _P, c_int64, c_int32,
+                      _P, _I64P, _P, _I64P, c_int32, c_int32, c_int32, _P, c_int64, _P],
+    "gcmi_seg_gemm_wgrad": [c_int32, _I32P, _I32P, _P, c_int64, c_int32, _P, c_int64, c_int32, _P,
+                            _I64P, _P, _I64P, c_int32, _P],
+    "gcmi_relu_bwd": [_P, c_int64, _P, c_int64, c_int64, c_int32, _P],
+    "gcmi_loss_fwd_bwd": [c_int32, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P],
+    "gcmi_softmax": [_P, c_int64, c_int32, _P, _P],
+    "gcmi_adam_step": [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int64, _P],
+    "gcmi_timing_enable": [c_int32, c_int32],
+    "gcmi_timing_read": [c_int32, _I64P, POINTER(c_double), c_int32],
+}
+
+EXPORTS = ["gcmi_version", "gcmi_last_error"] + sorted(_SIGNATURES)
+
+_lib = None
+
+
+class GcmiError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load():
+    """dlopen libgcmi.so (building it first when it is missing or stale and
+    hipcc is available).  Raises GcmiError otherwise -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if not os.path.exists(path):
+        try:
+            _build.build_lib(verbose=False)
+        except Exception as e:  # no hipcc on this machine
+            raise GcmiError(
+                "libgcmi.so is missing and could not be built (%s). Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` where hipcc exists." % e)
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:
+        raise GcmiError("cannot load %s: %s" % (path, e))
+    lib.gcmi_version.restype = ctypes.c_int
+    lib.gcmi_last_error.restype = c_char_p
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().gcmi_last_error()
+        raise GcmiError("%s failed (status %d): %s" % (what or "gcmi call", rc,
+                                                      msg.decode() if msg else "?"))
+
+
+def call(name: str, *args) -> None:
+    check(getattr(load(), name)(*args), name)

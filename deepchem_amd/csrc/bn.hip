@@ -1,0 +1,310 @@
+// K2: BatchNorm1d over atom rows (training statistics, folded scale/shift,
+// backward).  nn.BatchNorm1d(eps=1e-3, momentum=0.99, affine, running stats)
+// at models/torch_models/graphconvmodel.py:150-165.
+//
+// One streaming pass per reduction: every thread owns one 16-byte column chunk
+// and a strided set of rows, accumulates sum and sum of squares in fp64
+// registers (so E[x^2]-E[x]^2 has no cancellation problem at fp32 output
+// precision), the row-lanes of a workgroup are combined through LDS, and each
+// workgroup issues one fp64 atomic per column into a 2F-double scratch.  A
+// one-workgroup finalize turns that into mean / invstd / folded scale+shift
+// and updates the running statistics.  Consumers (gather-max, readout) apply
+// scale/shift on the fly, so the normalised tensor is never written to HBM.
+// Bound: HBM, N*4F bytes read per pass.
+#include "common.h"
+
+namespace gcmi {
+
+constexpr int kBBlock = 256;
+constexpr int kRowsPerBlock = 512;
+
+// sums[0:F] += sum_r a[r,:],  sums[F:2F] += sum_r a[r,:]*b[r,:]
+// MODE 0: b = a (sum of squares).  MODE 1: b = (x - mean)*invstd (x given), a = dy.
+template <int V, int MODE>
+__global__ void __launch_bounds__(kBBlock)
+col_sums_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ x, int64_t ldx,
+                const float* __restrict__ mean, const float* __restrict__ invstd, int64_t n_rows,
+                int n_feat, int lpr, int lx, double* __restrict__ sums) {
+  __shared__ double red[2 * kBBlock * 4];
+  const int ry = kBBlock / lx;  // row lanes
+  const int ty = threadIdx.x / lx;
+  const int tx = threadIdx.x - ty * lx;
+  const int64_t r_begin = (int64_t)blockIdx.x * kRowsPerBlock;
+  const int64_t r_end = (r_begin + kRowsPerBlock < n_rows) ? r_begin + kRowsPerBlock : n_rows;
+  for (int cc0 = 0; cc0 < lpr; cc0 += lx) {  // uniform trip count: barriers inside
+    const int cc = cc0 + tx;
+    const bool active = cc < lpr && ty < ry;
+    const int c = (cc < lpr ? cc : 0) * V;
+    double s1[V], s2[V];
+    float mu[V], is[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      s1[q] = 0.0;
+      s2[q] = 0.0;
+      mu[q] = MODE == 1 ? mean[c + q] : 0.f;
+      is[q] = MODE == 1 ? invstd[c + q] : 0.f;
+    }
+    if (active) {
+      for (int64_t r = r_begin + ty; r < r_end; r += ry) {
+        float av[V], xv[V];
+        if constexpr (V == 4) {
+          const float4 t4 = *reinterpret_cast<const float4*>(a + r * lda + c);
+          av[0] = t4.x; av[1] = t4.y; av[2] = t4.z; av[3] = t4.w;
+          if (MODE == 1) {
+            const float4 u4 = *reinterpret_cast<const float4*>(x + r * ldx + c);
+            xv[0] = u4.x; xv[1] = u4.y; xv[2] = u4.z; xv[3] = u4.w;
+          }
+        } else {
+          av[0] = a[r * lda + c];
+          if (MODE == 1) xv[0] = x[r * ldx + c];
+        }
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+          s1[q] += (double)av[q];
+          if (MODE == 0)
+            s2[q] += (double)av[q] * (double)av[q];
+          else
+            s2[q] += (double)av[q] * (double)((xv[q] - mu[q]) * is[q]);
+        }
+      }
+    }
+    // combine the row lanes of this column chunk
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      red[(threadIdx.x * V + q) * 2 + 0] = s1[q];
+      red[(threadIdx.x * V + q) * 2 + 1] = s2[q];
+    }
+    __syncthreads();
+    if (ty == 0 && cc < lpr) {
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int y = 0; y < ry; ++y) {
+          t1 += red[((y * lx + tx) * V + q) * 2 + 0];
+          t2 += red[((y * lx + tx) * V + q) * 2 + 1];
+        }
+        atomicAdd(sums + c + q, t1);
+        atomicAdd(sums + n_feat + c + q, t2);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int64_t n_rows, int n_feat,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float eps, float momentum, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float* __restrict__ mean,
+                                   float* __restrict__ invstd, float* __restrict__ scale,
+                                   float* __restrict__ shift) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_feat; c += gridDim.x * blockDim.x) {
+    const double n = (double)n_rows;
+    const double m = sums[c] / n;
+    double var = sums[n_feat + c] / n - m * m;  // biased
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)m;
+    const float is = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma ? gamma[c] : 1.f;
+    const float b = beta ? beta[c] : 0.f;
+    const float sc = g * is;
+    if (mean) mean[c] = mf;
+    if (invstd) invstd[c] = is;
+    scale[c] = sc;
+    shift[c] = b - mf * sc;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mf;
+    if (running_var) {
+      const double unbiased = n_rows > 1 ? var * n / (n - 1.0) : var;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  }
+}
+
+__global__ void bn_fold_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ rm, const float* __restrict__ rv,
+                                    float eps, int n_feat, float* __restrict__ scale,
+                                    float* __restrict__ shift) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_feat; c += gridDim.x * blockDim.x) {
+    const float is = 1.f / sqrtf(rv[c] + eps);
+    const float sc = (gamma ? gamma[c] : 1.f) * is;
+    scale[c] = sc;
+    shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
+  }
+}
+
+template <int V>
+__global__ void __launch_bounds__(kBBlock)
+bn_apply_kernel(const float* __restrict__ x, int64_t ldx, int64_t slots, int lpr,
+                const float* __restrict__ scale, const float* __restrict__ shift,
+                float* __restrict__ y, int64_t ldy) {
+  for (int64_t e = (int64_t)blockIdx.x * kBBlock + threadIdx.x; e < slots;
+       e += (int64_t)gridDim.x * kBBlock) {
+    const int64_t r = e / lpr;
+    const int c = (int)(e - r * lpr) * V;
+    if constexpr (V == 4) {
+      const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + c);
+      const float4 s = *reinterpret_cast<const float4*>(scale + c);
+      const float4 h = *reinterpret_cast<const float4*>(shift + c);
+      *reinterpret_cast<float4*>(y + r * ldy + c) =
+          make_float4(fmaf(v.x, s.x, h.x), fmaf(v.y, s.y, h.y), fmaf(v.z, s.z, h.z), fmaf(v.w, s.w, h.w));
+    } else {
+      y[r * ldy + c] = fmaf(x[r * ldx + c], scale[c], shift[c]);
+    }
+  }
+}
+
+// dgamma = sum dy*xhat, dbeta = sum dy (from sums); dx = gamma*invstd*(dy - dbeta/n - xhat*dgamma/n)
+template <int V>
+__global__ void __launch_bounds__(kBBlock)
+bn_bwd_dx_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+                 int64_t ldx, int64_t n_rows, int n_feat, int64_t slots, int lpr,
+                 const float* __restrict__ gamma, const float* __restrict__ mean,
+                 const float* __restrict__ invstd, const double* __restrict__ sums,
+                 float* __restrict__ dx, int64_t lddx) {
+  const float inv_n = 1.f / (float)n_rows;
+  for (int64_t e = (int64_t)blockIdx.x * kBBlock + threadIdx.x; e < slots;
+       e += (int64_t)gridDim.x * kBBlock) {
+    const int64_t r = e / lpr;
+    const int c = (int)(e - r * lpr) * V;
+    float o[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      const float is = invstd[c + q];
+      const float xh = (x[r * ldx + c + q] - mean[c + q]) * is;
+      const float db = (float)sums[c + q];
+      const float dg = (float)sums[n_feat + c + q];
+      const float g = gamma ? gamma[c + q] : 1.f;
+      o[q] = g * is * (dy[r * lddy + c + q] - db * inv_n - xh * dg * inv_n);
+    }
+    if constexpr (V == 4) {
+      *reinterpret_cast<float4*>(dx + r * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+      dx[r * lddx + c] = o[0];
+    }
+  }
+}
+
+__global__ void bn_bwd_params_kernel(const double* __restrict__ sums, int n_feat,
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_feat; c += gridDim.x * blockDim.x) {
+    if (dbeta) dbeta[c] = (float)sums[c];
+    if (dgamma) dgamma[c] = (float)sums[n_feat + c];
+  }
+}
+
+static int launch_col_sums(int mode, const float* a, int64_t lda, const float* x, int64_t ldx,
+                           const float* mean, const float* invstd, int64_t n_rows, int n_feat,
+                           double* sums, hipStream_t st) {
+  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * n_feat, st) != hipSuccess) {
+    set_error("bn: memset failed");
+    return GCMI_ERR_LAUNCH;
+  }
+  if (n_rows == 0) return GCMI_OK;
+  int V = vec_width(a, lda, n_feat);
+  if (mode == 1 && vec_width(x, ldx, n_feat) != 4) V = 1;
+  const int lpr = n_feat / V;
+  const int lx = lpr < kBBlock ? lpr : kBBlock;
+  const int blocks = (int)((n_rows + kRowsPerBlock - 1) / kRowsPerBlock);
+#define LAUNCH_CS(VV, MM)                                                                     \
+  hipLaunchKernelGGL((col_sums_kernel<VV, MM>), dim3(blocks), dim3(kBBlock), 0, st, a, lda, x, \
+                     ldx, mean, invstd, n_rows, n_feat, lpr, lx, sums)
+  if (V == 4) {
+    if (mode == 0) LAUNCH_CS(4, 0); else LAUNCH_CS(4, 1);
+  } else {
+    if (mode == 0) LAUNCH_CS(1, 0); else LAUNCH_CS(1, 1);
+  }
+#undef LAUNCH_CS
+  GCMI_CHECK_LAUNCH("bn col_sums");
+  return GCMI_OK;
+}
+
+}  // namespace gcmi
+
+using namespace gcmi;
+
+extern "C" {
+
+int gcmi_bn_stats(const float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat,
+                  const float* d_gamma, const float* d_beta, float eps, float momentum,
+                  float* d_running_mean, float* d_running_var, float* d_mean, float* d_invstd,
+                  float* d_scale, float* d_shift, double* d_acc, void* stream) {
+  GCMI_CHECK_ARG(n_feat > 0 && n_rows > 0 && ldx >= n_feat, "bn_stats: bad shape (n_rows=%lld)",
+                 (long long)n_rows);
+  GCMI_CHECK_ARG(d_x && d_scale && d_shift && d_acc, "bn_stats: NULL buffer");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = launch_col_sums(0, d_x, ldx, nullptr, 0, nullptr, nullptr, n_rows, n_feat, d_acc, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((n_feat + 255) / 256), dim3(256), 0, st, d_acc, n_rows,
+                     n_feat, d_gamma, d_beta, eps, momentum, d_running_mean, d_running_var, d_mean,
+                     d_invstd, d_scale, d_shift);
+  GCMI_CHECK_LAUNCH("bn_finalize");
+  return GCMI_OK;
+}
+
+int gcmi_bn_fold_eval(const float* d_gamma, const float* d_beta, const float* d_running_mean,
+                      const float* d_running_var, float eps, int32_t n_feat, float* d_scale,
+                      float* d_shift, void* stream) {
+  GCMI_CHECK_ARG(n_feat > 0 && d_running_mean && d_running_var && d_scale && d_shift,
+                 "bn_fold_eval: bad arguments");
+  hipLaunchKernelGGL(bn_fold_eval_kernel, dim3((n_feat + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, d_gamma, d_beta, d_running_mean, d_running_var, eps, n_feat,
+                     d_scale, d_shift);
+  GCMI_CHECK_LAUNCH("bn_fold_eval");
+  return GCMI_OK;
+}
+
+int gcmi_bn_apply(const float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat,
+                  const float* d_scale, const float* d_shift, float* d_y, int64_t ldy,
+                  void* stream) {
+  GCMI_CHECK_ARG(n_feat > 0 && n_rows >= 0 && ldx >= n_feat && ldy >= n_feat, "bn_apply: bad shape");
+  if (n_rows == 0) return GCMI_OK;
+  GCMI_CHECK_ARG(d_x && d_y && d_scale && d_shift, "bn_apply: NULL buffer");
+  const int V = (vec_width(d_x, ldx, n_feat) == 4 && vec_width(d_y, ldy, n_feat) == 4 &&
+                 aligned16(d_scale) && aligned16(d_shift))
+                    ? 4
+                    : 1;
+  const int lpr = n_feat / V;
+  const int64_t slots = n_rows * lpr;
+  hipStream_t st = (hipStream_t)stream;
+  if (V == 4)
+    hipLaunchKernelGGL(bn_apply_kernel<4>, dim3(grid_for(slots, kBBlock)), dim3(kBBlock), 0, st, d_x,
+                       ldx, slots, lpr, d_scale, d_shift, d_y, ldy);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(grid_for(slots, kBBlock)), dim3(kBBlock), 0, st, d_x,
+                       ldx, slots, lpr, d_scale, d_shift, d_y, ldy);
+  GCMI_CHECK_LAUNCH("bn_apply");
+  return GCMI_OK;
+}
+
+int gcmi_bn_bwd(const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx, int64_t n_rows,
+                int32_t n_feat, const float* d_gamma, const float* d_mean,
+                const float* d_invstd, float* d_dgamma, float* d_dbeta, float* d_dx,
+                int64_t lddx, double* d_acc, void* stream) {
+  GCMI_CHECK_ARG(n_feat > 0 && n_rows > 0 && lddy >= n_feat && ldx >= n_feat, "bn_bwd: bad shape");
+  GCMI_CHECK_ARG(d_dy && d_x && d_mean && d_invstd && d_acc, "bn_bwd: NULL buffer");
+  GCMI_CHECK_ARG(d_dx == nullptr || lddx >= n_feat, "bn_bwd: bad lddx");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = launch_col_sums(1, d_dy, lddy, d_x, ldx, d_mean, d_invstd, n_rows, n_feat, d_acc, st);
+  if (rc) return rc;
+  if (d_dgamma || d_dbeta) {
+    hipLaunchKernelGGL(bn_bwd_params_kernel, dim3((n_feat + 255) / 256), dim3(256), 0, st, d_acc,
+                       n_feat, d_dgamma, d_dbeta);
+    GCMI_CHECK_LAUNCH("bn_bwd_params");
+  }
+  if (d_dx) {
+    const int V = (vec_width(d_dx, lddx, n_feat) == 4) ? 4 : 1;
+    const int lpr = n_feat / V;
+    const int64_t slots = n_rows * lpr;
+    if (V == 4)
+      hipLaunchKernelGGL(bn_bwd_dx_kernel<4>, dim3(grid_for(slots, kBBlock)), dim3(kBBlock), 0, st,
+                         d_dy, lddy, d_x, ldx, n_rows, n_feat, slots, lpr, d_gamma, d_mean, d_invstd,
+                         d_acc, d_dx, lddx);
+    else
+      hipLaunchKernelGGL(bn_bwd_dx_kernel<1>, dim3(grid_for(slots, kBBlock)), dim3(kBBlock), 0, st,
+                         d_dy, lddy, d_x, ldx, n_rows, n_feat, slots, lpr, d_gamma, d_mean, d_invstd,
+                         d_acc, d_dx, lddx);
+    GCMI_CHECK_LAUNCH("bn_bwd_dx");
+  }
+  return GCMI_OK;
+}
+
+}  // extern "C"

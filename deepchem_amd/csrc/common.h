@@ -1,0 +1,104 @@
+// Shared host/device helpers for libgcmi.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/gcmi.h"
+
+namespace gcmi {
+
+void set_error(const char* fmt, ...);
+
+#define GCMI_CHECK_ARG(cond, ...)          \
+  do {                                     \
+    if (!(cond)) {                         \
+      ::gcmi::set_error(__VA_ARGS__);      \
+      return GCMI_ERR_ARG;                 \
+    }                                      \
+  } while (0)
+
+#define GCMI_CHECK_LAUNCH(what)                                                        \
+  do {                                                                                 \
+    hipError_t e__ = hipGetLastError();                                                \
+    if (e__ != hipSuccess) {                                                           \
+      ::gcmi::set_error("%s: %s", what, hipGetErrorString(e__));                       \
+      return GCMI_ERR_LAUNCH;                                                          \
+    }                                                                                  \
+  } while (0)
+
+// Per-kernel-family timing (bench.py roofline): events recorded on the launch stream.
+void timing_begin(int kernel_id, hipStream_t s);
+void timing_end(int kernel_id, hipStream_t s);
+
+struct TimedScope {
+  int id;
+  hipStream_t s;
+  TimedScope(int id_, hipStream_t s_) : id(id_), s(s_) { timing_begin(id, s); }
+  ~TimedScope() { timing_end(id, s); }
+};
+
+// The degree blocks of a collated batch, passed BY VALUE to kernels (lives in
+// SGPRs / the kernarg segment: no memory traffic for row -> degree lookups).
+struct DegTable {
+  int32_t max_deg;
+  int32_t deg_start[GCMI_MAX_DEG + 2];
+  int32_t edge_start[GCMI_MAX_DEG + 2];
+};
+
+inline DegTable make_deg_table(const gcmi_graph* g) {
+  DegTable t;
+  t.max_deg = g->max_deg;
+  for (int d = 0; d < GCMI_MAX_DEG + 2; ++d) {
+    t.deg_start[d] = g->deg_start[d < g->max_deg + 1 ? d : g->max_deg + 1];
+    t.edge_start[d] = g->edge_start[d < g->max_deg + 1 ? d : g->max_deg + 1];
+  }
+  return t;
+}
+
+int check_graph(const gcmi_graph* g, bool need_cols);
+
+// degree of batch row i: the number of block starts (d >= 1) that are <= i.
+__device__ __forceinline__ int degree_of_row(const DegTable& t, int i) {
+  int d = 0;
+#pragma unroll
+  for (int k = 1; k <= GCMI_MAX_DEG; ++k) d += (k <= t.max_deg && i >= t.deg_start[k]) ? 1 : 0;
+  return d;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// vector width usable for a row-major matrix access
+inline int vec_width(const void* p, int64_t ld, int n_feat) {
+  return (aligned16(p) && (ld % 4 == 0) && (n_feat % 4 == 0)) ? 4 : 1;
+}
+
+constexpr int kMaxBlocks = 256 * 8 * 4;  // grid cap for grid-stride kernels: 256 CUs x 8 x 4
+
+inline int grid_for(int64_t work_items, int block) {
+  int64_t b = (work_items + block - 1) / block;
+  if (b < 1) b = 1;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  return static_cast<int>(b);
+}
+
+template <int V>
+struct Vec;
+template <>
+struct Vec<1> {
+  using T = float;
+};
+template <>
+struct Vec<4> {
+  using T = float4;
+};
+
+__device__ __forceinline__ float vzero(float) { return 0.f; }
+__device__ __forceinline__ float4 vzero(float4) { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float vadd(float a, float b) { return a + b; }
+__device__ __forceinline__ float4 vadd(float4 a, float4 b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+}  // namespace gcmi

@@ -1,0 +1,432 @@
+// Row-segmented GEMMs on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact
+// fp32, an fmaf chain in k order -- MI355X_MICROARCH "FP32-input MFMA").
+//
+//   gcmi_seg_gemm        out[rows_s] = act(a1[rows_s].w1[s] + a2[rows_s].w2[s] + bias[s])
+//   gcmi_seg_gemm_wgrad  dw[s] += a[rows_s]^T . g[rows_s],  dbias[s] += colsum g[rows_s]
+//
+// Why "segmented": a collated batch is sorted by atom degree, GraphConv has one
+// weight pair per degree (layers.py:6202-6226), so every 64-row tile lies
+// inside ONE segment and sees ONE weight block -- the 21 small matmuls of the
+// reference become a single launch.  The dense layer and the task heads are
+// the one-segment case.
+//
+// Forward tile: 64 rows x 64 columns per 256-thread workgroup, 2x2 waves, each
+// wave one 32x32 accumulator (16 VGPRs).  K is walked in chunks of 32 staged
+// through LDS (A chunk padded to 33 floats/row, B chunk to 65: conflict-free
+// ds_read_b32 for the 32x32x2 operand maps A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]).
+// wgrad: no LDS at all -- the operand maps of a^T.g are lane-contiguous along
+// the feature dimension, so both operands are loaded straight from global
+// memory (one dword per lane per row pair) and every wave keeps <= 8
+// accumulators (k <= 256 per pass).
+#include "common.h"
+
+namespace gcmi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMaxSeg = 16;
+constexpr int kGBlock = 256;
+constexpr int BM = 64;
+constexpr int BNT = 64;
+constexpr int KC = 32;
+
+struct SegTable {
+  int32_t n_seg;
+  int32_t seg_begin[kMaxSeg];
+  int32_t seg_end[kMaxSeg];
+  int32_t tile_start[kMaxSeg + 1];
+  int64_t w1_off[kMaxSeg];  // < 0: term absent
+  int64_t w2_off[kMaxSeg];
+  int64_t bias_off[kMaxSeg];
+};
+
+__device__ __forceinline__ int seg_of_tile(const SegTable& st, int b) {
+  int s = 0;
+#pragma unroll
+  for (int k = 1; k < kMaxSeg; ++k) s += (k < st.n_seg && b >= st.tile_start[k]) ? 1 : 0;
+  return s;
+}
+
+template <typename T>
+__device__ __forceinline__ T pick_seg(const T* a, int s) {
+  T v = a[0];
+#pragma unroll
+  for (int k = 1; k < kMaxSeg; ++k) v = (s == k) ? a[k] : v;
+  return v;
+}
+
+// stage one K-chunk of A (64 rows x KC) and of W (KC x 64 cols) into LDS
+template <bool VEC4>
+__device__ __forceinline__ void stage_a(float (*As)[KC + 1], const float* __restrict__ a,
+                                        int64_t lda, int row0, int rows_valid, int k0, int K) {
+  const int tid = threadIdx.x;
+  if constexpr (VEC4) {
+    const int kq = (tid & 7) * 4;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int r = (tid >> 3) + pass * 32;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < rows_valid && k0 + kq < K) {  // K % 4 == 0 here, so the whole float4 is in range
+        v = *reinterpret_cast<const float4*>(a + (int64_t)(row0 + r) * lda + k0 + kq);
+      }
+      As[r][kq + 0] = v.x;
+      As[r][kq + 1] = v.y;
+      As[r][kq + 2] = v.z;
+      As[r][kq + 3] = v.w;
+    }
+  } else {
+    const int kk = tid & 31;
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int r = (tid >> 5) + pass * 8;
+      float v = 0.f;
+      if (r < rows_valid && k0 + kk < K) v = a[(int64_t)(row0 + r) * lda + k0 + kk];
+      As[r][kk] = v;
+    }
+  }
+}
+
+template <bool TRANS>
+__device__ __forceinline__ void stage_b(float (*Bs)[BNT + 1], const float* __restrict__ w, int K,
+                                        int n_out, int col0, int k0) {
+  const int tid = threadIdx.x;
+  if constexpr (!TRANS) {  // w is K x n_out
+    const int j = tid & 63;
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int kk = (tid >> 6) + pass * 4;
+      float v = 0.f;
+      if (k0 + kk < K && col0 + j < n_out) v = w[(int64_t)(k0 + kk) * n_out + col0 + j];
+      Bs[kk][j] = v;
+    }
+  } else {  // w is n_out x K
+    const int kk = tid & 31;
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+      const int j = (tid >> 5) + pass * 8;
+      float v = 0.f;
+      if (k0 + kk < K && col0 + j < n_out) v = w[(int64_t)(col0 + j) * K + k0 + kk];
+      Bs[kk][j] = v;
+    }
+  }
+}
+
+template <bool TRANS, bool VEC4>
+__global__ void __launch_bounds__(kGBlock)
+seg_gemm_kernel(SegTable st, const float* __restrict__ a1, int64_t lda1, int k1,
+                const float* __restrict__ w1, const float* __restrict__ a2, int64_t lda2, int k2,
+                const float* __restrict__ w2, const float* __restrict__ bias, int n_out, int act,
+                float* __restrict__ out, int64_t ldo) {
+  __shared__ float As[BM][KC + 1];
+  __shared__ float Bs[KC][BNT + 1];
+  const int b = blockIdx.x;
+  const int s = seg_of_tile(st, b);
+  const int row0 = pick_seg(st.seg_begin, s) + (b - pick_seg(st.tile_start, s)) * BM;
+  const int seg_end = pick_seg(st.seg_end, s);
+  const int rows_valid = (seg_end - row0 < BM) ? seg_end - row0 : BM;
+  const int col0 = blockIdx.y * BNT;
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wr = wave >> 1, wc = wave & 1;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const float* a = p == 0 ? a1 : a2;
+    const int64_t lda = p == 0 ? lda1 : lda2;
+    const int K = p == 0 ? k1 : k2;
+    const int64_t woff = p == 0 ? pick_seg(st.w1_off, s) : pick_seg(st.w2_off, s);
+    const float* wbase = p == 0 ? w1 : w2;
+    if (a == nullptr || wbase == nullptr || woff < 0) continue;  // block-uniform
+    const float* w = wbase + woff;
+    for (int k0 = 0; k0 < K; k0 += KC) {
+      stage_a<VEC4>(As, a, lda, row0, rows_valid, k0, K);
+      stage_b<TRANS>(Bs, w, K, n_out, col0, k0);
+      __syncthreads();
+#pragma unroll
+      for (int kk = 0; kk < KC; kk += 2) {
+        const float av = As[wr * 32 + (lane & 31)][kk + (lane >> 5)];
+        const float bv = Bs[kk + (lane >> 5)][wc * 32 + (lane & 31)];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+      }
+      __syncthreads();
+    }
+  }
+  const int64_t boff = pick_seg(st.bias_off, s);
+  const int col = col0 + wc * 32 + (lane & 31);
+  if (col < n_out) {
+    const float bv = (bias != nullptr && boff >= 0) ? bias[boff + col] : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int r = wr * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+      if (r < rows_valid) {
+        float v = acc[reg] + bv;
+        if (act == 1) v = v > 0.f ? v : 0.f;
+        out[(int64_t)(row0 + r) * ldo + col] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ wgrad
+struct SlabTable {
+  int32_t n_seg;
+  int32_t slab_rows;
+  int32_t seg_begin[kMaxSeg];
+  int32_t seg_end[kMaxSeg];
+  int32_t slab_start[kMaxSeg + 1];
+  int64_t dw_off[kMaxSeg];
+  int64_t db_off[kMaxSeg];
+};
+
+template <int KT, bool TRANS>
+__global__ void __launch_bounds__(kGBlock)
+wgrad_kernel(SlabTable st, const float* __restrict__ a, int64_t lda, int k, int kt0,
+             const float* __restrict__ g, int64_t ldg, int n, int ntw, float* __restrict__ dw,
+             float* __restrict__ dbias) {
+  const int b = blockIdx.x;
+  int s = 0;
+#pragma unroll
+  for (int q = 1; q < kMaxSeg; ++q) s += (q < st.n_seg && b >= st.slab_start[q]) ? 1 : 0;
+  const int seg_end = pick_seg(st.seg_end, s);
+  const int slab0 = pick_seg(st.seg_begin, s) + (b - pick_seg(st.slab_start, s)) * st.slab_rows;
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int nt = blockIdx.y * ntw + (wave % ntw);  // n-tile of this wave
+  const int rp = wave / ntw;                       // row part of this wave
+  const int parts = 4 / ntw;
+  const int part_rows = st.slab_rows / parts;      // slab_rows is a multiple of 8
+  const int r_begin = slab0 + rp * part_rows;
+  int r_end = r_begin + part_rows;
+  if (r_end > seg_end) r_end = seg_end;
+  const int ncol = nt * 32 + (lane & 31);
+  const bool n_ok = ncol < n;
+  const int half = lane >> 5;
+  f32x16 acc[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  float bsum = 0.f;
+  bool k_ok[KT];
+  int kcol[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    kcol[t] = (kt0 + t) * 32 + (lane & 31);
+    k_ok[t] = kcol[t] < k;
+  }
+  constexpr int U = 4;  // row pairs in flight
+  for (int r = r_begin; r < r_end; r += 2 * U) {
+    float av[U][KT], bv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int rr = r + 2 * u + half;
+      const bool ok = rr < r_end;
+      bv[u] = (ok && n_ok) ? g[(int64_t)rr * ldg + ncol] : 0.f;
+#pragma unroll
+      for (int t = 0; t < KT; ++t) av[u][t] = (ok && k_ok[t]) ? a[(int64_t)rr * lda + kcol[t]] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      bsum += bv[u];
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][t], bv[u], acc[t], 0, 0, 0);
+    }
+  }
+  if (r_begin >= r_end) return;
+  const int64_t woff = pick_seg(st.dw_off, s);
+  if (n_ok && woff >= 0) {
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int kf = (kt0 + t) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
+        if (kf < k) {
+          const int64_t idx = TRANS ? (int64_t)ncol * k + kf : (int64_t)kf * n + ncol;
+          atomicAdd(dw + woff + idx, acc[t][reg]);
+        }
+      }
+    }
+  }
+  if (dbias != nullptr && kt0 == 0) {
+    const int64_t boff = pick_seg(st.db_off, s);
+    bsum += __shfl_xor(bsum, 32);
+    if (half == 0 && n_ok && boff >= 0) atomicAdd(dbias + boff + ncol, bsum);
+  }
+}
+
+template <int V>
+__global__ void __launch_bounds__(256)
+relu_bwd_kernel(float* __restrict__ g, int64_t ldg, const float* __restrict__ y, int64_t ldy,
+                int64_t slots, int lpr) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < slots; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / lpr;
+    const int c = (int)(e - r * lpr) * V;
+    if constexpr (V == 4) {
+      float4 gv = *reinterpret_cast<float4*>(g + r * ldg + c);
+      const float4 yv = *reinterpret_cast<const float4*>(y + r * ldy + c);
+      gv.x = yv.x > 0.f ? gv.x : 0.f;
+      gv.y = yv.y > 0.f ? gv.y : 0.f;
+      gv.z = yv.z > 0.f ? gv.z : 0.f;
+      gv.w = yv.w > 0.f ? gv.w : 0.f;
+      *reinterpret_cast<float4*>(g + r * ldg + c) = gv;
+    } else {
+      g[r * ldg + c] = y[r * ldy + c] > 0.f ? g[r * ldg + c] : 0.f;
+    }
+  }
+}
+
+}  // namespace gcmi
+
+using namespace gcmi;
+
+extern "C" {
+
+int gcmi_seg_gemm(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_end,
+                  const float* d_a1, int64_t lda1, int32_t k1, const float* d_w1,
+                  const int64_t* w1_off, const float* d_a2, int64_t lda2, int32_t k2,
+                  const float* d_w2, const int64_t* w2_off, const float* d_bias,
+                  const int64_t* bias_off, int32_t n_out, int32_t trans_w, int32_t act,
+                  float* d_out, int64_t ldo, void* stream) {
+  GCMI_CHECK_ARG(n_seg >= 1 && n_seg <= kMaxSeg, "seg_gemm: n_seg %d outside [1,%d]", n_seg, kMaxSeg);
+  GCMI_CHECK_ARG(seg_begin && seg_end, "seg_gemm: NULL segment table");
+  GCMI_CHECK_ARG(n_out > 0 && ldo >= n_out && d_out, "seg_gemm: bad output");
+  GCMI_CHECK_ARG((d_a1 && d_w1 && w1_off && k1 > 0 && lda1 >= k1) || (d_a1 == nullptr),
+                 "seg_gemm: bad first operand");
+  GCMI_CHECK_ARG((d_a2 && d_w2 && w2_off && k2 > 0 && lda2 >= k2) || (d_a2 == nullptr),
+                 "seg_gemm: bad second operand");
+  GCMI_CHECK_ARG(d_a1 || d_a2, "seg_gemm: no operand");
+  GCMI_CHECK_ARG(d_bias == nullptr || bias_off != nullptr, "seg_gemm: bias without offsets");
+  GCMI_CHECK_ARG(act == 0 || act == 1, "seg_gemm: act must be 0 or 1");
+  SegTable st;
+  memset(&st, 0, sizeof(st));
+  st.n_seg = n_seg;
+  int64_t tiles = 0;
+  for (int s = 0; s < kMaxSeg; ++s) {
+    st.tile_start[s] = (int32_t)tiles;
+    if (s < n_seg) {
+      GCMI_CHECK_ARG(seg_end[s] >= seg_begin[s] && seg_begin[s] >= 0, "seg_gemm: bad segment %d", s);
+      st.seg_begin[s] = seg_begin[s];
+      st.seg_end[s] = seg_end[s];
+      st.w1_off[s] = (d_a1 && w1_off) ? w1_off[s] : -1;
+      st.w2_off[s] = (d_a2 && w2_off) ? w2_off[s] : -1;
+      st.bias_off[s] = (d_bias && bias_off) ? bias_off[s] : -1;
+      tiles += (seg_end[s] - seg_begin[s] + BM - 1) / BM;
+    } else {
+      st.w1_off[s] = st.w2_off[s] = st.bias_off[s] = -1;
+    }
+  }
+  st.tile_start[kMaxSeg] = (int32_t)tiles;
+  if (tiles == 0) return GCMI_OK;
+  hipStream_t sm = (hipStream_t)stream;
+  const bool vec4 = (d_a1 == nullptr || (aligned16(d_a1) && lda1 % 4 == 0 && k1 % 4 == 0)) &&
+                    (d_a2 == nullptr || (aligned16(d_a2) && lda2 % 4 == 0 && k2 % 4 == 0));
+  dim3 grid((unsigned)tiles, (unsigned)((n_out + BNT - 1) / BNT));
+  TimedScope ts(GCMI_K_SEG_GEMM, sm);
+#define LAUNCH_SG(TT, VV)                                                                       \
+  hipLaunchKernelGGL((seg_gemm_kernel<TT, VV>), grid, dim3(kGBlock), 0, sm, st, d_a1, lda1, k1,  \
+                     d_w1, d_a2, lda2, k2, d_w2, d_bias, n_out, act, d_out, ldo)
+  if (trans_w) {
+    if (vec4) LAUNCH_SG(true, true); else LAUNCH_SG(true, false);
+  } else {
+    if (vec4) LAUNCH_SG(false, true); else LAUNCH_SG(false, false);
+  }
+#undef LAUNCH_SG
+  GCMI_CHECK_LAUNCH("seg_gemm");
+  return GCMI_OK;
+}
+
+int gcmi_seg_gemm_wgrad(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_end,
+                        const float* d_a, int64_t lda, int32_t k, const float* d_g, int64_t ldg,
+                        int32_t n, float* d_dw, const int64_t* dw_off, float* d_dbias,
+                        const int64_t* dbias_off, int32_t trans_w, void* stream) {
+  GCMI_CHECK_ARG(n_seg >= 1 && n_seg <= kMaxSeg, "wgrad: n_seg %d outside [1,%d]", n_seg, kMaxSeg);
+  GCMI_CHECK_ARG(seg_begin && seg_end && dw_off, "wgrad: NULL segment table");
+  GCMI_CHECK_ARG(k > 0 && n > 0 && lda >= k && ldg >= n, "wgrad: bad shape");
+  GCMI_CHECK_ARG(d_a && d_g && d_dw, "wgrad: NULL buffer");
+  GCMI_CHECK_ARG(d_dbias == nullptr || dbias_off != nullptr, "wgrad: dbias without offsets");
+  SlabTable st;
+  memset(&st, 0, sizeof(st));
+  st.n_seg = n_seg;
+  int64_t total_rows = 0;
+  for (int s = 0; s < n_seg; ++s) {
+    GCMI_CHECK_ARG(seg_end[s] >= seg_begin[s] && seg_begin[s] >= 0, "wgrad: bad segment %d", s);
+    total_rows += seg_end[s] - seg_begin[s];
+  }
+  if (total_rows == 0) return GCMI_OK;
+  // slab size: enough workgroups to fill the chip, few enough that the atomics stay cheap
+  int64_t slab = (total_rows + 1023) / 1024;
+  slab = ((slab + 63) / 64) * 64;
+  if (slab < 64) slab = 64;
+  if (slab > 2048) slab = 2048;
+  st.slab_rows = (int32_t)slab;
+  int64_t slabs = 0;
+  for (int s = 0; s < kMaxSeg; ++s) {
+    st.slab_start[s] = (int32_t)slabs;
+    if (s < n_seg) {
+      st.seg_begin[s] = seg_begin[s];
+      st.seg_end[s] = seg_end[s];
+      st.dw_off[s] = dw_off[s];
+      st.db_off[s] = (d_dbias && dbias_off) ? dbias_off[s] : -1;
+      slabs += (seg_end[s] - seg_begin[s] + slab - 1) / slab;
+    } else {
+      st.dw_off[s] = st.db_off[s] = -1;
+    }
+  }
+  st.slab_start[kMaxSeg] = (int32_t)slabs;
+  hipStream_t sm = (hipStream_t)stream;
+  const int NT = (n + 31) / 32;
+  const int ntw = NT >= 3 ? 4 : NT;  // n-tiles per workgroup: 1, 2 or 4
+  const int KT_total = (k + 31) / 32;
+  dim3 grid((unsigned)slabs, (unsigned)((NT + ntw - 1) / ntw));
+  TimedScope ts(GCMI_K_WGRAD, sm);
+  for (int kt0 = 0; kt0 < KT_total; kt0 += 8) {
+    const int KT = KT_total - kt0 < 8 ? KT_total - kt0 : 8;
+#define LAUNCH_WG(KK)                                                                            \
+  do {                                                                                           \
+    if (trans_w)                                                                                 \
+      hipLaunchKernelGGL((wgrad_kernel<KK, true>), grid, dim3(kGBlock), 0, sm, st, d_a, lda, k,  \
+                         kt0, d_g, ldg, n, ntw, d_dw, d_dbias);                                  \
+    else                                                                                         \
+      hipLaunchKernelGGL((wgrad_kernel<KK, false>), grid, dim3(kGBlock), 0, sm, st, d_a, lda, k, \
+                         kt0, d_g, ldg, n, ntw, d_dw, d_dbias);                                  \
+  } while (0)
+    switch (KT) {
+      case 1: LAUNCH_WG(1); break;
+      case 2: LAUNCH_WG(2); break;
+      case 3: LAUNCH_WG(3); break;
+      case 4: LAUNCH_WG(4); break;
+      case 5: LAUNCH_WG(5); break;
+      case 6: LAUNCH_WG(6); break;
+      case 7: LAUNCH_WG(7); break;
+      default: LAUNCH_WG(8); break;
+    }
+#undef LAUNCH_WG
+    GCMI_CHECK_LAUNCH("seg_gemm_wgrad");
+  }
+  return GCMI_OK;
+}
+
+int gcmi_relu_bwd(float* d_g, int64_t ldg, const float* d_y, int64_t ldy, int64_t n_rows,
+                  int32_t n_feat, void* stream) {
+  GCMI_CHECK_ARG(n_feat > 0 && n_rows >= 0 && ldg >= n_feat && ldy >= n_feat, "relu_bwd: bad shape");
+  if (n_rows == 0) return GCMI_OK;
+  GCMI_CHECK_ARG(d_g && d_y, "relu_bwd: NULL buffer");
+  const int V = (vec_width(d_g, ldg, n_feat) == 4 && vec_width(d_y, ldy, n_feat) == 4) ? 4 : 1;
+  const int lpr = n_feat / V;
+  const int64_t slots = n_rows * lpr;
+  hipStream_t sm = (hipStream_t)stream;
+  if (V == 4)
+    hipLaunchKernelGGL(relu_bwd_kernel<4>, dim3(grid_for(slots, 256)), dim3(256), 0, sm, d_g, ldg,
+                       d_y, ldy, slots, lpr);
+  else
+    hipLaunchKernelGGL(relu_bwd_kernel<1>, dim3(grid_for(slots, 256)), dim3(256), 0, sm, d_g, ldg,
+                       d_y, ldy, slots, lpr);
+  GCMI_CHECK_LAUNCH("relu_bwd");
+  return GCMI_OK;
+}
+
+}  // extern "C"

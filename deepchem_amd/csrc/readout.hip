@@ -1,0 +1,226 @@
+// K4 readout: GraphGather = per-molecule [sum | max] over atom rows (+tanh),
+// and the per-molecule row ranges ("mol runs") it walks.
+//
+// In a collated batch the atoms of molecule b are NOT contiguous: the batch is
+// sorted by degree first, so b owns one short contiguous run of rows inside
+// every degree block (membership is ascending inside a block).  The plan
+// d_mol_runs[b][d] = [begin,end) lists those <= 11 runs; a group of F/4 lanes
+// (one 16-byte column chunk per lane) then walks the runs of ONE molecule in
+// ascending row order and keeps running sum / max / arg-max in registers: a
+// segmented reduction with no atomics, no sort, deterministic summation order
+// and the reference's first-maximum tie rule (lowest row wins,
+// utils/pytorch_utils.py:524-526 -> torch.max(dim=0)).
+// Bound: HBM.  Algorithmic bytes per launch: N*(4F+4) + B*8F.
+#include <limits.h>
+#include <math.h>
+
+#include "common.h"
+
+namespace gcmi {
+
+constexpr int kRBlock = 256;
+
+__global__ void __launch_bounds__(kRBlock)
+mol_runs_kernel(DegTable t, int n_atoms, int n_mols, const int32_t* __restrict__ membership,
+                int32_t* __restrict__ runs, int32_t* __restrict__ flag) {
+  const int n_deg = t.max_deg + 1;
+  for (int i = blockIdx.x * kRBlock + threadIdx.x; i < n_atoms; i += gridDim.x * kRBlock) {
+    const int d = degree_of_row(t, i);
+    int lo = 0, hi = 0;
+#pragma unroll
+    for (int k = 0; k <= GCMI_MAX_DEG; ++k) {
+      if (k == d) {
+        lo = t.deg_start[k];
+        hi = t.deg_start[k + 1];
+      }
+    }
+    const int b = membership[i];
+    if (b < 0 || b >= n_mols) {
+      if (flag) *flag = 1;
+      continue;
+    }
+    const int prev = (i > lo) ? membership[i - 1] : -1;
+    const int next = (i + 1 < hi) ? membership[i + 1] : INT_MAX;
+    if (prev > b && flag) *flag = 1;
+    int32_t* r = runs + ((int64_t)b * n_deg + d) * 2;
+    if (prev != b) r[0] = i;
+    if (next != b) r[1] = i + 1;
+  }
+}
+
+template <int V, bool BN>
+__global__ void __launch_bounds__(kRBlock)
+readout_fwd_kernel(int n_mols, int n_deg, const int32_t* __restrict__ runs,
+                   const float* __restrict__ x, int64_t ldx, int n_feat, int lpr, int gl,
+                   const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                   float* __restrict__ out, int64_t ldo, int32_t* __restrict__ arg) {
+  const int mpb = kRBlock / gl;  // molecules per workgroup
+  const int grp = threadIdx.x / gl;
+  const int lane = threadIdx.x - grp * gl;
+  if (grp >= mpb) return;
+  const int b = blockIdx.x * mpb + grp;
+  if (b >= n_mols) return;
+  const int32_t* rb = runs + (int64_t)b * n_deg * 2;
+  for (int cc = lane; cc < lpr; cc += gl) {
+    const int c = cc * V;
+    float sc[V], sh[V], sum[V], mx[V];
+    int am[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      sc[q] = BN ? scale[c + q] : 1.f;
+      sh[q] = BN ? shift[c + q] : 0.f;
+      sum[q] = 0.f;
+      mx[q] = -INFINITY;
+      am[q] = -1;
+    }
+    for (int d = 0; d < n_deg; ++d) {
+      const int r0 = rb[2 * d], r1 = rb[2 * d + 1];
+      for (int r = r0; r < r1; ++r) {
+        float v[V];
+        if constexpr (V == 4) {
+          const float4 tv = *reinterpret_cast<const float4*>(x + (int64_t)r * ldx + c);
+          v[0] = tv.x; v[1] = tv.y; v[2] = tv.z; v[3] = tv.w;
+        } else {
+          v[0] = x[(int64_t)r * ldx + c];
+        }
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+          const float a = BN ? fmaf(v[q], sc[q], sh[q]) : v[q];
+          sum[q] += a;
+          if (a > mx[q]) { mx[q] = a; am[q] = r; }
+        }
+      }
+    }
+    float* o = out + (int64_t)b * ldo;
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      o[c + q] = act == 1 ? tanhf(sum[q]) : sum[q];
+      o[n_feat + c + q] = act == 1 ? tanhf(mx[q]) : mx[q];
+      if (arg) arg[(int64_t)b * n_feat + c + q] = am[q];
+    }
+  }
+}
+
+template <int V>
+__global__ void __launch_bounds__(kRBlock)
+readout_bwd_kernel(int64_t slots, int lpr, int n_feat, const int32_t* __restrict__ membership,
+                   const float* __restrict__ dout, int64_t lddo, const float* __restrict__ out,
+                   int64_t ldo, int act, const int32_t* __restrict__ arg, float* __restrict__ dx,
+                   int64_t lddx) {
+  for (int64_t e = (int64_t)blockIdx.x * kRBlock + threadIdx.x; e < slots;
+       e += (int64_t)gridDim.x * kRBlock) {
+    const int i = (int)(e / lpr);
+    const int c = (int)(e - (int64_t)i * lpr) * V;
+    const int b = membership[i];
+    float g[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      float gs = dout[(int64_t)b * lddo + c + q];
+      float gm = dout[(int64_t)b * lddo + n_feat + c + q];
+      if (act == 1) {
+        const float os = out[(int64_t)b * ldo + c + q];
+        const float om = out[(int64_t)b * ldo + n_feat + c + q];
+        gs *= (1.f - os * os);
+        gm *= (1.f - om * om);
+      }
+      g[q] = gs + ((arg[(int64_t)b * n_feat + c + q] == i) ? gm : 0.f);
+    }
+    if constexpr (V == 4) {
+      *reinterpret_cast<float4*>(dx + (int64_t)i * lddx + c) = make_float4(g[0], g[1], g[2], g[3]);
+    } else {
+      dx[(int64_t)i * lddx + c] = g[0];
+    }
+  }
+}
+
+}  // namespace gcmi
+
+using namespace gcmi;
+
+extern "C" {
+
+int gcmi_build_mol_runs(const gcmi_graph* g, int32_t* d_mol_runs, int32_t* d_flag, void* stream) {
+  int rc = check_graph(g, false);
+  if (rc) return rc;
+  GCMI_CHECK_ARG(d_mol_runs != nullptr || g->n_mols == 0, "build_mol_runs: NULL output");
+  GCMI_CHECK_ARG(g->n_atoms == 0 || g->d_membership != nullptr, "build_mol_runs: d_membership is NULL");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t bytes = (size_t)g->n_mols * (g->max_deg + 1) * 2 * sizeof(int32_t);
+  if (bytes) {
+    if (hipMemsetAsync(d_mol_runs, 0, bytes, st) != hipSuccess) {
+      set_error("build_mol_runs: memset failed");
+      return GCMI_ERR_LAUNCH;
+    }
+  }
+  if (d_flag && hipMemsetAsync(d_flag, 0, sizeof(int32_t), st) != hipSuccess) {
+    set_error("build_mol_runs: memset failed");
+    return GCMI_ERR_LAUNCH;
+  }
+  if (g->n_atoms == 0) return GCMI_OK;
+  DegTable t = make_deg_table(g);
+  hipLaunchKernelGGL(mol_runs_kernel, dim3(grid_for(g->n_atoms, kRBlock)), dim3(kRBlock), 0, st, t,
+                     g->n_atoms, g->n_mols, g->d_membership, d_mol_runs, d_flag);
+  GCMI_CHECK_LAUNCH("build_mol_runs");
+  return GCMI_OK;
+}
+
+int gcmi_readout_fwd(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t n_feat,
+                     const float* d_scale, const float* d_shift, int32_t act, float* d_out,
+                     int64_t ldo, int32_t* d_arg, void* stream) {
+  int rc = check_graph(g, false);
+  if (rc) return rc;
+  GCMI_CHECK_ARG(n_feat > 0 && ldx >= n_feat && ldo >= 2 * (int64_t)n_feat, "readout: bad n_feat/ld");
+  GCMI_CHECK_ARG(g->n_mols == 0 || (d_out && g->d_mol_runs), "readout: NULL output or mol runs");
+  GCMI_CHECK_ARG(g->n_atoms == 0 || d_x, "readout: NULL input");
+  GCMI_CHECK_ARG((d_scale == nullptr) == (d_shift == nullptr), "readout: scale/shift must come together");
+  GCMI_CHECK_ARG(act == 0 || act == 1, "readout: act must be 0 or 1");
+  if (g->n_mols == 0) return GCMI_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int V = vec_width(d_x, ldx, n_feat);
+  const int lpr = n_feat / V;
+  const int gl = lpr < kRBlock ? lpr : kRBlock;
+  const int mpb = kRBlock / gl;
+  const int blocks = (g->n_mols + mpb - 1) / mpb;
+  const bool bn = d_scale != nullptr;
+  const int n_deg = g->max_deg + 1;
+  TimedScope ts(GCMI_K_READOUT, st);
+#define LAUNCH_RO(VV, BB)                                                                        \
+  hipLaunchKernelGGL((readout_fwd_kernel<VV, BB>), dim3(blocks), dim3(kRBlock), 0, st, g->n_mols, \
+                     n_deg, g->d_mol_runs, d_x, ldx, n_feat, lpr, gl, d_scale, d_shift, act,     \
+                     d_out, ldo, d_arg)
+  if (V == 4) {
+    if (bn) LAUNCH_RO(4, true); else LAUNCH_RO(4, false);
+  } else {
+    if (bn) LAUNCH_RO(1, true); else LAUNCH_RO(1, false);
+  }
+#undef LAUNCH_RO
+  GCMI_CHECK_LAUNCH("readout_fwd");
+  return GCMI_OK;
+}
+
+int gcmi_readout_bwd(const gcmi_graph* g, const float* d_dout, int64_t lddo, const float* d_out,
+                     int64_t ldo, int32_t n_feat, int32_t act, const int32_t* d_arg,
+                     float* d_dx, int64_t lddx, void* stream) {
+  int rc = check_graph(g, false);
+  if (rc) return rc;
+  GCMI_CHECK_ARG(n_feat > 0 && lddo >= 2 * (int64_t)n_feat && lddx >= n_feat, "readout_bwd: bad n_feat/ld");
+  GCMI_CHECK_ARG(act == 0 || (d_out && ldo >= 2 * (int64_t)n_feat), "readout_bwd: saved output needed for tanh");
+  if (g->n_atoms == 0) return GCMI_OK;
+  GCMI_CHECK_ARG(d_dout && d_arg && d_dx && g->d_membership, "readout_bwd: NULL buffer");
+  hipStream_t st = (hipStream_t)stream;
+  const int V = vec_width(d_dx, lddx, n_feat);
+  const int lpr = n_feat / V;
+  const int64_t slots = (int64_t)g->n_atoms * lpr;
+  if (V == 4)
+    hipLaunchKernelGGL(readout_bwd_kernel<4>, dim3(grid_for(slots, kRBlock)), dim3(kRBlock), 0, st,
+                       slots, lpr, n_feat, g->d_membership, d_dout, lddo, d_out, ldo, act, d_arg,
+                       d_dx, lddx);
+  else
+    hipLaunchKernelGGL(readout_bwd_kernel<1>, dim3(grid_for(slots, kRBlock)), dim3(kRBlock), 0, st,
+                       slots, lpr, n_feat, g->d_membership, d_dout, lddo, d_out, ldo, act, d_arg,
+                       d_dx, lddx);
+  GCMI_CHECK_LAUNCH("readout_bwd");
+  return GCMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,167 @@
+"""BatchGraph: one collated batch of molecules resident on the GPU, in the form
+``struct gcmi_graph`` (include/gcmi.h) wants it.
+
+It is built either from the tensors the reference's layers receive
+(``[atom_features, deg_slice, membership, deg_adj_1..10]``,
+models/torch_models/layers.py:6182-6187) or straight from the native collation
+(``deepchem_amd.data.collate``).  The per-degree neighbour tables are stored
+back to back in one int32 ``col_idx`` array; the row pointer of this CSR is
+implicit in the degree blocks.
+"""
+import ctypes
+import weakref
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from deepchem_amd import _lib
+from deepchem_amd._lib import GCMI_MAX_DEG, GcmiGraph
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class BatchGraph:
+
+    def __init__(self, deg_counts: Sequence[int], col_idx: torch.Tensor, membership: torch.Tensor,
+                 n_mols: Optional[int] = None, mol_runs: Optional[torch.Tensor] = None,
+                 symmetric: Optional[bool] = None):
+        max_deg = len(deg_counts) - 1
+        if max_deg > GCMI_MAX_DEG:
+            raise ValueError("max degree %d > %d" % (max_deg, GCMI_MAX_DEG))
+        self.max_deg = max_deg
+        self.deg_counts = [int(c) for c in deg_counts]
+        self.deg_start = [0]
+        self.edge_start = [0]
+        for d, c in enumerate(self.deg_counts):
+            if c < 0:
+                raise ValueError("negative degree count")
+            self.deg_start.append(self.deg_start[-1] + c)
+            self.edge_start.append(self.edge_start[-1] + c * d)
+        self.n_atoms = self.deg_start[-1]
+        self.n_edges = self.edge_start[-1]
+        if col_idx.dtype != torch.int32 or not col_idx.is_cuda or not col_idx.is_contiguous():
+            raise ValueError("col_idx must be a contiguous int32 CUDA tensor")
+        if col_idx.numel() != self.n_edges:
+            raise ValueError("col_idx has %d entries, the degree blocks need %d" %
+                             (col_idx.numel(), self.n_edges))
+        if membership is not None:
+            if membership.dtype != torch.int32 or not membership.is_cuda or not membership.is_contiguous():
+                raise ValueError("membership must be a contiguous int32 CUDA tensor")
+            if membership.numel() != self.n_atoms:
+                raise ValueError("membership has %d entries for %d atoms" %
+                                 (membership.numel(), self.n_atoms))
+        self.col_idx = col_idx
+        self.membership = membership
+        self.device = col_idx.device
+        self.symmetric = symmetric
+        self.n_mols = None
+        self.mol_runs = None
+        self.c = GcmiGraph()
+        self.c.n_atoms = self.n_atoms
+        self.c.n_edges = self.n_edges
+        self.c.n_mols = 0
+        self.c.max_deg = max_deg
+        for d in range(GCMI_MAX_DEG + 2):
+            k = min(d, max_deg + 1)
+            self.c.deg_start[d] = self.deg_start[k]
+            self.c.edge_start[d] = self.edge_start[k]
+        self.c.d_col_idx = col_idx.data_ptr() if self.n_edges else None
+        self.c.d_membership = membership.data_ptr() if (membership is not None and self.n_atoms) else None
+        self.c.d_mol_runs = None
+        # segment tables of the per-degree GEMMs: segment d = rows of degree d
+        n_seg = max_deg + 1
+        self.seg_begin = (ctypes.c_int32 * n_seg)(*self.deg_start[:-1])
+        self.seg_end = (ctypes.c_int32 * n_seg)(*self.deg_start[1:])
+        if n_mols is not None:
+            self.set_mols(n_mols, mol_runs)
+
+    # ------------------------------------------------------------------ readout plan
+    def set_mols(self, n_mols: int, mol_runs: Optional[torch.Tensor] = None, check: bool = True):
+        """Attach the per-molecule row ranges GraphGather walks.  Without
+        ``mol_runs`` they are derived on the device from ``membership``."""
+        if self.n_mols == n_mols and self.mol_runs is not None:
+            return
+        if self.membership is None:
+            raise ValueError("membership is needed for the readout")
+        n_deg = self.max_deg + 1
+        self.c.n_mols = int(n_mols)
+        if mol_runs is None:
+            mol_runs = torch.empty(max(1, n_mols * n_deg * 2), dtype=torch.int32, device=self.device)
+            flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+            _lib.call("gcmi_build_mol_runs", ctypes.byref(self.c), ctypes.c_void_p(mol_runs.data_ptr()),
+                      ctypes.c_void_p(flag.data_ptr()), _stream())
+            if check and int(flag.item()) != 0:
+                raise ValueError(
+                    "membership must be ascending inside every degree block and < batch_size=%d "
+                    "(the layout ConvMol.agglomerate_mols produces)" % n_mols)
+        else:
+            if (mol_runs.dtype != torch.int32 or not mol_runs.is_cuda or
+                    mol_runs.numel() < n_mols * n_deg * 2):
+                raise ValueError("bad mol_runs tensor")
+        self.n_mols = int(n_mols)
+        self.mol_runs = mol_runs
+        self.c.d_mol_runs = mol_runs.data_ptr()
+
+    @property
+    def ref(self):
+        return ctypes.byref(self.c)
+
+    # ------------------------------------------------------------------ constructors
+    @staticmethod
+    def from_layer_inputs(deg_slice, membership, deg_adjs: Sequence[torch.Tensor],
+                          device: torch.device, validate: bool = True) -> "BatchGraph":
+        """From the reference layer inputs.  ``deg_slice[:,1].tolist()`` is the same
+        host read the reference does (layers.py:6199-6201)."""
+        counts = [int(v) for v in (deg_slice[:, 1].tolist() if torch.is_tensor(deg_slice) else
+                                   np.asarray(deg_slice)[:, 1].tolist())]
+        max_deg = len(counts) - 1
+        if len(deg_adjs) != max_deg:
+            raise ValueError("expected %d neighbour tables, got %d" % (max_deg, len(deg_adjs)))
+        parts = []
+        for d in range(1, max_deg + 1):
+            a = deg_adjs[d - 1]
+            if not torch.is_tensor(a):
+                a = torch.as_tensor(np.asarray(a))
+            if a.numel() != counts[d] * d:
+                raise ValueError("neighbour table of degree %d has shape %s, deg_slice says %d atoms"
+                                 % (d, tuple(a.shape), counts[d]))
+            if a.numel():
+                parts.append(a.reshape(-1).to(device=device, dtype=torch.int32))
+        col = torch.cat(parts) if parts else torch.empty(0, dtype=torch.int32, device=device)
+        n_atoms = sum(counts)
+        if validate and col.numel():
+            lo, hi = int(col.min().item()), int(col.max().item())
+            if lo < 0 or hi >= n_atoms:
+                raise ValueError("neighbour index outside [0, %d)" % n_atoms)
+        mem = None
+        if membership is not None:
+            if not torch.is_tensor(membership):
+                membership = torch.as_tensor(np.asarray(membership))
+            mem = membership.to(device=device, dtype=torch.int32).contiguous()
+        return BatchGraph(counts, col.contiguous(), mem)
+
+
+# A model forward hands the SAME deg_adj / membership tensor objects to five
+# layers in a row; key a tiny cache on object identity so the graph is built once.
+_cache: List = []
+
+
+def graph_for_layer_inputs(inputs: Sequence[torch.Tensor], device: torch.device) -> BatchGraph:
+    deg_slice, membership, deg_adjs = inputs[1], inputs[2], list(inputs[3:])
+    key_objs = [membership] + deg_adjs
+    for refs, versions, g in _cache:
+        if len(refs) == len(key_objs) and all(r() is o for r, o in zip(refs, key_objs)) and \
+                versions == [getattr(o, "_version", 0) for o in key_objs] and g.device == device:
+            return g
+    g = BatchGraph.from_layer_inputs(deg_slice, membership, deg_adjs, device)
+    try:
+        refs = [weakref.ref(o) for o in key_objs]
+        _cache.append((refs, [getattr(o, "_version", 0) for o in key_objs], g))
+        if len(_cache) > 4:
+            _cache.pop(0)
+    except TypeError:
+        pass
+    return g

@@ -1,0 +1,3 @@
+from deepchem_amd.models.torch_models.torch_model import TorchModel
+from deepchem_amd.models.torch_models.graphconvmodel import GraphConvModel, _GraphConvTorchModel
+from deepchem_amd.models.torch_models import layers

@@ -1,0 +1,268 @@
+"""``_GraphConvTorchModel`` / ``GraphConvModel`` with the reference's contract
+(deepchem/models/torch_models/graphconvmodel.py), running on libgcmi.so.
+
+Same constructor arguments, sub-module names (= checkpoint keys:
+``graph_convs.{i}.W_list.{k}``, ``batch_norms.{i}.*``, ``dense.*``,
+``reshape_dense.*`` | ``regression_dense.*`` | ``uncertainty_dense.*``), output
+lists, ``output_types``, losses, ``default_generator`` and errors.  A
+checkpoint written by either implementation loads into the other.
+
+What runs where: every tensor op of the forward and backward pass is a HIP
+kernel behind the C ABI (ops.py); BatchNorm is folded into its consumer
+(GraphPool / GraphGather read ``x*scale+shift`` on the fly), so the normalised
+activations are never written to HBM.  The ``nn.BatchNorm1d`` / ``nn.Linear``
+sub-modules only hold parameters and buffers under the reference's names.
+
+Reference behaviours kept on purpose: dropout is a no-op
+unless ``training=True`` is passed to the module directly
+(graphconvmodel.py:217/:226 vs torch_model.py:436); BatchNorm momentum 0.99 in
+torch semantics; hard-coded width 64 of BatchNorm / dense input (:151, :172);
+GraphGather emits ``batch_size`` rows and only predictions are trimmed to
+``n_samples``.  ``grad_mode="reference"`` (default) also keeps the autograd cut
+at GraphConv; ``grad_mode="full"`` trains every parameter.
+"""
+from collections.abc import Sequence as SequenceCollection
+from typing import Any, Callable, List, Optional, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from deepchem_amd import ops
+from deepchem_amd.feat.mol_graphs import ConvMol
+from deepchem_amd.graph import BatchGraph, graph_for_layer_inputs
+from deepchem_amd.metrics import to_one_hot
+from deepchem_amd.models.losses import L2Loss, SoftmaxCrossEntropy, _make_pytorch_shapes_consistent
+from deepchem_amd.models.torch_models import layers as torch_layers
+from deepchem_amd.models.torch_models.torch_model import TorchModel
+from deepchem_amd.utils.pytorch_utils import get_activation
+
+
+class TrimGraphOutput(nn.Module):
+    """Trim the fixed-size GraphGather batch to the real sample count
+    (graphconvmodel.py:21-33)."""
+
+    def forward(self, inputs):
+        n_samples = int(inputs[1])
+        return inputs[0][0:n_samples]
+
+
+class _BNApplyFn(torch.autograd.Function):
+    """Stand-alone BatchNorm1d (only used when dropout sits between it and its consumer)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rm, rv, training, eps, momentum):
+        x = ops.rowmajor(x)
+        if training:
+            mean, invstd, scale, shift = ops.bn_stats(x, gamma, beta, rm, rv, eps, momentum)
+        else:
+            mean = invstd = None
+            scale, shift = ops.bn_fold_eval(gamma, beta, rm, rv, eps)
+        ctx.training = training
+        ctx.save_for_backward(x, gamma, mean, invstd)
+        return ops.bn_apply(x, scale, shift)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise NotImplementedError("gradients through an eval-mode BatchNorm are not implemented")
+        x, gamma, mean, invstd = ctx.saved_tensors
+        dgamma, dbeta, dx = ops.bn_bwd(ops.rowmajor(dy), x, gamma, mean, invstd, True)
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+class _GraphConvTorchModel(nn.Module):
+    """Graph convolution network of Duvenaud et al. (graphconvmodel.py:36-249)."""
+
+    def __init__(self, n_tasks: int, number_input_features: List[int],
+                 graph_conv_layers: List[int] = [64, 64], dense_layer_size: int = 128, dropout=0.0,
+                 mode: str = "classification", number_atom_features: int = 75, n_classes: int = 2,
+                 batch_normalize: bool = True, uncertainty: bool = False, batch_size: int = 100,
+                 grad_mode: str = "reference"):
+        super(_GraphConvTorchModel, self).__init__()
+        if mode not in ['classification', 'regression']:
+            raise ValueError("mode must be either 'classification' or 'regression'")
+        self.n_tasks: int = n_tasks
+        self.n_classes: int = n_classes
+        self.mode: str = mode
+        self.uncertainty: bool = uncertainty
+        self.grad_mode = grad_mode
+        if not isinstance(dropout, SequenceCollection):
+            dropout = [dropout] * (len(graph_conv_layers) + 1)
+        if len(dropout) != len(graph_conv_layers) + 1:
+            raise ValueError('Wrong number of dropout probabilities provided')
+        if uncertainty:
+            if mode != "regression":
+                raise ValueError("Uncertainty is only supported in regression mode")
+            if any(d == 0.0 for d in dropout):
+                raise ValueError('Dropout must be included in every layer to predict uncertainty')
+        self.graph_convs = nn.ModuleList([
+            torch_layers.GraphConv(layer_size, input_size, activation_fn=get_activation('relu'),
+                                   grad_mode=grad_mode)
+            for layer_size, input_size in zip(graph_conv_layers, number_input_features)
+        ])
+        # the reference hard-codes width 64 here (:151, :172); same for the default
+        # [64, 64] layers, generalised to the actual layer widths otherwise
+        bn_widths = list(graph_conv_layers)
+        self.batch_norms = nn.ModuleList([
+            nn.BatchNorm1d(num_features=w, eps=1e-3, momentum=0.99, affine=True,
+                           track_running_stats=True) if batch_normalize else nn.Identity()
+            for w in bn_widths
+        ])
+        self.batch_norms.append(
+            nn.BatchNorm1d(num_features=dense_layer_size, eps=1e-3, momentum=0.99, affine=True,
+                           track_running_stats=True) if batch_normalize else nn.Identity())
+        self.dropouts = nn.ModuleList(
+            [nn.Dropout(rate) if rate > 0.0 else nn.Identity() for rate in dropout])
+        self.graph_pools = nn.ModuleList([torch_layers.GraphPool() for _ in graph_conv_layers])
+        self.dense = nn.Linear(graph_conv_layers[-1] if graph_conv_layers else 64, dense_layer_size)
+        self.dense_act = F.relu
+        self.graph_gather = torch_layers.GraphGather(batch_size=batch_size,
+                                                     activation_fn=get_activation('tanh'))
+        self.trim = TrimGraphOutput()
+        if self.mode == 'classification':
+            self.reshape_dense = nn.Linear(dense_layer_size * 2, n_tasks * n_classes)
+        else:
+            self.regression_dense = nn.Linear(dense_layer_size * 2, n_tasks)
+            if self.uncertainty:
+                self.uncertainty_dense = nn.Linear(dense_layer_size * 2, n_tasks)
+                self.uncertainty_trim = TrimGraphOutput()
+
+    def _bn_args(self, i: int):
+        bn = self.batch_norms[i]
+        if isinstance(bn, nn.BatchNorm1d):
+            training = self.training and bn.training
+            if training:
+                bn.num_batches_tracked += 1
+            return (bn.weight, bn.bias, bn.running_mean, bn.running_var), True, training, bn.eps, bn.momentum
+        return (None, None, None, None), False, False, 0.0, 0.0
+
+    def forward(self, inputs, training=False) -> List[torch.Tensor]:
+        """inputs = [atom_features, degree_slice, membership, n_samples, deg_adj_1..10]
+        (graphconvmodel.py:202-208), or a ``deepchem_amd.data.collate.DeviceBatch``."""
+        graph = getattr(inputs, "graph", None)
+        if graph is not None:  # pre-collated batch already resident on the GPU
+            atom_features, n_samples = inputs.atom_features, inputs.n_samples
+        else:
+            atom_features = inputs[0]
+            n_samples = inputs[3]
+            if not atom_features.is_cuda:
+                raise ops._lib.GcmiError(
+                    "GraphConvModel: inputs must be CUDA tensors (no CPU path in deepchem_amd)")
+            graph = graph_for_layer_inputs([inputs[0], inputs[1], inputs[2]] + list(inputs[4:]),
+                                           atom_features.device)
+        n_samples = int(n_samples)
+        x = atom_features.to(torch.float32)
+        for i in range(len(self.graph_convs)):
+            gc = self.graph_convs[i]([x, None, None], graph=graph)
+            bn_t, has_bn, bn_train, eps, mom = self._bn_args(i)
+            if training and not isinstance(self.dropouts[i], nn.Identity):
+                if has_bn:
+                    gc = _BNApplyFn.apply(gc, *bn_t, bn_train, eps, mom)
+                gc = self.dropouts[i](gc)
+                x = ops.PoolFn.apply(gc, None, None, None, None, graph, False, False, 0.0, 0.0)
+            else:
+                x = ops.PoolFn.apply(gc, *bn_t, graph, has_bn, bn_train, eps, mom)
+        dense = ops.LinearFn.apply(x, self.dense.weight, self.dense.bias, True)
+        bn_t, has_bn, bn_train, eps, mom = self._bn_args(len(self.graph_convs))
+        batch_size = self.graph_gather.batch_size
+        assert batch_size > 1, "graph_gather requires batches larger than 1"
+        if training and not isinstance(self.dropouts[-1], nn.Identity):
+            if has_bn:
+                dense = _BNApplyFn.apply(dense, *bn_t, bn_train, eps, mom)
+            dense = self.dropouts[-1](dense)
+            neural_fingerprint = ops.ReadoutFn.apply(dense, None, None, None, None, graph, batch_size,
+                                                     False, False, 0.0, 0.0, True)
+        else:
+            neural_fingerprint = ops.ReadoutFn.apply(dense, *bn_t, graph, batch_size, has_bn, bn_train,
+                                                     eps, mom, True)
+        if self.mode == 'classification':
+            logits = ops.LinearFn.apply(neural_fingerprint, self.reshape_dense.weight,
+                                        self.reshape_dense.bias, False)
+            logits = torch.reshape(logits, (-1, self.n_tasks, self.n_classes))
+            logits = self.trim([logits, n_samples])
+            output = ops.SoftmaxFn.apply(logits)
+            outputs = [output, logits, neural_fingerprint]
+        else:
+            output = ops.LinearFn.apply(neural_fingerprint, self.regression_dense.weight,
+                                        self.regression_dense.bias, False)
+            output = self.trim([output, n_samples])
+            if self.uncertainty:
+                log_var = ops.LinearFn.apply(neural_fingerprint, self.uncertainty_dense.weight,
+                                             self.uncertainty_dense.bias, False)
+                log_var = self.uncertainty_trim([log_var, n_samples])
+                var = torch.exp(log_var)
+                outputs = [output, var, output, log_var, neural_fingerprint]
+            else:
+                outputs = [output, neural_fingerprint]
+        return outputs
+
+
+class GraphConvModel(TorchModel):
+    """Graph convolutional model with the ``dc.models.torch_models.GraphConvModel``
+    interface (graphconvmodel.py:252-422).
+
+    >>> model = GraphConvModel(12, number_input_features=[75, 64], batch_size=100,
+    ...                        mode='classification')                      # doctest: +SKIP
+    >>> loss = model.fit(dataset, nb_epoch=10)                             # doctest: +SKIP
+    """
+
+    def __init__(self, n_tasks: int, number_input_features: List[int],
+                 graph_conv_layers: List[int] = [64, 64], dense_layer_size: int = 128,
+                 dropout: float = 0.0, mode: str = "classification", number_atom_features: int = 75,
+                 n_classes: int = 2, batch_size: int = 100, batch_normalize: bool = True,
+                 uncertainty: bool = False, grad_mode: str = "reference", **kwargs):
+        self.mode: str = mode
+        self.n_tasks: int = n_tasks
+        self.n_classes: int = n_classes
+        self.batch_size: int = batch_size
+        self.uncertainty: bool = uncertainty
+        model = _GraphConvTorchModel(n_tasks, graph_conv_layers=graph_conv_layers,
+                                     number_input_features=number_input_features,
+                                     dense_layer_size=dense_layer_size, dropout=dropout, mode=mode,
+                                     number_atom_features=number_atom_features, n_classes=n_classes,
+                                     batch_normalize=batch_normalize, uncertainty=uncertainty,
+                                     batch_size=batch_size, grad_mode=grad_mode)
+        loss: Union[SoftmaxCrossEntropy, L2Loss, Callable[[Any, Any, Any], Any]]
+        if mode == "classification":
+            output_types = ['prediction', 'loss', 'embedding']
+            loss = SoftmaxCrossEntropy()
+        else:
+            if self.uncertainty:
+                output_types = ['prediction', 'variance', 'loss', 'loss', 'embedding']
+
+                def loss(outputs, labels, weights):
+                    output, labels = _make_pytorch_shapes_consistent(outputs[0], labels[0])
+                    losses = torch.square(output - labels) / torch.exp(outputs[1]) + outputs[1]
+                    w = weights[0]
+                    if len(w.shape) < len(losses.shape):
+                        shape = tuple(w.shape)
+                        w = torch.reshape(w, shape + (1,) * (len(losses.shape) - len(w.shape)))
+                    return torch.mean(losses * w)
+            else:
+                output_types = ['prediction', 'embedding']
+                loss = L2Loss()
+        super(GraphConvModel, self).__init__(model, loss, output_types=output_types,
+                                             batch_size=batch_size, **kwargs)
+
+    def default_generator(self, dataset, epochs: int = 1, mode: str = 'fit',
+                          deterministic: bool = True, pad_batches: bool = True):
+        """Batches as ``([atom_features, deg_slice, membership, n_samples, adj_1..adj_10],
+        [y], [w])`` (graphconvmodel.py:382-422)."""
+        for epoch in range(epochs):
+            for (X_b, y_b, w_b, ids_b) in dataset.iterbatches(batch_size=self.batch_size,
+                                                              deterministic=deterministic,
+                                                              pad_batches=pad_batches):
+                if y_b is not None and self.mode == 'classification' and not (mode == 'predict'):
+                    y_b = to_one_hot(y_b.flatten(), self.n_classes).reshape(
+                        -1, self.n_tasks, self.n_classes)
+                multiConvMol = ConvMol.agglomerate_mols(X_b)
+                n_samples = np.array(X_b.shape[0])
+                inputs = [
+                    multiConvMol.get_atom_features(), multiConvMol.deg_slice,
+                    np.array(multiConvMol.membership), n_samples
+                ]
+                for i in range(1, len(multiConvMol.get_deg_adjacency_lists())):
+                    inputs.append(multiConvMol.get_deg_adjacency_lists()[i])
+                yield (inputs, [y_b], [w_b])

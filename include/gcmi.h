@@ -1,0 +1,239 @@
+/*
+ * gcmi.h -- C ABI of libgcmi.so: the MI355X (gfx950) graph-convolution hot path.
+ *
+ * The reference (DeepChem, pure Python) has no FFI for this path; its boundary
+ * is a Python class contract.  These entry points are what the
+ * reference's layers would bind if they had one -- one per reference function
+ * on the hot path -- and what deepchem_amd's host-side mirror calls through
+ * ctypes.  Reference citations are relative to /root/reference/deepchem/.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / STL types.
+ *   - every pointer named d_* is DEVICE memory, borrowed for the call; all
+ *     other pointers are host memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  All
+ *     work is enqueued on it; nothing synchronises, allocates or frees, so
+ *     every entry point can be captured into a hipGraph.
+ *   - return 0 on success, a negative gcmi_status otherwise; the message of
+ *     the last failure on the calling thread: gcmi_last_error().
+ *   - feature matrices are row-major float32 with an explicit leading
+ *     dimension (ld, in floats).  When ld % 4 == 0 and the base is 16-byte
+ *     aligned the kernels move 16 B per lane; otherwise 4 B per lane.
+ *   - thread-compatible: no global mutable state except the per-thread error
+ *     string.
+ */
+#ifndef GCMI_H
+#define GCMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCMI_VERSION 100 /* 0.1.0 */
+#define GCMI_MAX_DEG 10  /* degrees 0..10: ConvMol default, feat/mol_graphs.py:48 */
+
+typedef enum gcmi_status {
+  GCMI_OK = 0,
+  GCMI_ERR_ARG = -1,    /* bad argument (null pointer, negative size, shape mismatch) */
+  GCMI_ERR_LAUNCH = -2, /* HIP launch / runtime error */
+  GCMI_ERR_UNSUPPORTED = -3
+} gcmi_status;
+
+/*
+ * One collated batch of molecules in the layout ConvMol.agglomerate_mols
+ * produces (feat/mol_graphs.py:256-349): atoms sorted by (degree, molecule),
+ * so the atoms of degree d are the contiguous rows
+ * [deg_start[d], deg_start[d+1]) and each of them has exactly d neighbours.
+ * The per-degree (n_d, d) int32 tables deg_adj_lists[1..max_deg] are stored
+ * back to back in ONE array d_col_idx; the table of degree d starts at
+ * edge_start[d].  That is a CSR whose row pointer is implicit:
+ *   row_ptr(i) = edge_start[d] + (i - deg_start[d]) * d.
+ */
+typedef struct gcmi_graph {
+  int32_t n_atoms;                      /* N                                        */
+  int32_t n_edges;                      /* E = sum_d d * n_d  (directed)            */
+  int32_t n_mols;                       /* B: rows GraphGather emits (batch_size)   */
+  int32_t max_deg;                      /* <= GCMI_MAX_DEG                          */
+  int32_t deg_start[GCMI_MAX_DEG + 2];  /* [max_deg+1] = N                          */
+  int32_t edge_start[GCMI_MAX_DEG + 2]; /* [max_deg+1] = E                          */
+  const int32_t* d_col_idx;             /* E neighbour rows                         */
+  const int32_t* d_membership;          /* N: molecule of every atom, ascending
+                                           inside every degree block               */
+  const int32_t* d_mol_runs;            /* n_mols*(max_deg+1)*2: per molecule and
+                                           degree the row range [begin,end) of its
+                                           atoms; built by gcmi_build_mol_runs     */
+} gcmi_graph;
+
+int gcmi_version(void);
+const char* gcmi_last_error(void);
+
+/* ---------------------------------------------------------------- host side
+ * gcmi_collate: ConvMol.agglomerate_mols (feat/mol_graphs.py:256-349) over a
+ * packed molecule set, plus the flattening the kernels want.  Host only.
+ *   in : atom_features [A x n_feat] (molecule-major), atom_ptr [n_set+1],
+ *        adj_ptr [A+1], adj_idx [nnz] (molecule-local ids), sel [n_sel]
+ *        molecules to collate, in order (repeats allowed = pad_batch tiling,
+ *        data/datasets.py:204-216).
+ *   out: out_features [N x out_ld] (rows in batch order, columns >= n_feat
+ *        zero), out_membership [N], out_col_idx [E], out_mol_runs
+ *        [n_sel*(max_deg+1)*2], *graph (counts and offsets filled, device
+ *        pointers left NULL).  Capacities are checked.
+ */
+int gcmi_collate_sizes(const int64_t* atom_ptr, const int64_t* adj_ptr, const int64_t* sel,
+                       int64_t n_sel, int64_t* out_n_atoms, int64_t* out_n_edges);
+int gcmi_collate(const float* atom_features, int64_t n_feat, const int64_t* atom_ptr,
+                 const int64_t* adj_ptr, const int32_t* adj_idx, const int64_t* sel,
+                 int64_t n_sel, int32_t max_deg, float* out_features, int64_t out_ld,
+                 int64_t cap_atoms, int32_t* out_membership, int32_t* out_col_idx,
+                 int64_t cap_edges, int32_t* out_mol_runs, gcmi_graph* graph);
+
+/* ---------------------------------------------------------------- graph plan
+ * d_mol_runs from d_membership (device).  d_flag (1 int, device) is set to 1
+ * when membership is NOT ascending inside a degree block or out of range.   */
+int gcmi_build_mol_runs(const gcmi_graph* g, int32_t* d_mol_runs, int32_t* d_flag, void* stream);
+
+/* ---------------------------------------------------------------- K1 gather-sum
+ * GraphConv.sum_neigh (models/torch_models/layers.py:6236-6246):
+ *   s[i,:] = sum_{j<deg(i)} x[col_idx[row_ptr(i)+j], :]   (degree-0 rows: 0)
+ * Backward of the gather (dx[k,:] += ds[i,:] for every edge i->k) as
+ * gcmi_scatter_add (float atomics; any adjacency).  For a symmetric adjacency
+ * (every bond listed from both ends: ConvMol) the same result is
+ * gcmi_gather_sum_fwd applied to ds -- deterministic, no atomics.             */
+int gcmi_gather_sum_fwd(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t n_feat,
+                        float* d_s, int64_t lds, int32_t accumulate /* s += instead of s = */,
+                        void* stream);
+int gcmi_scatter_add(const gcmi_graph* g, const float* d_ds, int64_t ldds, int32_t n_feat,
+                     float* d_dx, int64_t lddx, void* stream);
+
+/* ---------------------------------------------------------------- K3 gather-max
+ * GraphPool.forward (layers.py:6319-6367): out[i,:] = max over {x[i], x[nbrs]}
+ * with candidates ordered self, nbr_0, nbr_1, ... and the FIRST maximum winning
+ * (torch.max(dim) tie rule).  d_arg[i,f] (uint8, ld = n_feat) records the
+ * winner: 0 = self, j+1 = neighbour j.  If d_scale/d_shift are non-NULL the
+ * candidates are x*scale[f]+shift[f] (the preceding BatchNorm1d folded in).
+ * Backward: dx[winner row, f] += dout[i,f] (atomics), dx pre-zeroed by caller. */
+int gcmi_gather_max_fwd(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t n_feat,
+                        const float* d_scale, const float* d_shift, float* d_out, int64_t ldo,
+                        uint8_t* d_arg, void* stream);
+int gcmi_gather_max_bwd(const gcmi_graph* g, const float* d_dout, int64_t lddo, int32_t n_feat,
+                        const uint8_t* d_arg, float* d_dx, int64_t lddx, void* stream);
+
+/* ---------------------------------------------------------------- K4 readout
+ * GraphGather.forward (layers.py:6450-6479) = unsorted_segment_sum
+ * (utils/pytorch_utils.py:20-74) ++ unsorted_segment_max (:473-528) (+tanh):
+ *   out[b, 0:F]  = act(sum_{i in mol b} x[i,:]),  out[b, F:2F] = act(max ...)
+ * n_mols rows always; an empty molecule gives (0, -inf) -> tanh -> (0, -1).
+ * Optional folded BatchNorm (scale/shift) as above.  act: 0 none, 1 tanh.
+ * d_arg [n_mols x F] int32: row of the first maximum (-1 for empty).
+ * Backward: dx[i,:] = dsum[b,:] + (i == arg[b,:]) * dmax[b,:], with the tanh
+ * derivative taken from the saved output.                                     */
+int gcmi_readout_fwd(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t n_feat,
+                     const float* d_scale, const float* d_shift, int32_t act, float* d_out,
+                     int64_t ldo, int32_t* d_arg, void* stream);
+int gcmi_readout_bwd(const gcmi_graph* g, const float* d_dout, int64_t lddo, const float* d_out,
+                     int64_t ldo, int32_t n_feat, int32_t act, const int32_t* d_arg,
+                     float* d_dx, int64_t lddx, void* stream);
+
+/* ---------------------------------------------------------------- K2 batch norm
+ * nn.BatchNorm1d(F, eps=1e-3, momentum=0.99) over the atom rows
+ * (models/torch_models/graphconvmodel.py:150-165, applied :215-216, :224-225).
+ * gcmi_bn_stats: training statistics of x[n_rows x F] -> d_mean, d_invstd,
+ *   folded d_scale = gamma*invstd, d_shift = beta - mean*scale; running stats
+ *   updated with torch semantics (running = (1-m)*running + m*batch; unbiased
+ *   variance into running_var).  d_acc: 2*F doubles of scratch.
+ * gcmi_bn_fold_eval: scale/shift from the running statistics (eval mode).
+ * gcmi_bn_apply: y = x*scale + shift (only when the consumer cannot fold it).
+ * gcmi_bn_bwd: given dy, x and the saved mean/invstd: dgamma, dbeta and
+ *   (if d_dx) dx = gamma*invstd*(dy - dbeta/n - xhat*dgamma/n).               */
+int gcmi_bn_stats(const float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat,
+                  const float* d_gamma, const float* d_beta, float eps, float momentum,
+                  float* d_running_mean, float* d_running_var, float* d_mean, float* d_invstd,
+                  float* d_scale, float* d_shift, double* d_acc, void* stream);
+int gcmi_bn_fold_eval(const float* d_gamma, const float* d_beta, const float* d_running_mean,
+                      const float* d_running_var, float eps, int32_t n_feat, float* d_scale,
+                      float* d_shift, void* stream);
+int gcmi_bn_apply(const float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat,
+                  const float* d_scale, const float* d_shift, float* d_y, int64_t ldy,
+                  void* stream);
+int gcmi_bn_bwd(const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx, int64_t n_rows,
+                int32_t n_feat, const float* d_gamma, const float* d_mean,
+                const float* d_invstd, float* d_dgamma, float* d_dbeta, float* d_dx,
+                int64_t lddx, double* d_acc, void* stream);
+
+/* ---------------------------------------------------------------- GEMMs (MFMA, exact fp32)
+ * Row-segmented affine map on v_mfma_f32_32x32x2_f32:
+ *   for every segment s (rows [seg_begin[s], seg_end[s])), s < n_seg <= 16:
+ *     out[rows,:] = act( a1[rows,:k1] . W1_s + a2[rows,:k2] . W2_s + bias_s )
+ * W1_s is the k1 x n_out row-major block at d_w1 + w1_off[s] (floats); a
+ * negative offset drops that term for the segment.  a2/w2 may be NULL.
+ * bias_s = d_bias + bias_off[s] (n_out floats; negative offset: none).
+ * act: 0 none, 1 relu.  trans_w != 0: the blocks are stored n_out x k
+ * (nn.Linear layout, or the transposed product of a backward pass).
+ * seg_begin, seg_end, *_off are HOST arrays of n_seg entries.
+ *
+ * Uses: GraphConv (layers.py:6202-6231: per degree S_d.W_rel + X_d.W_self + both
+ * biases, relu; 11 segments, degree 0 without the S term), the atom-level
+ * dense layer (graphconvmodel.py:222-223), the task heads
+ * (graphconvmodel.py:230-247), and every data-gradient product of the
+ * backward pass (dA = dOut . W^T is the same map with trans_w flipped).       */
+int gcmi_seg_gemm(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_end,
+                  const float* d_a1, int64_t lda1, int32_t k1, const float* d_w1,
+                  const int64_t* w1_off, const float* d_a2, int64_t lda2, int32_t k2,
+                  const float* d_w2, const int64_t* w2_off, const float* d_bias,
+                  const int64_t* bias_off, int32_t n_out, int32_t trans_w, int32_t act,
+                  float* d_out, int64_t ldo, void* stream);
+/* dW_s += a[rows_s,:k]^T . g[rows_s,:n]  (block at d_dw + dw_off[s], k x n, or
+ * n x k when trans_w) and dbias_s += column sums of g[rows_s] (d_dbias may be
+ * NULL).  Accumulates with float atomics into caller-zeroed buffers.          */
+int gcmi_seg_gemm_wgrad(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_end,
+                        const float* d_a, int64_t lda, int32_t k, const float* d_g, int64_t ldg,
+                        int32_t n, float* d_dw, const int64_t* dw_off, float* d_dbias,
+                        const int64_t* dbias_off, int32_t trans_w, void* stream);
+/* elementwise g *= (y > 0): ReLU derivative, in place on g. */
+int gcmi_relu_bwd(float* d_g, int64_t ldg, const float* d_y, int64_t ldy, int64_t n_rows,
+                  int32_t n_feat, void* stream);
+
+/* ---------------------------------------------------------------- loss
+ * SoftmaxCrossEntropy (models/losses.py:251-259) / L2Loss (:85-94) through
+ * _StandardLoss (models/torch_models/torch_model.py:1275-1294):
+ *   loss = mean over (n_rows, n_tasks) of  w[b,t] * l[b,t]
+ *   kind 0: l = -sum_c y[b,t,c] * log_softmax(logits[b,t,:])[c]
+ *   kind 1: l = (out[b,t] - y[b,t])^2
+ * Writes *d_loss (float, device) and d_dlogits (same shape as logits).
+ * d_probs (may be NULL): softmax(logits) (the model's 'prediction' output,
+ * graphconvmodel.py:235).  d_acc: 1 double of scratch.                        */
+int gcmi_loss_fwd_bwd(int32_t kind, const float* d_logits, const float* d_labels,
+                      const float* d_weights, int64_t n_rows, int32_t n_tasks,
+                      int32_t n_classes, float* d_loss, float* d_dlogits, float* d_probs,
+                      double* d_acc, void* stream);
+int gcmi_softmax(const float* d_logits, int64_t n_rows_tasks, int32_t n_classes, float* d_probs,
+                 void* stream);
+
+/* ---------------------------------------------------------------- optimizer
+ * torch.optim.Adam(lr, betas, eps, weight_decay=0) (models/optimizers.py:231-241)
+ * on one flat range.  step = 1-based step count after this update.            */
+int gcmi_adam_step(float* d_param, const float* d_grad, float* d_m, float* d_v, int64_t n,
+                   float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
+
+/* ---------------------------------------------------------------- measurement
+ * Optional per-kernel timing with hipEvents recorded on `stream` around the
+ * launches of one kernel family (bench.py roofline).  id: see GCMI_K_*.       */
+enum {
+  GCMI_K_GATHER_SUM = 0,
+  GCMI_K_GATHER_MAX = 1,
+  GCMI_K_READOUT = 2,
+  GCMI_K_SEG_GEMM = 3,
+  GCMI_K_WGRAD = 4,
+  GCMI_K_COUNT = 8
+};
+int gcmi_timing_enable(int32_t kernel_id, int32_t on);
+/* Synchronises the recorded events; returns launches and total milliseconds. */
+int gcmi_timing_read(int32_t kernel_id, int64_t* n_launches, double* total_ms, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCMI_H */

@@ -1,0 +1,296 @@
+"""GPU parity at layer and model level: the drop-in classes of deepchem_amd
+against (a) the reference's own golden assets, (b) fixtures produced by running
+the reference (tests/golden/model_*.npz) and (c) the oracle, in both gradient
+modes.  Tolerance 1e-4 relative on fp32 (BASELINE.json north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import graphconv_oracle as O
+from tests.test_oracle_golden import MODEL_FIXTURES, carbon
+from tests.util import cfg_from, load_golden, oracle_convmols, oracle_fit, packed_from, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def product_convmols(packed):
+    from deepchem_amd.feat.mol_graphs import convmols_from_packed
+    return convmols_from_packed(packed)
+
+
+def ccc_and_c_args(with_n_samples=False):
+    from deepchem_amd.feat.mol_graphs import ConvMol
+    mols = [ConvMol(np.stack([carbon(1, 3), carbon(2, 2), carbon(1, 3)]), [[1], [0, 2], [1]]),
+            ConvMol(np.stack([carbon(0, 4)]), [[]])]
+    multi = ConvMol.agglomerate_mols(mols)
+    dev = torch.device(DEV)
+    args = [torch.from_numpy(multi.get_atom_features().astype(np.float32)).to(dev),
+            torch.from_numpy(multi.deg_slice), torch.from_numpy(multi.membership).to(dev)]
+    if with_n_samples:
+        args.append(torch.tensor(2))
+    return args + [torch.from_numpy(a).to(dev) for a in multi.get_deg_adjacency_lists()[1:]]
+
+
+# ------------------------------------------------------------------ the reference's own tests
+def test_torch_graph_conv_asset():
+    """test_layers.py:1456-1493."""
+    from deepchem_amd.models.torch_models import layers as torch_layers
+    a = load_golden("ref_assets.npz")
+    args = ccc_and_c_args()
+    layer = torch_layers.GraphConv(2, number_input_features=75).to(DEV)
+    layer.W_list = nn.ParameterList([nn.Parameter(torch.tensor(k, device=DEV)) for k in a["graphconvlayer_weights"]])
+    layer.b_list = nn.ParameterList([nn.Parameter(torch.tensor(k, device=DEV)) for k in a["graphconvlayer_biases"]])
+    result = layer(args)
+    assert np.allclose(result.detach().cpu().numpy(), a["graphconvlayer_result"], atol=1e-4)
+    assert result.shape == (4, 2)
+    assert len(list(layer.parameters())) == 2 * (2 * layer.max_degree + (1 - layer.min_degree))
+
+
+def test_torch_graph_pool_asset():
+    """test_layers.py:1496-1519."""
+    from deepchem_amd.models.torch_models import layers as torch_layers
+    a = load_golden("ref_assets.npz")
+    result = torch_layers.GraphPool()(ccc_and_c_args())
+    assert np.allclose(result.detach().cpu().numpy(), a["graphpoollayer_result"], atol=1e-4)
+    assert result.shape[0] == 4
+
+
+def test_torch_graph_gather_asset():
+    """test_layers.py:1522-1546."""
+    from deepchem_amd.models.torch_models import layers as torch_layers
+    a = load_golden("ref_assets.npz")
+    result = torch_layers.GraphGather(2)(ccc_and_c_args())
+    assert np.allclose(result.detach().cpu().numpy(), a["graphgatherlayer_result"], atol=1e-4)
+    assert result.shape == (2, 150)
+
+
+def test_graph_conv_classification_asset():
+    """test_graphconv_torchmodel.py:14-93."""
+    from deepchem_amd.models.torch_models import _GraphConvTorchModel
+    a = load_golden("ref_assets.npz")
+    model_p = _GraphConvTorchModel(2, graph_conv_layers=[64, 64], number_input_features=[75, 64],
+                                   dense_layer_size=128, dropout=0.0, mode="classification",
+                                   number_atom_features=75, n_classes=2, batch_normalize=False,
+                                   uncertainty=False, batch_size=10).to(DEV)
+    for li in (0, 1):
+        model_p.graph_convs[li].W_list = nn.ParameterList(
+            [nn.Parameter(torch.tensor(k, device=DEV)) for k in a["graphconvlayer%d_weights" % li]])
+        model_p.graph_convs[li].b_list = nn.ParameterList(
+            [nn.Parameter(torch.tensor(k, device=DEV)) for k in a["graphconvlayer%d_biases" % li]])
+    model_p.dense.weight.data = torch.from_numpy(np.transpose(a["dense_weights"]).copy()).to(DEV)
+    model_p.dense.bias.data = torch.from_numpy(a["dense_biases"]).to(DEV)
+    model_p.reshape_dense.weight.data = torch.from_numpy(np.transpose(a["reshapedense_weights"]).copy()).to(DEV)
+    model_p.reshape_dense.bias.data = torch.from_numpy(a["reshapedense_biases"]).to(DEV)
+    result_p = model_p(ccc_and_c_args(with_n_samples=True))
+    assert len(result_p) == 3
+    assert np.allclose(result_p[0].detach().cpu().numpy(), a["graphconvmodel_output_classification"], atol=1e-4)
+    assert np.allclose(result_p[1].detach().cpu().numpy(), a["graphconvmodel_logits_classification"], atol=1e-4)
+    assert np.allclose(result_p[2].detach().cpu().numpy(), a["graphconvmodel_neural_classification"], atol=1e-4)
+
+
+def test_segment_utils_assets():
+    """utils/test/test_pytorch_utils.py:12-33, :122-140 (unsorted ids)."""
+    from deepchem_amd.utils.pytorch_utils import unsorted_segment_max, unsorted_segment_sum
+    a = load_golden("ref_assets.npz")
+    ids = torch.tensor([0, 1, 0]).to(DEV)
+    data = torch.tensor([[1., 2, 3, 4], [5, 6, 7, 8], [4, 3, 2, 1]]).to(DEV)
+    assert np.allclose(unsorted_segment_sum(data, ids, 2).cpu().numpy(), a["result_segment_sum"], atol=1e-4)
+    assert np.allclose(unsorted_segment_max(data, ids, 2).cpu().numpy(), a["result_segment_max"], atol=1e-4)
+
+
+def test_layers_refuse_cpu_and_small_batch():
+    from deepchem_amd._lib import GcmiError
+    from deepchem_amd.models.torch_models import layers as torch_layers
+    args = [t.cpu() for t in ccc_and_c_args()]
+    with pytest.raises(GcmiError):
+        torch_layers.GraphPool()(args)
+    with pytest.raises(AssertionError):
+        torch_layers.GraphGather(1)(ccc_and_c_args())
+
+
+# ------------------------------------------------------------------ fixtures from the reference
+def build_model(g, grad_mode, **kw):
+    from deepchem_amd.models.torch_models import GraphConvModel
+    cfg = cfg_from(g)
+    model = GraphConvModel(cfg.n_tasks, number_input_features=[75, 64], dense_layer_size=cfg.dense_layer_size,
+                           dropout=0.25 if cfg.uncertainty else 0.0, mode=cfg.mode,
+                           batch_size=cfg.batch_size, batch_normalize=cfg.batch_normalize,
+                           uncertainty=cfg.uncertainty, grad_mode=grad_mode, learning_rate=1e-3,
+                           device=torch.device(DEV), **kw)
+    state = O.init_state(cfg, int(g["cfg_seed"]))
+    res = model.model.load_state_dict({k: v.clone() for k, v in state.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys  # same checkpoint keys as the reference
+    return model, cfg, state
+
+
+def dataset_from(g):
+    from deepchem_amd.data import NumpyDataset
+    packed = packed_from(g)
+    return NumpyDataset(product_convmols(packed), g["in_y"], g["in_w"]), packed
+
+
+@pytest.mark.parametrize("name", MODEL_FIXTURES)
+def test_first_batch_outputs_loss_grads(name):
+    g = load_golden("model_%s.npz" % name)
+    for gm in ("reference", "full"):
+        model, cfg, state = build_model(g, gm)
+        ds, _ = dataset_from(g)
+        model._ensure_built()
+        batch = next(iter(model.default_generator(ds, epochs=1, deterministic=True, pad_batches=True)))
+        inputs, labels, weights = model._prepare_batch(batch)
+        assert int(inputs[0].shape[0]) == int(g["b0_n_atoms"])
+        assert np.array_equal(inputs[1].cpu().numpy(), g["b0_deg_slice"])
+        assert np.array_equal(inputs[2].cpu().numpy(), g["b0_membership"])
+        if gm == "reference":
+            model.model.eval()
+            with torch.no_grad():
+                ev = model.model(inputs)
+            for i, t in enumerate(ev):
+                assert rel_err(t.cpu().numpy(), g["eval_out%d" % i]) < 1e-4, ("eval", i)
+        model.model.train()
+        outs = model.model(inputs)
+        if gm == "reference":
+            for i, t in enumerate(outs):
+                assert rel_err(t.detach().cpu().numpy(), g["train_out%d" % i]) < 1e-4, ("train", i)
+        louts = [outs[i] for i in model._loss_outputs]
+        loss = model._loss_fn(louts, labels, weights)
+        loss.backward()
+        assert abs(float(loss) - float(g["%s_b0_loss" % gm])) < 1e-4 * max(1.0, abs(float(loss)))
+        keys = set(g["%s_grad_keys" % gm].tolist())
+        got = {k: p.grad for k, p in model.model.named_parameters() if p.grad is not None}
+        assert set(got) == keys, (gm, set(got) ^ keys)
+        for k in keys:
+            full = "%s_grad__%s" % (gm, k)
+            gk = got[k].cpu().numpy()
+            if full in g.files:
+                scale = max(np.abs(g[full]).max(), 1e-6)
+                assert np.abs(gk - g[full]).max() / scale < 1e-3, (gm, k)
+            else:
+                from oracle.gen_golden import sample
+                exp = g["%s_gradsample__%s" % (gm, k)]
+                assert np.abs(sample(gk) - exp).max() / max(np.abs(exp).max(), 1e-6) < 1e-3, (gm, k)
+        # BatchNorm running statistics after one training forward
+        tr = O.OracleTrainer(cfg, state, grad_mode=gm)
+        cpu_inputs = [t.cpu() for t in inputs]
+        tr.loss(cpu_inputs, labels[0].cpu(), weights[0].cpu())
+        for k, v in model.model.state_dict().items():
+            if "running" in k:
+                assert rel_err(v.cpu().numpy(), tr.state[k].detach().numpy()) < 1e-4, k
+            if k.endswith("num_batches_tracked"):
+                assert int(v) == int(tr.state[k])
+
+
+@pytest.mark.parametrize("name", MODEL_FIXTURES)
+@pytest.mark.parametrize("gm", ["reference", "full"])
+def test_fit_trajectory_predict_embedding(name, gm):
+    g = load_golden("model_%s.npz" % name)
+    model, cfg, state = build_model(g, gm)
+    ds, _ = dataset_from(g)
+    step_losses = []
+    model.fit(ds, nb_epoch=2, deterministic=True, checkpoint_interval=0,
+              callbacks=[lambda m, s, iteration_loss=None: step_losses.append(float(iteration_loss))])
+    exp = g["%s_fit_losses" % gm]
+    assert len(step_losses) == len(exp)
+    assert np.allclose(step_losses, exp, rtol=5e-3, atol=1e-5), (step_losses, exp)
+    changed = set(g["%s_fit_changed_keys" % gm].tolist())
+    sd = model.model.state_dict()
+    for k, v in sd.items():
+        v = v.cpu().numpy()
+        if k not in changed:
+            assert np.array_equal(v, state[k].numpy()), k  # untouched parameters stay bit-identical
+            continue
+        full = "%s_fit_state__%s" % (gm, k)
+        if full in g.files:
+            e = g[full]
+            assert np.abs(v - e).max() <= 5e-3 * max(np.abs(e).max(), 1e-3), k
+        else:
+            from oracle.gen_golden import sample
+            e = g["%s_fit_statesample__%s" % (gm, k)]
+            assert np.abs(sample(v) - e).max() <= 5e-3 * max(np.abs(e).max(), 1e-3), k
+    pred = model.predict(ds)
+    assert pred.shape == g["%s_predict" % gm].shape  # ragged last batch trimmed
+    assert np.abs(pred - g["%s_predict" % gm]).max() < 1e-2
+    emb = model.predict_embedding(ds)
+    assert emb.shape == g["%s_embedding" % gm].shape  # untrimmed
+    assert np.abs(emb - g["%s_embedding" % gm]).max() < 1e-2
+
+
+def test_predict_uncertainty_api():
+    g = load_golden("model_reg_unc.npz")
+    model, cfg, state = build_model(g, "reference")
+    ds, _ = dataset_from(g)
+    model.fit(ds, nb_epoch=2, deterministic=True, checkpoint_interval=0)
+    p, s = model.predict_uncertainty(ds, masks=2)
+    assert p.shape == g["reference_unc_pred"].shape
+    assert np.abs(p - g["reference_unc_pred"]).max() < 1e-2
+    assert np.abs(s - g["reference_unc_std"]).max() < 1e-2
+
+
+def test_checkpoint_roundtrip_and_reference_key_names(tmp_path):
+    g = load_golden("model_cls_bn.npz")
+    model, cfg, state = build_model(g, "full", model_dir=str(tmp_path / "m1"))
+    ds, _ = dataset_from(g)
+    model.fit(ds, nb_epoch=1, deterministic=True, checkpoint_interval=2, max_checkpoints_to_keep=3)
+    files = sorted(os.listdir(str(tmp_path / "m1")))
+    assert "checkpoint1.pt" in files
+    data = torch.load(os.path.join(str(tmp_path / "m1"), "checkpoint1.pt"), map_location="cpu")
+    assert set(data.keys()) == {"model_state_dict", "optimizer_state_dict", "global_step"}
+    assert set(data["model_state_dict"].keys()) == set(state.keys())  # the reference's 103 keys
+    pred1 = model.predict(ds)
+    model2, _, _ = build_model(g, "full", model_dir=str(tmp_path / "m1"))
+    model2.restore()
+    assert model2.get_global_step() == model.get_global_step()
+    assert np.allclose(pred1, model2.predict(ds))
+    # continue training from the restored optimizer state: same as uninterrupted
+    l1 = model.fit(ds, nb_epoch=1, deterministic=True, checkpoint_interval=0)
+    l2 = model2.fit(ds, nb_epoch=1, deterministic=True, checkpoint_interval=0)
+    assert abs(l1 - l2) < 1e-5 * max(1.0, abs(l1))
+
+
+def test_overfit_small_set_classification():
+    """models/tests/test_graph_conv.py:48-66 (AUC >= 0.9 on 20 molecules after 20 epochs; the
+    reference needs its frozen GraphConv weights for that, ``full`` trains them)."""
+    from deepchem_amd.data import NumpyDataset
+    from deepchem_amd.metrics import roc_auc_per_task
+    from deepchem_amd.models.torch_models import GraphConvModel
+    from deepchem_amd.utils.synthetic import synthetic_molecules
+    torch.manual_seed(5)
+    np.random.seed(5)
+    packed = synthetic_molecules(20, seed=11)
+    y = (np.random.rand(20, 1) < 0.5).astype(np.float64)
+    ds = NumpyDataset(product_convmols(packed), y, np.ones((20, 1)))
+    for gm in ("reference", "full"):
+        model = GraphConvModel(1, number_input_features=[75, 64], batch_size=10, batch_normalize=False,
+                               mode='classification', grad_mode=gm, device=torch.device(DEV))
+        model.fit(ds, nb_epoch=40 if gm == "reference" else 20)
+        auc = roc_auc_per_task(y, model.predict(ds))
+        assert auc[0] >= 0.9, (gm, auc)
+
+
+def test_tox21_like_auc_matches_oracle():
+    """Per-task ROC-AUC within +-0.002 of the CPU path after training from the same
+    state on the same batches (BASELINE.json north_star)."""
+    from deepchem_amd.data import NumpyDataset
+    from deepchem_amd.metrics import roc_auc_per_task
+    from deepchem_amd.models.torch_models import GraphConvModel
+    from deepchem_amd.utils.synthetic import synthetic_labels, synthetic_molecules
+    from tests.util import oracle_predict
+    n, T, B = 300, 12, 100
+    packed = synthetic_molecules(n, seed=21)
+    y, w = synthetic_labels(n, T, "classification", 21, pos_rate=0.3)
+    cfg = O.ModelConfig(T, batch_size=B)
+    state = O.init_state(cfg, 21)
+    for gm in ("reference", "full"):
+        tr, _ = oracle_fit(cfg, state, oracle_convmols(packed), y, w, 3, gm, faithful=False)
+        ref_auc = roc_auc_per_task(y, oracle_predict(tr, cfg, oracle_convmols(packed), 0), w)
+        model = GraphConvModel(T, number_input_features=[75, 64], batch_size=B, grad_mode=gm,
+                               device=torch.device(DEV))
+        model.model.load_state_dict({k: v.clone() for k, v in state.items()})
+        ds = NumpyDataset(product_convmols(packed), y, w)
+        model.fit(ds, nb_epoch=3, deterministic=True, checkpoint_interval=0)
+        auc = roc_auc_per_task(y, model.predict(ds), w)
+        assert np.nanmax(np.abs(auc - ref_auc)) <= 0.002, (gm, auc, ref_auc)
