@@ -1,0 +1,244 @@
+"""bench.py -- molecules/s of the GraphConvModel training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+One STEP = one optimizer step of ``GraphConvModel`` (forward, loss, backward,
+gradient all-reduce when N > 1, Adam) over one collated batch of Tox21-like
+synthetic molecules that is already resident in HBM when the timed region
+starts.  ``value`` = molecules processed by all ranks / wall time of K steps
+(max over ranks, barrier + synchronize on both sides).
+
+The JSON line also carries
+  roofline     -- the GraphConv gather-sum kernel: algorithmic bytes
+                  (E*(4F+4) + N*4F per forward launch) / its
+                  average duration measured with HIP events on the launch
+                  stream during the timed steps, against HBM peak 8 TB/s;
+  cpu_baseline -- the oracle (CPU restatement of the reference, reference-
+                  faithful op sequence, reference gradient semantics) timed on
+                  this box's host cores on a bounded sample, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md); measured float4 copy: 6290
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=65536, help="molecules per GPU per step")
+    ap.add_argument("--tasks", type=int, default=12)
+    ap.add_argument("--grad-mode", default="full", choices=["full", "reference"])
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--small-batch", type=int, default=100,
+                    help="also report mol/s at the reference's default batch size (0 = skip)")
+    return ap.parse_args()
+
+
+def gather_sum_bytes(n_atoms, n_edges, n_deg0, feats, accumulate):
+    b = n_edges * (4 * feats + 4) + (n_atoms - n_deg0) * 4 * feats
+    if accumulate:
+        b += (n_atoms - n_deg0) * 4 * feats  # read-modify-write of the destination
+    else:
+        b += n_deg0 * 4 * feats  # zero rows of lone atoms
+    return b
+
+
+def make_workload(args, rank, device, batch):
+    import deepchem_amd as dc
+    from deepchem_amd.data.collate import collate_to_device
+    from deepchem_amd.metrics import to_one_hot
+    from deepchem_amd.utils.synthetic import synthetic_labels, synthetic_molecules
+    packed = synthetic_molecules(batch, seed=1000 + rank)
+    y, w = synthetic_labels(batch, args.tasks, "classification", seed=1000 + rank)
+    dbatch = collate_to_device(packed, None, device)
+    labels = torch.as_tensor(to_one_hot(y.flatten(), 2).reshape(-1, args.tasks, 2).astype(np.float32),
+                             device=device)
+    weights = torch.as_tensor(w.astype(np.float32), device=device)
+    model = dc.models.torch_models.GraphConvModel(args.tasks, number_input_features=[75, 64],
+                                                  batch_size=batch, mode="classification",
+                                                  grad_mode=args.grad_mode, device=device,
+                                                  learning_rate=1e-3, log_frequency=10**9)
+    return model, dbatch, labels, weights
+
+
+def run_steps(model, dbatch, labels, weights, n):
+    def gen():
+        for _ in range(n):
+            yield (dbatch, [labels], [weights])
+    return model.fit_generator(gen(), checkpoint_interval=0)
+
+
+def cpu_baseline(args, seconds):
+    """The oracle's training step (reference-faithful ops, reference gradient cut, Adam) at the
+    reference's default batch size on pre-collated batches; threads = all host cores."""
+    from deepchem_amd.feat.mol_graphs import collate_packed
+    from deepchem_amd.utils.synthetic import synthetic_labels, synthetic_molecules
+    from oracle import graphconv_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = 100
+    n_batches = 8
+    packed = synthetic_molecules(B * n_batches, seed=77)
+    y, w = synthetic_labels(B * n_batches, args.tasks, "classification", seed=77)
+    cfg = O.ModelConfig(args.tasks, batch_size=B)
+    tr = O.OracleTrainer(cfg, O.init_state(cfg, 0), grad_mode="reference", faithful=True)
+    batches = []
+    for b in range(n_batches):
+        sel = np.arange(b * B, (b + 1) * B)
+        m = collate_packed(packed, sel)
+        multi = dict(atom_features=m.get_atom_features(), deg_slice=m.deg_slice, membership=m.membership,
+                     deg_adj_lists=m.get_deg_adjacency_lists())
+        batches.append(O.batch_tensors(multi, B, y[sel], w[sel], cfg))
+    tr.train_step(*batches[0])  # warm-up
+    t0 = time.time()
+    steps = 0
+    while time.time() - t0 < seconds:
+        tr.train_step(*batches[steps % n_batches])
+        steps += 1
+    wall = time.time() - t0
+    return {
+        "value": round(steps * B / wall, 1),
+        "unit": "molecules/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d training steps (fwd+bwd+Adam, reference grad semantics, batch %d, pre-collated "
+                  "Tox21-like synthetic batches, %d tasks) in %.1f s; torch threads=%d" %
+                  (steps, B, args.tasks, wall, torch.get_num_threads()),
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU implementation)")
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(device)
+
+    from deepchem_amd import ops
+    from deepchem_amd._lib import K_GATHER_MAX, K_GATHER_SUM, K_READOUT, K_SEG_GEMM, K_WGRAD
+
+    model, dbatch, labels, weights = make_workload(args, rank, device, args.batch)
+    if world > 1:
+        from deepchem_amd.dist import shard_model
+        shard_model(model)
+    run_steps(model, dbatch, labels, weights, max(args.warmup, 1))
+
+    kernel_ids = {"gather_sum": K_GATHER_SUM, "gather_max": K_GATHER_MAX, "readout": K_READOUT,
+                  "seg_gemm": K_SEG_GEMM, "wgrad": K_WGRAD}
+    for kid in kernel_ids.values():
+        ops.timing_enable(kid, True)
+        ops.timing_read(kid, reset=True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(model, dbatch, labels, weights, args.steps)
+    barrier()
+    wall = time.perf_counter() - t0
+    ktimes = {name: ops.timing_read(kid, reset=True) for name, kid in kernel_ids.items()}
+    for kid in kernel_ids.values():
+        ops.timing_enable(kid, False)
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+
+    g = dbatch.graph
+    n0 = g.deg_counts[0]
+    # gather-sum launches of one step: forward layer 0 (F=75), forward layer 1 (F=64) and, in
+    # "full" mode, the backward of layer 1 as a gather of dS (F=64, accumulating)
+    per_step = gather_sum_bytes(g.n_atoms, g.n_edges, n0, 75, False) + \
+        gather_sum_bytes(g.n_atoms, g.n_edges, n0, 64, False)
+    launches_per_step = 2
+    if args.grad_mode == "full":
+        per_step += gather_sum_bytes(g.n_atoms, g.n_edges, n0, 64, True)
+        launches_per_step = 3
+    n_launch, ms = ktimes["gather_sum"]
+    achieved = (per_step * args.steps) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+
+    out = {
+        "metric": "molecules/sec fwd+bwd GraphConvModel",
+        "value": round(args.batch * world * args.steps / wall, 1),
+        "unit": "molecules/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(wall / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "Tox21-like synthetic molecules (18.2 atoms/mol, E/N 2.08), 12 binary tasks, "
+                        "GraphConvModel [64,64]/dense 128, BatchNorm on, fwd+bwd+Adam per step",
+            "molecules_per_gpu_per_step": args.batch,
+            "atoms_per_gpu_per_step": g.n_atoms,
+            "directed_edges_per_gpu_per_step": g.n_edges,
+            "grad_mode": args.grad_mode,
+            "parallelism": "dp%d (molecules sharded by rank, one flat all-reduce per step)" % world,
+        },
+        "roofline": {
+            "kernel": "gather_sum_kernel (GraphConv.sum_neigh and its backward)",
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": None,
+            "algorithmic_bytes_per_step": int(per_step),
+            "launches_per_step": launches_per_step,
+            "avg_launch_us": round(ms * 1e3 / max(n_launch, 1), 2),
+        },
+        "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in ktimes.items()},
+    }
+
+    if rank == 0 and args.small_batch and world == 1:
+        m2, b2, l2, w2 = make_workload(args, 0, device, args.small_batch)
+        run_steps(m2, b2, l2, w2, 10)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_small = 100
+        run_steps(m2, b2, l2, w2, n_small)
+        torch.cuda.synchronize()
+        out["config"]["molecules_per_s_at_batch_%d" % args.small_batch] = round(
+            args.small_batch * n_small / (time.perf_counter() - t1), 1)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

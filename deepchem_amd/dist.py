@@ -1,0 +1,78 @@
+"""Data-parallel sharding over the GPUs of one node.
+
+Molecules are independent graphs, so a global batch shards by molecule with no
+data-path exchange at all: every rank collates and runs its own molecules.  The
+one collective per step is a sum all-reduce (RCCL over xGMI; ``gloo`` on CPU in
+the tests) of ONE flat fp32 bucket holding every gradient that exists --
+head + dense + BatchNorm[1..2] (15 k floats for Tox21) in ``grad_mode="reference"``,
+all 204 k floats in ``"full"``.  At <= 1 MB the ring is latency-bound on the
+7 x 153 GB/s links, so a single fused call beats per-tensor calls; the result
+is scaled by 1/world_size, which equals the single-process mean over the global
+batch when every rank holds the same number of molecules
+(loss = mean over (B, T), torch_model.py:1290-1291).  BatchNorm statistics stay
+per rank, as torch DDP would leave them.
+"""
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of rank; sizes differ by at most one (the same
+    partition deepchem/data/pytorch_datasets.py:104-113 applies to disk shards)."""
+    lo = n_items * rank // world_size
+    hi = n_items * (rank + 1) // world_size
+    return lo, hi
+
+
+def shard_indices(indices: Sequence[int], rank: Optional[int] = None,
+                  world_size: Optional[int] = None) -> np.ndarray:
+    """The molecules of one global batch that this rank processes."""
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    if world_size is None:
+        world_size = dist.get_world_size() if dist.is_initialized() else 1
+    idx = np.asarray(indices)
+    lo, hi = shard_range(len(idx), rank, world_size)
+    return idx[lo:hi]
+
+
+class FlatGradAllReduce:
+    """One flat-bucket all-reduce of all existing gradients per step."""
+
+    def __init__(self, world_size: Optional[int] = None, group=None):
+        self.group = group
+        self.world_size = world_size if world_size is not None else dist.get_world_size(group)
+        self._bucket: Optional[torch.Tensor] = None
+
+    def __call__(self, module: torch.nn.Module) -> None:
+        grads: List[torch.Tensor] = [p.grad for p in module.parameters() if p.grad is not None]
+        if not grads or self.world_size == 1:
+            return
+        n = sum(g.numel() for g in grads)
+        if self._bucket is None or self._bucket.numel() != n or self._bucket.device != grads[0].device:
+            self._bucket = torch.empty(n, dtype=torch.float32, device=grads[0].device)
+        off = 0
+        views = []
+        for g in grads:
+            v = self._bucket[off:off + g.numel()].view_as(g)
+            v.copy_(g)
+            views.append(v)
+            off += g.numel()
+        dist.all_reduce(self._bucket, op=dist.ReduceOp.SUM, group=self.group)
+        self._bucket.mul_(1.0 / self.world_size)
+        for g, v in zip(grads, views):
+            g.copy_(v)
+
+
+def shard_model(model, group=None) -> None:
+    """Make ``model.fit*`` data-parallel across the initialised process group:
+    broadcast rank 0's parameters and buffers, then all-reduce gradients each step."""
+    if not dist.is_initialized():
+        raise RuntimeError("torch.distributed is not initialised")
+    with torch.no_grad():
+        for t in list(model.model.parameters()) + list(model.model.buffers()):
+            dist.broadcast(t, src=0, group=group)
+    model._grad_sync = FlatGradAllReduce(group=group)

@@ -80,6 +80,8 @@ class TorchModel(Model):
                 self._loss_outputs = self._prediction_outputs
         self._built = False
         self._optimizer_for_vars: Dict[Any, Any] = {}
+        # set by deepchem_amd.dist.shard_model(); None = single process
+        self._grad_sync: Optional[Callable] = None
 
     def _ensure_built(self) -> None:
         if self._built:
@@ -149,6 +151,8 @@ class TorchModel(Model):
                 outputs = [outputs[i] for i in self._loss_outputs]
             batch_loss = loss(outputs, labels, weights)
             batch_loss.backward()
+            if self._grad_sync is not None:
+                self._grad_sync(self.model)  # data-parallel ranks: one flat all-reduce per step
             optimizer.step()
             if lr_schedule is not None:
                 lr_schedule.step()
@@ -320,7 +324,10 @@ class TorchModel(Model):
 
     def _prepare_batch(self, batch: Tuple[Any, Any, Any]):
         inputs, labels, weights = batch
-        input_tensors = [self._to_device(x) for x in inputs]
+        if hasattr(inputs, "graph"):  # a DeviceBatch: already collated and resident in HBM
+            input_tensors = inputs
+        else:
+            input_tensors = [self._to_device(x) for x in inputs]
         label_tensors = [self._to_device(x) for x in labels] if labels is not None else []
         weight_tensors = [self._to_device(x) for x in weights] if weights is not None else []
         return (input_tensors, label_tensors, weight_tensors)

@@ -336,11 +336,15 @@ class GraphConvFn(torch.autograd.Function):
         k, n_out = wpack.shape[1], wpack.shape[2]
         if wpack.shape[0] != 2 * graph.max_deg + 1 or tuple(bsum.shape) != (graph.max_deg + 1, n_out):
             raise ValueError("GraphConv parameters do not match max_deg=%d" % graph.max_deg)
-        _mat(x, "atom_features", rows=graph.n_atoms, cols=k)
+        _mat(x, "atom_features", rows=graph.n_atoms)
+        if x.shape[1] < k or x.shape[1] >= k + 4:
+            raise ValueError("atom_features has %d columns, the layer expects %d" % (x.shape[1], k))
+        # x may carry zero padding columns (DeviceBatch pads 75 -> 76 so that the gather moves
+        # 16 bytes per lane); the GEMMs read the first k columns only
         w_rel, w_self, b_off = _graphconv_offsets(graph.max_deg, k, n_out)
         s = gather_sum(graph, x)
-        out = seg_gemm(list(graph.seg_begin), list(graph.seg_end), s, wpack, w_rel, x, wpack, w_self,
-                       bsum, b_off, n_out, False, relu, graph.n_atoms, k, k)
+        out = seg_gemm(list(graph.seg_begin), list(graph.seg_end), s[:, :k], wpack, w_rel, x[:, :k],
+                       wpack, w_self, bsum, b_off, n_out, False, relu, graph.n_atoms, k, k)
         ctx.graph = graph
         ctx.relu = relu
         ctx.save_for_backward(x, s, wpack, out)
@@ -360,8 +364,8 @@ class GraphConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dw = torch.zeros_like(wpack)
             dbs = torch.zeros((graph.max_deg + 1, n_out), dtype=torch.float32, device=g.device)
-            seg_gemm_wgrad(sb, se, s, g, dw, w_rel, None, None, False)
-            seg_gemm_wgrad(sb, se, x, g, dw, w_self, dbs, b_off, False)
+            seg_gemm_wgrad(sb, se, s[:, :k], g, dw, w_rel, None, None, False)
+            seg_gemm_wgrad(sb, se, x[:, :k], g, dw, w_self, dbs, b_off, False)
         if ctx.needs_input_grad[0]:
             # dS = g . W_rel^T, dX = g . W_self^T  (same blocks read transposed)
             ds = seg_gemm(sb, se, g, wpack, w_rel, None, None, None, None, None, k, True, False,
@@ -372,6 +376,8 @@ class GraphConvFn(torch.autograd.Function):
                 gather_sum(graph, ds, dx, accumulate=True)  # no atomics: bonds are listed from both ends
             else:
                 scatter_add(graph, ds, dx)
+            if x.shape[1] > k:
+                dx = torch.nn.functional.pad(dx, (0, x.shape[1] - k))
         return dx, dw, dbs, None, None
 
 
