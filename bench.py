@@ -82,13 +82,38 @@ def run_steps(model, dbatch, labels, weights, n):
     return model.fit_generator(gen(), checkpoint_interval=0)
 
 
+def usable_cores() -> int:
+    """Host cores this process may actually use (affinity mask and cgroup CPU quota), not
+    the machine's core count: oversubscribing torch's thread pool makes the CPU arm look
+    absurdly slow."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // period))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(args, seconds):
     """The oracle's training step (reference-faithful ops, reference gradient cut, Adam) at the
     reference's default batch size on pre-collated batches; threads = all host cores."""
     from deepchem_amd.feat.mol_graphs import collate_packed
     from deepchem_amd.utils.synthetic import synthetic_labels, synthetic_molecules
     from oracle import graphconv_oracle as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     B = 100
     n_batches = 8
@@ -136,7 +161,8 @@ def main():
     torch.cuda.set_device(device)
 
     from deepchem_amd import ops
-    from deepchem_amd._lib import K_GATHER_MAX, K_GATHER_SUM, K_READOUT, K_SEG_GEMM, K_WGRAD
+    from deepchem_amd._lib import (K_GATHER_MAX, K_GATHER_MAX_BWD, K_GATHER_SUM, K_READOUT, K_SEG_GEMM,
+                                   K_WGRAD)
 
     model, dbatch, labels, weights = make_workload(args, rank, device, args.batch)
     if world > 1:
@@ -144,8 +170,8 @@ def main():
         shard_model(model)
     run_steps(model, dbatch, labels, weights, max(args.warmup, 1))
 
-    kernel_ids = {"gather_sum": K_GATHER_SUM, "gather_max": K_GATHER_MAX, "readout": K_READOUT,
-                  "seg_gemm": K_SEG_GEMM, "wgrad": K_WGRAD}
+    kernel_ids = {"gather_sum": K_GATHER_SUM, "gather_max": K_GATHER_MAX, "gather_max_bwd": K_GATHER_MAX_BWD,
+                  "readout": K_READOUT, "seg_gemm": K_SEG_GEMM, "wgrad": K_WGRAD}
     for kid in kernel_ids.values():
         ops.timing_enable(kid, True)
         ops.timing_read(kid, reset=True)

@@ -11,7 +11,12 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int32, c_
 from deepchem_amd import _build
 
 GCMI_MAX_DEG = 10
-K_GATHER_SUM, K_GATHER_MAX, K_READOUT, K_SEG_GEMM, K_WGRAD = 0, 1, 2, 3, 4
+BN_ACC_REPLICAS = 32
+
+
+def bn_acc_doubles(n_feat: int) -> int:
+    return 66 * n_feat
+K_GATHER_SUM, K_GATHER_MAX, K_READOUT, K_SEG_GEMM, K_WGRAD, K_GATHER_MAX_BWD = 0, 1, 2, 3, 4, 5
 
 
 class GcmiGraph(Structure):
@@ -26,6 +31,7 @@ class GcmiGraph(Structure):
         ("d_col_idx", c_void_p),
         ("d_membership", c_void_p),
         ("d_mol_runs", c_void_p),
+        ("d_rev_pos", c_void_p),
     ]
 
 
@@ -40,6 +46,7 @@ _SIGNATURES = {
     "gcmi_collate": [_P, c_int64, _P, _P, _P, _P, c_int64, c_int32, _P, c_int64, c_int64, _P, _P,
                      c_int64, _P, _G],
     "gcmi_build_mol_runs": [_G, _P, _P, _P],
+    "gcmi_build_rev_pos": [_G, _P, _P, _P],
     "gcmi_gather_sum_fwd": [_G, _P, c_int64, c_int32, _P, c_int64, c_int32, _P],
     "gcmi_scatter_add": [_G, _P, c_int64, c_int32, _P, c_int64, _P],
     "gcmi_gather_max_fwd": [_G, _P, c_int64, c_int32, _P, _P, _P, c_int64, _P, _P],
@@ -51,7 +58,7 @@ _SIGNATURES = {
     "gcmi_bn_fold_eval": [_P, _P, _P, _P, c_float, c_int32, _P, _P, _P],
     "gcmi_bn_apply": [_P, c_int64, c_int64, c_int32, _P, _P, _P, c_int64, _P],
     "gcmi_bn_bwd": [_P, c_int64, _P, c_int64, c_int64, c_int32, _P, _P, _P, _P, _P, _P, c_int64,
-                    _P, _P],
+                    c_int32, _P, _P],
     "gcmi_seg_gemm": [c_int32, _I32P, _I32P, _P, c_int64, c_int32, _P, _I64P, _P, c_int64, c_int32,
                       _P, _I64P, _P, _I64P, c_int32, c_int32, c_int32, _P, c_int64, _P],
     "gcmi_seg_gemm_wgrad": [c_int32, _I32P, _I32P, _P, c_int64, c_int32, _P, c_int64, c_int32, _P,

@@ -17,6 +17,8 @@ namespace gcmi {
 
 constexpr int kBBlock = 256;
 constexpr int kRowsPerBlock = 512;
+constexpr int kReplicas = 32;  // accumulator replicas: same-address fp64 atomics serialise
+// scratch layout (doubles): [0, 2F) reduced sums, then kReplicas blocks of 2F partial sums
 
 // sums[0:F] += sum_r a[r,:],  sums[F:2F] += sum_r a[r,:]*b[r,:]
 // MODE 0: b = a (sum of squares).  MODE 1: b = (x - mean)*invstd (x given), a = dy.
@@ -83,11 +85,20 @@ col_sums_kernel(const float* __restrict__ a, int64_t lda, const float* __restric
           t1 += red[((y * lx + tx) * V + q) * 2 + 0];
           t2 += red[((y * lx + tx) * V + q) * 2 + 1];
         }
-        atomicAdd(sums + c + q, t1);
-        atomicAdd(sums + n_feat + c + q, t2);
+        double* rep = sums + (size_t)2 * n_feat * (1 + (blockIdx.x % kReplicas));
+        atomicAdd(rep + c + q, t1);
+        atomicAdd(rep + n_feat + c + q, t2);
       }
     }
     __syncthreads();
+  }
+}
+
+__global__ void sums_reduce_kernel(double* __restrict__ sums, int n_feat) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < 2 * n_feat; c += gridDim.x * blockDim.x) {
+    double t = 0.0;
+    for (int r = 0; r < kReplicas; ++r) t += sums[(size_t)2 * n_feat * (1 + r) + c];
+    sums[c] = t;
   }
 }
 
@@ -153,7 +164,8 @@ bn_apply_kernel(const float* __restrict__ x, int64_t ldx, int64_t slots, int lpr
 }
 
 // dgamma = sum dy*xhat, dbeta = sum dy (from sums); dx = gamma*invstd*(dy - dbeta/n - xhat*dgamma/n)
-template <int V>
+// RELU: x is a ReLU output and dx is wanted w.r.t. the ReLU input: dx *= (x > 0).
+template <int V, bool RELU>
 __global__ void __launch_bounds__(kBBlock)
 bn_bwd_dx_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
                  int64_t ldx, int64_t n_rows, int n_feat, int64_t slots, int lpr,
@@ -165,15 +177,25 @@ bn_bwd_dx_kernel(const float* __restrict__ dy, int64_t lddy, const float* __rest
        e += (int64_t)gridDim.x * kBBlock) {
     const int64_t r = e / lpr;
     const int c = (int)(e - r * lpr) * V;
-    float o[V];
+    float xv[V], gv[V], o[V];
+    if constexpr (V == 4) {
+      const float4 a4 = *reinterpret_cast<const float4*>(x + r * ldx + c);
+      const float4 b4 = *reinterpret_cast<const float4*>(dy + r * lddy + c);
+      xv[0] = a4.x; xv[1] = a4.y; xv[2] = a4.z; xv[3] = a4.w;
+      gv[0] = b4.x; gv[1] = b4.y; gv[2] = b4.z; gv[3] = b4.w;
+    } else {
+      xv[0] = x[r * ldx + c];
+      gv[0] = dy[r * lddy + c];
+    }
 #pragma unroll
     for (int q = 0; q < V; ++q) {
       const float is = invstd[c + q];
-      const float xh = (x[r * ldx + c + q] - mean[c + q]) * is;
+      const float xh = (xv[q] - mean[c + q]) * is;
       const float db = (float)sums[c + q];
       const float dg = (float)sums[n_feat + c + q];
       const float g = gamma ? gamma[c + q] : 1.f;
-      o[q] = g * is * (dy[r * lddy + c + q] - db * inv_n - xh * dg * inv_n);
+      const float v = g * is * (gv[q] - db * inv_n - xh * dg * inv_n);
+      o[q] = (RELU && !(xv[q] > 0.f)) ? 0.f : v;
     }
     if constexpr (V == 4) {
       *reinterpret_cast<float4*>(dx + r * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
@@ -194,7 +216,7 @@ __global__ void bn_bwd_params_kernel(const double* __restrict__ sums, int n_feat
 static int launch_col_sums(int mode, const float* a, int64_t lda, const float* x, int64_t ldx,
                            const float* mean, const float* invstd, int64_t n_rows, int n_feat,
                            double* sums, hipStream_t st) {
-  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * n_feat, st) != hipSuccess) {
+  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * n_feat * (1 + kReplicas), st) != hipSuccess) {
     set_error("bn: memset failed");
     return GCMI_ERR_LAUNCH;
   }
@@ -214,6 +236,8 @@ static int launch_col_sums(int mode, const float* a, int64_t lda, const float* x
   }
 #undef LAUNCH_CS
   GCMI_CHECK_LAUNCH("bn col_sums");
+  hipLaunchKernelGGL(sums_reduce_kernel, dim3((2 * n_feat + 255) / 256), dim3(256), 0, st, sums, n_feat);
+  GCMI_CHECK_LAUNCH("bn sums_reduce");
   return GCMI_OK;
 }
 
@@ -278,7 +302,7 @@ int gcmi_bn_apply(const float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat,
 int gcmi_bn_bwd(const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx, int64_t n_rows,
                 int32_t n_feat, const float* d_gamma, const float* d_mean,
                 const float* d_invstd, float* d_dgamma, float* d_dbeta, float* d_dx,
-                int64_t lddx, double* d_acc, void* stream) {
+                int64_t lddx, int32_t relu_mask, double* d_acc, void* stream) {
   GCMI_CHECK_ARG(n_feat > 0 && n_rows > 0 && lddy >= n_feat && ldx >= n_feat, "bn_bwd: bad shape");
   GCMI_CHECK_ARG(d_dy && d_x && d_mean && d_invstd && d_acc, "bn_bwd: NULL buffer");
   GCMI_CHECK_ARG(d_dx == nullptr || lddx >= n_feat, "bn_bwd: bad lddx");
@@ -291,17 +315,22 @@ int gcmi_bn_bwd(const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx, 
     GCMI_CHECK_LAUNCH("bn_bwd_params");
   }
   if (d_dx) {
-    const int V = (vec_width(d_dx, lddx, n_feat) == 4) ? 4 : 1;
+    const int V = (vec_width(d_dx, lddx, n_feat) == 4 && vec_width(d_dy, lddy, n_feat) == 4 &&
+                   vec_width(d_x, ldx, n_feat) == 4)
+                      ? 4
+                      : 1;
     const int lpr = n_feat / V;
     const int64_t slots = n_rows * lpr;
-    if (V == 4)
-      hipLaunchKernelGGL(bn_bwd_dx_kernel<4>, dim3(grid_for(slots, kBBlock)), dim3(kBBlock), 0, st,
-                         d_dy, lddy, d_x, ldx, n_rows, n_feat, slots, lpr, d_gamma, d_mean, d_invstd,
-                         d_acc, d_dx, lddx);
-    else
-      hipLaunchKernelGGL(bn_bwd_dx_kernel<1>, dim3(grid_for(slots, kBBlock)), dim3(kBBlock), 0, st,
-                         d_dy, lddy, d_x, ldx, n_rows, n_feat, slots, lpr, d_gamma, d_mean, d_invstd,
-                         d_acc, d_dx, lddx);
+#define LAUNCH_DX(VV, RR)                                                                        \
+  hipLaunchKernelGGL((bn_bwd_dx_kernel<VV, RR>), dim3(grid_for(slots, kBBlock)), dim3(kBBlock), 0, \
+                     st, d_dy, lddy, d_x, ldx, n_rows, n_feat, slots, lpr, d_gamma, d_mean,       \
+                     d_invstd, d_acc, d_dx, lddx)
+    if (V == 4) {
+      if (relu_mask) LAUNCH_DX(4, true); else LAUNCH_DX(4, false);
+    } else {
+      if (relu_mask) LAUNCH_DX(1, true); else LAUNCH_DX(1, false);
+    }
+#undef LAUNCH_DX
     GCMI_CHECK_LAUNCH("bn_bwd_dx");
   }
   return GCMI_OK;

@@ -251,6 +251,104 @@ gather_max_bwd_kernel(DegTable t, TileTable tt, const int32_t* __restrict__ col,
   }
 }
 
+// Transposed (gather) form of the GraphPool backward for a symmetric adjacency:
+//   dx[k,f] = dout[k,f]*[arg[k,f]==0] + sum_j dout[i_j,f]*[arg[i_j,f] == rev_pos(k,j)+1]
+// with i_j the j-th neighbour of k.  Every dx row is produced by exactly one lane
+// group: no atomics, no pre-zeroing, bitwise reproducible.  Traffic per edge:
+// 16 B of dout + 4 B of arg + 5 B of index/slot per 16-byte column chunk.
+template <int V>
+__global__ void __launch_bounds__(kBlock)
+gather_max_bwd_gather_kernel(DegTable t, TileTable tt, const int32_t* __restrict__ col,
+                             const uint8_t* __restrict__ rev, const float* __restrict__ dout,
+                             int64_t lddo, int lpr, int n_feat, const uint8_t* __restrict__ arg,
+                             float* __restrict__ dx, int64_t lddx) {
+  const int b = blockIdx.x;
+  const int d = block_degree(tt, b);
+  const int row0 = pick(t.deg_start, d);
+  const int n_d = pick(t.deg_start, d + 1) - row0;
+  const int64_t e0 = pick(t.edge_start, d);
+  const int64_t slots = (int64_t)n_d * lpr;
+  const int64_t first = (int64_t)(b - pick(tt.tile_start, d)) * (kBlock * kUnroll) + threadIdx.x;
+#pragma unroll
+  for (int u = 0; u < kUnroll; ++u) {
+    const int64_t e = first + (int64_t)u * kBlock;
+    if (e >= slots) break;
+    const int r = (int)(e / lpr);
+    const int c = (int)(e - (int64_t)r * lpr) * V;
+    const int k = row0 + r;
+    const int32_t* nb = col + e0 + (int64_t)r * d;
+    const uint8_t* rp = rev + e0 + (int64_t)r * d;
+    float acc[V], gv[V];
+    uint8_t av[V];
+    ld_arr<V>(dout + (int64_t)k * lddo + c, gv);
+    if constexpr (V == 4) {
+      const uchar4 a4 = *reinterpret_cast<const uchar4*>(arg + (int64_t)k * n_feat + c);
+      av[0] = a4.x; av[1] = a4.y; av[2] = a4.z; av[3] = a4.w;
+    } else {
+      av[0] = arg[(int64_t)k * n_feat + c];
+    }
+#pragma unroll
+    for (int q = 0; q < V; ++q) acc[q] = av[q] == 0 ? gv[q] : 0.f;
+    for (int j = 0; j < d; ++j) {
+      const int i = nb[j];
+      const uint8_t want = (uint8_t)(rp[j] + 1);
+      ld_arr<V>(dout + (int64_t)i * lddo + c, gv);
+      if constexpr (V == 4) {
+        const uchar4 a4 = *reinterpret_cast<const uchar4*>(arg + (int64_t)i * n_feat + c);
+        av[0] = a4.x; av[1] = a4.y; av[2] = a4.z; av[3] = a4.w;
+      } else {
+        av[0] = arg[(int64_t)i * n_feat + c];
+      }
+#pragma unroll
+      for (int q = 0; q < V; ++q) acc[q] += av[q] == want ? gv[q] : 0.f;
+    }
+    st_arr<V>(dx + (int64_t)k * lddx + c, acc);
+  }
+}
+
+// rev_pos[(k, j)] = slot of k inside the neighbour list of i = col[(k, j)]; the n-th
+// slot of k that points at i is matched with the n-th slot of i that points at k, so
+// multi-bonds pair up one to one.  One thread per edge slot.
+__global__ void __launch_bounds__(kBlock)
+rev_pos_kernel(DegTable t, int n_edges, const int32_t* __restrict__ col,
+               uint8_t* __restrict__ rev, int32_t* __restrict__ flag) {
+  for (int e = blockIdx.x * kBlock + threadIdx.x; e < n_edges; e += gridDim.x * kBlock) {
+    int d = 0;
+#pragma unroll
+    for (int q = 1; q <= GCMI_MAX_DEG; ++q) d += (q <= t.max_deg && e >= t.edge_start[q]) ? 1 : 0;
+    int es = 0, ds = 0;
+#pragma unroll
+    for (int q = 0; q <= GCMI_MAX_DEG; ++q) {
+      if (q == d) { es = t.edge_start[q]; ds = t.deg_start[q]; }
+    }
+    const int r = (e - es) / d;
+    const int j = (e - es) - r * d;
+    const int k = ds + r;
+    const int i = col[e];
+    int nth = 0;
+    for (int q = 0; q < j; ++q) nth += (col[es + r * d + q] == i) ? 1 : 0;
+    const int di = degree_of_row(t, i);
+    int esi = 0, dsi = 0;
+#pragma unroll
+    for (int q = 0; q <= GCMI_MAX_DEG; ++q) {
+      if (q == di) { esi = t.edge_start[q]; dsi = t.deg_start[q]; }
+    }
+    const int32_t* li = col + esi + (int64_t)(i - dsi) * di;
+    int found = -1;
+    for (int p = 0; p < di; ++p) {
+      if (li[p] == k) {
+        if (nth == 0) { found = p; break; }
+        --nth;
+      }
+    }
+    if (found < 0) {
+      *flag = 1;
+      found = 255;
+    }
+    rev[e] = (uint8_t)found;
+  }
+}
+
 }  // namespace gcmi
 
 using namespace gcmi;
@@ -342,6 +440,24 @@ int gcmi_gather_max_fwd(const gcmi_graph* g, const float* d_x, int64_t ldx, int3
   return GCMI_OK;
 }
 
+int gcmi_build_rev_pos(const gcmi_graph* g, uint8_t* d_rev_pos, int32_t* d_flag, void* stream) {
+  int rc = check_graph(g, true);
+  if (rc) return rc;
+  GCMI_CHECK_ARG(d_flag != nullptr, "build_rev_pos: d_flag is NULL");
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(d_flag, 0, sizeof(int32_t), st) != hipSuccess) {
+    set_error("build_rev_pos: memset failed");
+    return GCMI_ERR_LAUNCH;
+  }
+  if (g->n_edges == 0) return GCMI_OK;
+  GCMI_CHECK_ARG(d_rev_pos != nullptr, "build_rev_pos: NULL output");
+  DegTable t = make_deg_table(g);
+  hipLaunchKernelGGL(rev_pos_kernel, dim3(grid_for(g->n_edges, kBlock)), dim3(kBlock), 0, st, t,
+                     g->n_edges, g->d_col_idx, d_rev_pos, d_flag);
+  GCMI_CHECK_LAUNCH("build_rev_pos");
+  return GCMI_OK;
+}
+
 int gcmi_gather_max_bwd(const gcmi_graph* g, const float* d_dout, int64_t lddo, int32_t n_feat,
                         const uint8_t* d_arg, float* d_dx, int64_t lddx, void* stream) {
   int rc = check_graph(g, true);
@@ -350,11 +466,25 @@ int gcmi_gather_max_bwd(const gcmi_graph* g, const float* d_dout, int64_t lddo, 
   GCMI_CHECK_ARG(g->n_atoms == 0 || (d_dout && d_arg && d_dx), "gather_max_bwd: NULL buffer");
   if (g->n_atoms == 0) return GCMI_OK;
   hipStream_t st = (hipStream_t)stream;
-  const int V = (n_feat % 4 == 0) ? 4 : 1;
+  const int V = (n_feat % 4 == 0 && vec_width(d_dout, lddo, n_feat) == 4 &&
+                 vec_width(d_dx, lddx, n_feat) == 4 && (reinterpret_cast<uintptr_t>(d_arg) & 3u) == 0)
+                    ? 4
+                    : 1;
   const int lpr = n_feat / V;
   TileTable tt;
   const int tiles = make_tiles(g, lpr, false, &tt);
   DegTable t = make_deg_table(g);
+  if (g->d_rev_pos != nullptr || g->n_edges == 0) {
+    TimedScope ts(GCMI_K_GATHER_MAX_BWD, st);
+    if (V == 4)
+      hipLaunchKernelGGL(gather_max_bwd_gather_kernel<4>, dim3(tiles), dim3(kBlock), 0, st, t, tt,
+                         g->d_col_idx, g->d_rev_pos, d_dout, lddo, lpr, n_feat, d_arg, d_dx, lddx);
+    else
+      hipLaunchKernelGGL(gather_max_bwd_gather_kernel<1>, dim3(tiles), dim3(kBlock), 0, st, t, tt,
+                         g->d_col_idx, g->d_rev_pos, d_dout, lddo, lpr, n_feat, d_arg, d_dx, lddx);
+    GCMI_CHECK_LAUNCH("gather_max_bwd (gather form)");
+    return GCMI_OK;
+  }
   if (V == 4)
     hipLaunchKernelGGL(gather_max_bwd_kernel<4>, dim3(tiles), dim3(kBlock), 0, st, t, tt,
                        g->d_col_idx, d_dout, lddo, lpr, n_feat, d_arg, d_dx, lddx);

@@ -236,7 +236,33 @@ wgrad_kernel(SlabTable st, const float* __restrict__ a, int64_t lda, int k, int 
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][t], bv[u], acc[t], 0, 0, 0);
     }
   }
-  if (r_begin >= r_end) return;
+  // combine the row parts of this workgroup through LDS, so that ONE wave per n-tile
+  // issues the atomics (fewer, less contended adds into the small dW block)
+  if (parts > 1) {
+    extern __shared__ float red[];
+    float* racc = red + (size_t)(wave % ntw) * KT * 16 * 64;
+    float* rb = red + (size_t)ntw * KT * 16 * 64 + (wave % ntw) * 64;
+    for (int p = 1; p < parts; ++p) {
+      if (rp == p) {
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) racc[(t * 16 + reg) * 64 + lane] = acc[t][reg];
+        rb[lane] = bsum;
+      }
+      __syncthreads();
+      if (rp == 0) {
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) acc[t][reg] += racc[(t * 16 + reg) * 64 + lane];
+        bsum += rb[lane];
+      }
+      __syncthreads();
+    }
+    if (rp != 0) return;
+  }
+  if (slab0 >= seg_end) return;
   const int64_t woff = pick_seg(st.dw_off, s);
   if (n_ok && woff >= 0) {
 #pragma unroll
@@ -357,11 +383,12 @@ int gcmi_seg_gemm_wgrad(int32_t n_seg, const int32_t* seg_begin, const int32_t* 
     total_rows += seg_end[s] - seg_begin[s];
   }
   if (total_rows == 0) return GCMI_OK;
-  // slab size: enough workgroups to fill the chip, few enough that the atomics stay cheap
-  int64_t slab = (total_rows + 1023) / 1024;
+  // slab size: about two workgroups per CU, but never so small that the atomic epilogue
+  // (k x n adds per workgroup into one small block) outweighs the row loop
+  int64_t slab = (total_rows + 511) / 512;
   slab = ((slab + 63) / 64) * 64;
-  if (slab < 64) slab = 64;
-  if (slab > 2048) slab = 2048;
+  if (slab < 512) slab = 512;
+  if (slab > 4096) slab = 4096;
   st.slab_rows = (int32_t)slab;
   int64_t slabs = 0;
   for (int s = 0; s < kMaxSeg; ++s) {
@@ -387,12 +414,13 @@ int gcmi_seg_gemm_wgrad(int32_t n_seg, const int32_t* seg_begin, const int32_t* 
     const int KT = KT_total - kt0 < 8 ? KT_total - kt0 : 8;
 #define LAUNCH_WG(KK)                                                                            \
   do {                                                                                           \
+    const size_t lds = ntw == 4 ? 0 : (size_t)ntw * (KK * 16 * 64 + 64) * sizeof(float);         \
     if (trans_w)                                                                                 \
-      hipLaunchKernelGGL((wgrad_kernel<KK, true>), grid, dim3(kGBlock), 0, sm, st, d_a, lda, k,  \
-                         kt0, d_g, ldg, n, ntw, d_dw, d_dbias);                                  \
+      hipLaunchKernelGGL((wgrad_kernel<KK, true>), grid, dim3(kGBlock), lds, sm, st, d_a, lda,   \
+                         k, kt0, d_g, ldg, n, ntw, d_dw, d_dbias);                               \
     else                                                                                         \
-      hipLaunchKernelGGL((wgrad_kernel<KK, false>), grid, dim3(kGBlock), 0, sm, st, d_a, lda, k, \
-                         kt0, d_g, ldg, n, ntw, d_dw, d_dbias);                                  \
+      hipLaunchKernelGGL((wgrad_kernel<KK, false>), grid, dim3(kGBlock), lds, sm, st, d_a, lda,  \
+                         k, kt0, d_g, ldg, n, ntw, d_dw, d_dbias);                               \
   } while (0)
     switch (KT) {
       case 1: LAUNCH_WG(1); break;

@@ -112,18 +112,40 @@ readout_bwd_kernel(int64_t slots, int lpr, int n_feat, const int32_t* __restrict
     const int i = (int)(e / lpr);
     const int c = (int)(e - (int64_t)i * lpr) * V;
     const int b = membership[i];
-    float g[V];
+    float g[V], gs[V], gm[V], os[V], om[V];
+    int am[V];
+    const float* drow = dout + (int64_t)b * lddo;
+    const float* orow = out + (int64_t)b * ldo;
+    if constexpr (V == 4) {
+      const float4 a4 = *reinterpret_cast<const float4*>(drow + c);
+      const float4 b4 = *reinterpret_cast<const float4*>(drow + n_feat + c);
+      const int4 i4 = *reinterpret_cast<const int4*>(arg + (int64_t)b * n_feat + c);
+      gs[0] = a4.x; gs[1] = a4.y; gs[2] = a4.z; gs[3] = a4.w;
+      gm[0] = b4.x; gm[1] = b4.y; gm[2] = b4.z; gm[3] = b4.w;
+      am[0] = i4.x; am[1] = i4.y; am[2] = i4.z; am[3] = i4.w;
+      if (act == 1) {
+        const float4 c4 = *reinterpret_cast<const float4*>(orow + c);
+        const float4 d4 = *reinterpret_cast<const float4*>(orow + n_feat + c);
+        os[0] = c4.x; os[1] = c4.y; os[2] = c4.z; os[3] = c4.w;
+        om[0] = d4.x; om[1] = d4.y; om[2] = d4.z; om[3] = d4.w;
+      }
+    } else {
+      gs[0] = drow[c];
+      gm[0] = drow[n_feat + c];
+      am[0] = arg[(int64_t)b * n_feat + c];
+      if (act == 1) {
+        os[0] = orow[c];
+        om[0] = orow[n_feat + c];
+      }
+    }
 #pragma unroll
     for (int q = 0; q < V; ++q) {
-      float gs = dout[(int64_t)b * lddo + c + q];
-      float gm = dout[(int64_t)b * lddo + n_feat + c + q];
+      float s1 = gs[q], m1 = gm[q];
       if (act == 1) {
-        const float os = out[(int64_t)b * ldo + c + q];
-        const float om = out[(int64_t)b * ldo + n_feat + c + q];
-        gs *= (1.f - os * os);
-        gm *= (1.f - om * om);
+        s1 *= (1.f - os[q] * os[q]);
+        m1 *= (1.f - om[q] * om[q]);
       }
-      g[q] = gs + ((arg[(int64_t)b * n_feat + c + q] == i) ? gm : 0.f);
+      g[q] = s1 + ((am[q] == i) ? m1 : 0.f);
     }
     if constexpr (V == 4) {
       *reinterpret_cast<float4*>(dx + (int64_t)i * lddx + c) = make_float4(g[0], g[1], g[2], g[3]);
@@ -208,7 +230,10 @@ int gcmi_readout_bwd(const gcmi_graph* g, const float* d_dout, int64_t lddo, con
   if (g->n_atoms == 0) return GCMI_OK;
   GCMI_CHECK_ARG(d_dout && d_arg && d_dx && g->d_membership, "readout_bwd: NULL buffer");
   hipStream_t st = (hipStream_t)stream;
-  const int V = vec_width(d_dx, lddx, n_feat);
+  const int V = (vec_width(d_dx, lddx, n_feat) == 4 && vec_width(d_dout, lddo, n_feat) == 4 &&
+                 (act == 0 || vec_width(d_out, ldo, n_feat) == 4) && aligned16(d_arg))
+                    ? 4
+                    : 1;
   const int lpr = n_feat / V;
   const int64_t slots = (int64_t)g->n_atoms * lpr;
   if (V == 4)

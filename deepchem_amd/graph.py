@@ -71,6 +71,8 @@ class BatchGraph:
         self.c.d_col_idx = col_idx.data_ptr() if self.n_edges else None
         self.c.d_membership = membership.data_ptr() if (membership is not None and self.n_atoms) else None
         self.c.d_mol_runs = None
+        self.c.d_rev_pos = None
+        self.rev_pos = None
         # segment tables of the per-degree GEMMs: segment d = rows of degree d
         n_seg = max_deg + 1
         self.seg_begin = (ctypes.c_int32 * n_seg)(*self.deg_start[:-1])
@@ -104,6 +106,26 @@ class BatchGraph:
         self.n_mols = int(n_mols)
         self.mol_runs = mol_runs
         self.c.d_mol_runs = mol_runs.data_ptr()
+
+    def ensure_rev_pos(self) -> bool:
+        """Build (once) the reverse-slot table that lets the scatter backwards run as
+        gathers.  Returns False when the adjacency is not symmetric (bonds not listed from
+        both ends): the atomic kernels are used then."""
+        if self.rev_pos is not None:
+            return True
+        if self.symmetric is False:
+            return False
+        rev = torch.empty(max(1, self.n_edges), dtype=torch.uint8, device=self.device)
+        flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        _lib.call("gcmi_build_rev_pos", ctypes.byref(self.c), ctypes.c_void_p(rev.data_ptr()),
+                  ctypes.c_void_p(flag.data_ptr()), _stream())
+        if self.symmetric is None:  # unknown provenance: one read-back per graph
+            self.symmetric = int(flag.item()) == 0
+        if not self.symmetric:
+            return False
+        self.rev_pos = rev
+        self.c.d_rev_pos = rev.data_ptr()
+        return True
 
     @property
     def ref(self):

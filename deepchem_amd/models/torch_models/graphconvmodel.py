@@ -155,42 +155,48 @@ class _GraphConvTorchModel(nn.Module):
         n_samples = int(n_samples)
         x = atom_features.to(torch.float32)
         for i in range(len(self.graph_convs)):
-            gc = self.graph_convs[i]([x, None, None], graph=graph)
             bn_t, has_bn, bn_train, eps, mom = self._bn_args(i)
-            if training and not isinstance(self.dropouts[i], nn.Identity):
+            use_dropout = training and not isinstance(self.dropouts[i], nn.Identity)
+            # a training-mode BatchNorm folded into the pool also folds the ReLU derivative
+            # of the GraphConv in front of it into its backward (one pass less over N x 64)
+            mask_in_bn = has_bn and bn_train and not use_dropout and self.grad_mode == "full"
+            gc = self.graph_convs[i]([x, None, None], graph=graph, grad_masked=mask_in_bn)
+            if use_dropout:
                 if has_bn:
                     gc = _BNApplyFn.apply(gc, *bn_t, bn_train, eps, mom)
                 gc = self.dropouts[i](gc)
-                x = ops.PoolFn.apply(gc, None, None, None, None, graph, False, False, 0.0, 0.0)
+                x = ops.PoolFn.apply(gc, None, None, None, None, graph, False, False, 0.0, 0.0, False)
             else:
-                x = ops.PoolFn.apply(gc, *bn_t, graph, has_bn, bn_train, eps, mom)
-        dense = ops.LinearFn.apply(x, self.dense.weight, self.dense.bias, True)
+                x = ops.PoolFn.apply(gc, *bn_t, graph, has_bn, bn_train, eps, mom, mask_in_bn)
         bn_t, has_bn, bn_train, eps, mom = self._bn_args(len(self.graph_convs))
+        use_dropout = training and not isinstance(self.dropouts[-1], nn.Identity)
+        mask_in_bn = has_bn and bn_train and not use_dropout
+        dense = ops.LinearFn.apply(x, self.dense.weight, self.dense.bias, True, mask_in_bn)
         batch_size = self.graph_gather.batch_size
         assert batch_size > 1, "graph_gather requires batches larger than 1"
-        if training and not isinstance(self.dropouts[-1], nn.Identity):
+        if use_dropout:
             if has_bn:
                 dense = _BNApplyFn.apply(dense, *bn_t, bn_train, eps, mom)
             dense = self.dropouts[-1](dense)
             neural_fingerprint = ops.ReadoutFn.apply(dense, None, None, None, None, graph, batch_size,
-                                                     False, False, 0.0, 0.0, True)
+                                                     False, False, 0.0, 0.0, True, False)
         else:
             neural_fingerprint = ops.ReadoutFn.apply(dense, *bn_t, graph, batch_size, has_bn, bn_train,
-                                                     eps, mom, True)
+                                                     eps, mom, True, mask_in_bn)
         if self.mode == 'classification':
             logits = ops.LinearFn.apply(neural_fingerprint, self.reshape_dense.weight,
-                                        self.reshape_dense.bias, False)
+                                        self.reshape_dense.bias, False, False)
             logits = torch.reshape(logits, (-1, self.n_tasks, self.n_classes))
             logits = self.trim([logits, n_samples])
             output = ops.SoftmaxFn.apply(logits)
             outputs = [output, logits, neural_fingerprint]
         else:
             output = ops.LinearFn.apply(neural_fingerprint, self.regression_dense.weight,
-                                        self.regression_dense.bias, False)
+                                        self.regression_dense.bias, False, False)
             output = self.trim([output, n_samples])
             if self.uncertainty:
                 log_var = ops.LinearFn.apply(neural_fingerprint, self.uncertainty_dense.weight,
-                                             self.uncertainty_dense.bias, False)
+                                             self.uncertainty_dense.bias, False, False)
                 log_var = self.uncertainty_trim([log_var, n_samples])
                 var = torch.exp(log_var)
                 outputs = [output, var, output, log_var, neural_fingerprint]

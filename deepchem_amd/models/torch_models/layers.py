@@ -89,7 +89,10 @@ class GraphConv(nn.Module):
         bsum = torch.cat([b[2 * m:2 * m + 1], b[0:2 * m:2] + b[1:2 * m:2]], 0)  # (max+1, out): both biases
         return w, bsum
 
-    def forward(self, inputs: List[torch.Tensor], graph: Optional[BatchGraph] = None) -> torch.Tensor:
+    def forward(self, inputs: List[torch.Tensor], graph: Optional[BatchGraph] = None,
+                grad_masked: bool = False) -> torch.Tensor:
+        """``graph`` / ``grad_masked`` are used by ``_GraphConvTorchModel`` only: a prebuilt
+        BatchGraph, and the promise that the consumer's backward applies the ReLU mask."""
         atom_features = inputs[0]
         _require_cuda(atom_features, "GraphConv")
         g = _graph(inputs, graph)
@@ -98,10 +101,10 @@ class GraphConv(nn.Module):
         if self.grad_mode == "reference":
             with torch.no_grad():
                 w, bsum = self._packed()
-                out = ops.GraphConvFn.apply(x.detach(), w, bsum, g, fused_relu)
+                out = ops.GraphConvFn.apply(x.detach(), w, bsum, g, fused_relu, False)
         else:
             w, bsum = self._packed()
-            out = ops.GraphConvFn.apply(x, w, bsum, g, fused_relu)
+            out = ops.GraphConvFn.apply(x, w, bsum, g, fused_relu, grad_masked and fused_relu)
         if self.activation_fn is not None and not fused_relu:
             out = self.activation_fn(out)
         return out
@@ -139,7 +142,7 @@ class GraphPool(nn.Module):
         _require_cuda(atom_features, "GraphPool")
         g = _graph(inputs, graph)
         return ops.PoolFn.apply(atom_features.to(torch.float32), None, None, None, None, g, False,
-                                False, 0.0, 0.0)
+                                False, 0.0, 0.0, False)
 
 
 class GraphGather(nn.Module):
@@ -161,7 +164,7 @@ class GraphGather(nn.Module):
         g = _graph(inputs, graph)
         fused_tanh = _is_tanh(self.activation_fn)
         out = ops.ReadoutFn.apply(atom_features.to(torch.float32), None, None, None, None, g,
-                                  self.batch_size, False, False, 0.0, 0.0, fused_tanh)
+                                  self.batch_size, False, False, 0.0, 0.0, fused_tanh, False)
         if self.activation_fn is not None and not fused_tanh:
             out = self.activation_fn(out)
         return out

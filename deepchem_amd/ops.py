@@ -95,7 +95,10 @@ def gather_max_bwd(g: BatchGraph, dout: torch.Tensor, arg: torch.Tensor) -> torc
     F_ = dout.shape[1]
     if arg.dtype != torch.uint8 or tuple(arg.shape) != (g.n_atoms, F_) or not arg.is_contiguous():
         raise ValueError("bad arg tensor")
-    dx = torch.zeros((g.n_atoms, F_), dtype=torch.float32, device=dout.device)
+    if g.ensure_rev_pos():  # gather form: every row written once, no atomics
+        dx = torch.empty((g.n_atoms, F_), dtype=torch.float32, device=dout.device)
+    else:
+        dx = torch.zeros((g.n_atoms, F_), dtype=torch.float32, device=dout.device)
     _lib.call("gcmi_gather_max_bwd", g.ref, _ptr(dout), _ld(dout), F_, _ptr(arg), _ptr(dx), _ld(dx),
               _stream())
     return dx
@@ -138,7 +141,7 @@ def bn_stats(x, gamma, beta, running_mean, running_var, eps: float, momentum: fl
     invstd = torch.empty(F_, dtype=torch.float32, device=dev)
     scale = torch.empty(F_, dtype=torch.float32, device=dev)
     shift = torch.empty(F_, dtype=torch.float32, device=dev)
-    acc = torch.empty(2 * F_, dtype=torch.float64, device=dev)
+    acc = torch.empty(_lib.bn_acc_doubles(F_), dtype=torch.float64, device=dev)
     _lib.call("gcmi_bn_stats", _ptr(x), _ld(x), n, F_, _ptr(_vec(gamma, "gamma", F_)),
               _ptr(_vec(beta, "beta", F_)), float(eps), float(momentum),
               _ptr(_vec(running_mean, "running_mean", F_)), _ptr(_vec(running_var, "running_var", F_)),
@@ -165,7 +168,7 @@ def bn_apply(x, scale, shift):
     return y
 
 
-def bn_bwd(dy, x, gamma, mean, invstd, need_dx: bool):
+def bn_bwd(dy, x, gamma, mean, invstd, need_dx: bool, relu_mask: bool = False):
     _mat(dy, "dy")
     _mat(x, "x", rows=dy.shape[0], cols=dy.shape[1])
     n, F_ = x.shape
@@ -173,10 +176,10 @@ def bn_bwd(dy, x, gamma, mean, invstd, need_dx: bool):
     dgamma = torch.empty(F_, dtype=torch.float32, device=dev)
     dbeta = torch.empty(F_, dtype=torch.float32, device=dev)
     dx = torch.empty((n, F_), dtype=torch.float32, device=dev) if need_dx else None
-    acc = torch.empty(2 * F_, dtype=torch.float64, device=dev)
+    acc = torch.empty(_lib.bn_acc_doubles(F_), dtype=torch.float64, device=dev)
     _lib.call("gcmi_bn_bwd", _ptr(dy), _ld(dy), _ptr(x), _ld(x), n, F_, _ptr(_vec(gamma, "gamma", F_)),
               _ptr(_vec(mean, "mean", F_)), _ptr(_vec(invstd, "invstd", F_)), _ptr(dgamma), _ptr(dbeta),
-              _ptr(dx), _ld(dx) if need_dx else 0, _ptr(acc), _stream())
+              _ptr(dx), _ld(dx) if need_dx else 0, 1 if relu_mask else 0, _ptr(acc), _stream())
     return dgamma, dbeta, dx
 
 
@@ -329,7 +332,9 @@ class GraphConvFn(torch.autograd.Function):
     wpack: (2*max_deg+1, K, n_out) in reference order; bsum: (max_deg+1, n_out)."""
 
     @staticmethod
-    def forward(ctx, x, wpack, bsum, graph: BatchGraph, relu: bool):
+    def forward(ctx, x, wpack, bsum, graph: BatchGraph, relu: bool, grad_masked: bool = False):
+        """grad_masked: the consumer's backward already multiplies by (out > 0) (a folded
+        BatchNorm does), so the ReLU derivative is not applied again."""
         x = rowmajor(x)
         wpack = wpack.contiguous()
         bsum = bsum.contiguous()
@@ -346,7 +351,7 @@ class GraphConvFn(torch.autograd.Function):
         out = seg_gemm(list(graph.seg_begin), list(graph.seg_end), s[:, :k], wpack, w_rel, x[:, :k],
                        wpack, w_self, bsum, b_off, n_out, False, relu, graph.n_atoms, k, k)
         ctx.graph = graph
-        ctx.relu = relu
+        ctx.relu = relu and not grad_masked
         ctx.save_for_backward(x, s, wpack, out)
         return out
 
@@ -378,7 +383,7 @@ class GraphConvFn(torch.autograd.Function):
                 scatter_add(graph, ds, dx)
             if x.shape[1] > k:
                 dx = torch.nn.functional.pad(dx, (0, x.shape[1] - k))
-        return dx, dw, dbs, None, None
+        return dx, dw, dbs, None, None, None
 
 
 class PoolFn(torch.autograd.Function):
@@ -386,7 +391,9 @@ class PoolFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, graph: BatchGraph, bn: bool,
-                training: bool, eps: float, momentum: float):
+                training: bool, eps: float, momentum: float, relu_in: bool = False):
+        """relu_in: x is the output of a fused ReLU whose producer was told
+        ``grad_masked``; the returned gradient is then w.r.t. the ReLU input."""
         x = rowmajor(x)
         _mat(x, "atom_features", rows=graph.n_atoms)
         mean = invstd = scale = shift = None
@@ -397,7 +404,9 @@ class PoolFn(torch.autograd.Function):
             else:
                 scale, shift = bn_fold_eval(gamma, beta, running_mean, running_var, eps)
         out, arg = gather_max(graph, x, scale, shift)
-        ctx.graph, ctx.bn, ctx.training = graph, bn, training
+        if relu_in and not (bn and training):
+            raise ValueError("relu_in needs a training-mode BatchNorm to fold the mask into")
+        ctx.graph, ctx.bn, ctx.training, ctx.relu_in = graph, bn, training, relu_in
         ctx.save_for_backward(x, gamma, mean, invstd, scale, arg)
         return out
 
@@ -406,11 +415,11 @@ class PoolFn(torch.autograd.Function):
         x, gamma, mean, invstd, scale, arg = ctx.saved_tensors
         dy = gather_max_bwd(ctx.graph, rowmajor(dout), arg)
         if not ctx.bn:
-            return dy, None, None, None, None, None, None, None, None, None
+            return (dy,) + (None,) * 10
         if not ctx.training:
             raise NotImplementedError("gradients through an eval-mode BatchNorm are not implemented")
-        dgamma, dbeta, dx = bn_bwd(dy, x, gamma, mean, invstd, ctx.needs_input_grad[0])
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None
+        dgamma, dbeta, dx = bn_bwd(dy, x, gamma, mean, invstd, ctx.needs_input_grad[0], ctx.relu_in)
+        return (dx, dgamma, dbeta) + (None,) * 8
 
 
 class ReadoutFn(torch.autograd.Function):
@@ -419,7 +428,8 @@ class ReadoutFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, graph: BatchGraph, n_mols: int,
-                bn: bool, training: bool, eps: float, momentum: float, tanh: bool):
+                bn: bool, training: bool, eps: float, momentum: float, tanh: bool,
+                relu_in: bool = False):
         x = rowmajor(x)
         _mat(x, "atom_features", rows=graph.n_atoms)
         mean = invstd = scale = shift = None
@@ -430,7 +440,9 @@ class ReadoutFn(torch.autograd.Function):
             else:
                 scale, shift = bn_fold_eval(gamma, beta, running_mean, running_var, eps)
         out, arg = readout(graph, x, n_mols, scale, shift, tanh)
-        ctx.graph, ctx.bn, ctx.training, ctx.tanh = graph, bn, training, tanh
+        if relu_in and not (bn and training):
+            raise ValueError("relu_in needs a training-mode BatchNorm to fold the mask into")
+        ctx.graph, ctx.bn, ctx.training, ctx.tanh, ctx.relu_in = graph, bn, training, tanh, relu_in
         ctx.save_for_backward(x, gamma, mean, invstd, out, arg)
         return out
 
@@ -438,20 +450,19 @@ class ReadoutFn(torch.autograd.Function):
     def backward(ctx, dout):
         x, gamma, mean, invstd, out, arg = ctx.saved_tensors
         dy = readout_bwd(ctx.graph, rowmajor(dout), out, arg, ctx.tanh)
-        none = (None,) * 9
         if not ctx.bn:
-            return (dy,) + (None,) * 11
+            return (dy,) + (None,) * 12
         if not ctx.training:
             raise NotImplementedError("gradients through an eval-mode BatchNorm are not implemented")
-        dgamma, dbeta, dx = bn_bwd(dy, x, gamma, mean, invstd, ctx.needs_input_grad[0])
-        return (dx, dgamma, dbeta) + none
+        dgamma, dbeta, dx = bn_bwd(dy, x, gamma, mean, invstd, ctx.needs_input_grad[0], ctx.relu_in)
+        return (dx, dgamma, dbeta) + (None,) * 10
 
 
 class LinearFn(torch.autograd.Function):
     """act(x . W^T + b) with nn.Linear's (out, in) weight layout."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu: bool):
+    def forward(ctx, x, weight, bias, relu: bool, grad_masked: bool = False):
         x = rowmajor(x)
         weight = weight.contiguous()
         n_out, k = weight.shape
@@ -459,7 +470,7 @@ class LinearFn(torch.autograd.Function):
         n = x.shape[0]
         out = seg_gemm([0], [n], x, weight, [0], None, None, None,
                        None if bias is None else bias.contiguous(), [0], n_out, True, relu, n, k, 0)
-        ctx.relu = relu
+        ctx.relu = relu and not grad_masked
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, weight, out)
         return out
@@ -481,7 +492,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = seg_gemm([0], [n], g, weight, [0], None, None, None, None, None, k, False, False, n,
                           n_out, 0)
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class StandardLossFn(torch.autograd.Function):

@@ -65,6 +65,11 @@ typedef struct gcmi_graph {
   const int32_t* d_mol_runs;            /* n_mols*(max_deg+1)*2: per molecule and
                                            degree the row range [begin,end) of its
                                            atoms; built by gcmi_build_mol_runs     */
+  const uint8_t* d_rev_pos;             /* E (may be NULL): for the edge slot (k, j)
+                                           with i = col_idx[row_ptr(k)+j], the slot of
+                                           k in i's own neighbour list; exists when
+                                           every bond is listed from both ends; built
+                                           by gcmi_build_rev_pos                    */
 } gcmi_graph;
 
 int gcmi_version(void);
@@ -94,6 +99,10 @@ int gcmi_collate(const float* atom_features, int64_t n_feat, const int64_t* atom
  * d_mol_runs from d_membership (device).  d_flag (1 int, device) is set to 1
  * when membership is NOT ascending inside a degree block or out of range.   */
 int gcmi_build_mol_runs(const gcmi_graph* g, int32_t* d_mol_runs, int32_t* d_flag, void* stream);
+/* d_rev_pos from d_col_idx (device).  d_flag is set to 1 when some edge has no
+ * partner (the adjacency is not symmetric): the table is then unusable and the
+ * scatter (atomic) backward kernels must be used.                              */
+int gcmi_build_rev_pos(const gcmi_graph* g, uint8_t* d_rev_pos, int32_t* d_flag, void* stream);
 
 /* ---------------------------------------------------------------- K1 gather-sum
  * GraphConv.sum_neigh (models/torch_models/layers.py:6236-6246):
@@ -114,7 +123,9 @@ int gcmi_scatter_add(const gcmi_graph* g, const float* d_ds, int64_t ldds, int32
  * (torch.max(dim) tie rule).  d_arg[i,f] (uint8, ld = n_feat) records the
  * winner: 0 = self, j+1 = neighbour j.  If d_scale/d_shift are non-NULL the
  * candidates are x*scale[f]+shift[f] (the preceding BatchNorm1d folded in).
- * Backward: dx[winner row, f] += dout[i,f] (atomics), dx pre-zeroed by caller. */
+ * Backward: dx[winner row, f] += dout[i,f].  With g->d_rev_pos the transposed
+ * (gather) form runs -- every dx row is written once, no atomics, deterministic;
+ * without it float atomics into a dx the caller pre-zeroed.                    */
 int gcmi_gather_max_fwd(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t n_feat,
                         const float* d_scale, const float* d_shift, float* d_out, int64_t ldo,
                         uint8_t* d_arg, void* stream);
@@ -143,11 +154,14 @@ int gcmi_readout_bwd(const gcmi_graph* g, const float* d_dout, int64_t lddo, con
  * gcmi_bn_stats: training statistics of x[n_rows x F] -> d_mean, d_invstd,
  *   folded d_scale = gamma*invstd, d_shift = beta - mean*scale; running stats
  *   updated with torch semantics (running = (1-m)*running + m*batch; unbiased
- *   variance into running_var).  d_acc: 2*F doubles of scratch.
+ *   variance into running_var).  d_acc: GCMI_BN_ACC_DOUBLES(F) doubles of scratch
+ *   (column sums are accumulated in 32 replicas to keep fp64 atomics uncontended).
  * gcmi_bn_fold_eval: scale/shift from the running statistics (eval mode).
  * gcmi_bn_apply: y = x*scale + shift (only when the consumer cannot fold it).
  * gcmi_bn_bwd: given dy, x and the saved mean/invstd: dgamma, dbeta and
- *   (if d_dx) dx = gamma*invstd*(dy - dbeta/n - xhat*dgamma/n).               */
+ *   (if d_dx) dx = gamma*invstd*(dy - dbeta/n - xhat*dgamma/n).  relu_mask != 0:
+ *   x is the output of a ReLU and dx is wanted w.r.t. its input: dx *= (x > 0).  */
+#define GCMI_BN_ACC_DOUBLES(F) (66 * (F))
 int gcmi_bn_stats(const float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat,
                   const float* d_gamma, const float* d_beta, float eps, float momentum,
                   float* d_running_mean, float* d_running_var, float* d_mean, float* d_invstd,
@@ -161,7 +175,7 @@ int gcmi_bn_apply(const float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat,
 int gcmi_bn_bwd(const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx, int64_t n_rows,
                 int32_t n_feat, const float* d_gamma, const float* d_mean,
                 const float* d_invstd, float* d_dgamma, float* d_dbeta, float* d_dx,
-                int64_t lddx, double* d_acc, void* stream);
+                int64_t lddx, int32_t relu_mask, double* d_acc, void* stream);
 
 /* ---------------------------------------------------------------- GEMMs (MFMA, exact fp32)
  * Row-segmented affine map on v_mfma_f32_32x32x2_f32:
@@ -227,6 +241,7 @@ enum {
   GCMI_K_READOUT = 2,
   GCMI_K_SEG_GEMM = 3,
   GCMI_K_WGRAD = 4,
+  GCMI_K_GATHER_MAX_BWD = 5,
   GCMI_K_COUNT = 8
 };
 int gcmi_timing_enable(int32_t kernel_id, int32_t on);

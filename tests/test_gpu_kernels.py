@@ -108,6 +108,46 @@ def test_gather_max_fwd_bwd(n_feat, ints):
     assert rel(dx, xc.grad) < TOL  # first-max tie rule: self, then neighbours in table order
 
 
+def test_pool_backward_gather_form_equals_atomic_form_and_detects_asymmetry():
+    from deepchem_amd import ops
+    from deepchem_amd.feat.mol_graphs import ConvMol
+    from deepchem_amd.graph import BatchGraph
+    dev = torch.device("cuda:0")
+    cpu, g, x, _ = make_batch(n_feat=64, seed=23, int_features=True)
+    g.symmetric = None  # unknown provenance: must be detected on the device
+    out, arg = ops.gather_max(g, x)
+    dout = torch.randn(x.shape, generator=torch.Generator().manual_seed(4)).cuda()
+    dx_gather = ops.gather_max_bwd(g, dout, arg)
+    assert g.symmetric is True and g.rev_pos is not None
+    g2 = BatchGraph.from_layer_inputs(cpu[1], cpu[2], cpu[3:], dev)
+    g2.symmetric = False  # force the atomic scatter
+    dx_atomic = ops.gather_max_bwd(g2, dout, arg)
+    assert g2.rev_pos is None
+    assert rel(dx_gather, dx_atomic) < 1e-5
+    # self-loops with multiplicity (the reference's null molecule, mol_graphs.py:236-254)
+    np.random.seed(0)
+    null = ConvMol.agglomerate_mols([ConvMol.get_null_mol(8), ConvMol.get_null_mol(8)])
+    gn = BatchGraph.from_layer_inputs(torch.from_numpy(np.asarray(null.deg_slice)),
+                                      torch.from_numpy(null.membership),
+                                      [torch.from_numpy(a) for a in null.get_deg_adjacency_lists()[1:]], dev)
+    xn = torch.from_numpy(null.get_atom_features().astype(np.float32)).to(dev)
+    on, an = ops.gather_max(gn, xn)
+    dn = torch.randn(xn.shape, generator=torch.Generator().manual_seed(5)).cuda()
+    d1 = ops.gather_max_bwd(gn, dn, an)
+    assert gn.symmetric is True
+    assert rel(d1, dn) < 1e-6  # every candidate is the atom itself: the gradient goes to self
+    # a one-directional bond: not symmetric -> atomics, still the oracle's answer
+    deg_slice = torch.tensor([[0, 1], [1, 1]] + [[2, 0]] * 9)  # atom 0: degree 0, atom 1: degree 1
+    adj = [torch.tensor([[0]], dtype=torch.int32)] + [torch.zeros((0, d), dtype=torch.int32) for d in range(2, 11)]
+    ga = BatchGraph.from_layer_inputs(deg_slice, torch.tensor([0, 0], dtype=torch.int32), adj, dev)
+    xa = torch.tensor([[1.0, 5.0], [2.0, 3.0]]).to(dev)
+    oa, aa = ops.gather_max(ga, xa)
+    da = ops.gather_max_bwd(ga, torch.ones_like(xa), aa)
+    assert ga.symmetric is False
+    assert torch.equal(oa.cpu(), torch.tensor([[1.0, 5.0], [2.0, 5.0]]))
+    assert torch.equal(da.cpu(), torch.tensor([[1.0, 2.0], [1.0, 0.0]]))
+
+
 def test_gather_max_with_folded_batchnorm():
     from deepchem_amd import ops
     cpu, g, x, _ = make_batch(n_feat=64, seed=13)
@@ -174,6 +214,8 @@ def test_batchnorm_stats_fold_bwd(n, f):
     dgamma, dbeta, dx = ops.bn_bwd(dy.cuda(), x.cuda(), gamma.cuda(), mean, invstd, True)
     assert rel(dgamma, gc.grad) < TOL and rel(dbeta, bc.grad) < TOL
     assert float((dx.cpu() - xc.grad).abs().max()) < 1e-4 * max(1.0, float(xc.grad.abs().max()))
+    _, _, dxm = ops.bn_bwd(dy.cuda(), x.cuda(), gamma.cuda(), mean, invstd, True, relu_mask=True)
+    assert torch.equal(dxm, torch.where(x.cuda() > 0, dx, torch.zeros_like(dx)))
     # eval fold
     s2, h2 = ops.bn_fold_eval(gamma.cuda(), beta.cuda(), drm, drv, 1e-3)
     ye = F.batch_norm(x, rm, rv, gamma, beta, False, 0.99, 1e-3)
