@@ -163,53 +163,76 @@ bn_apply_kernel(const float* __restrict__ x, int64_t ldx, int64_t slots, int lpr
   }
 }
 
-// dgamma = sum dy*xhat, dbeta = sum dy (from sums); dx = gamma*invstd*(dy - dbeta/n - xhat*dgamma/n)
+// BatchNorm backward, elementwise part.  With dbeta = sum dy and dgamma = sum dy*xhat
+// already reduced, dx = gamma*invstd*(dy - dbeta/n - xhat*dgamma/n) is affine in (dy, x):
+//   dx = A[c]*dy + B[c]*x + C[c],   A = gamma*invstd,  B = -A*invstd*dgamma/n,
+//   C = -A*dbeta/n - B*mean
+// The three coefficient vectors are produced once (bn_bwd_params_kernel); the streaming
+// kernel keeps them in registers: each thread owns one 16-byte column chunk and walks rows.
 // RELU: x is a ReLU output and dx is wanted w.r.t. the ReLU input: dx *= (x > 0).
-template <int V, bool RELU>
-__global__ void __launch_bounds__(kBBlock)
-bn_bwd_dx_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
-                 int64_t ldx, int64_t n_rows, int n_feat, int64_t slots, int lpr,
-                 const float* __restrict__ gamma, const float* __restrict__ mean,
-                 const float* __restrict__ invstd, const double* __restrict__ sums,
-                 float* __restrict__ dx, int64_t lddx) {
-  const float inv_n = 1.f / (float)n_rows;
-  for (int64_t e = (int64_t)blockIdx.x * kBBlock + threadIdx.x; e < slots;
-       e += (int64_t)gridDim.x * kBBlock) {
-    const int64_t r = e / lpr;
-    const int c = (int)(e - r * lpr) * V;
-    float xv[V], gv[V], o[V];
-    if constexpr (V == 4) {
-      const float4 a4 = *reinterpret_cast<const float4*>(x + r * ldx + c);
-      const float4 b4 = *reinterpret_cast<const float4*>(dy + r * lddy + c);
-      xv[0] = a4.x; xv[1] = a4.y; xv[2] = a4.z; xv[3] = a4.w;
-      gv[0] = b4.x; gv[1] = b4.y; gv[2] = b4.z; gv[3] = b4.w;
-    } else {
-      xv[0] = x[r * ldx + c];
-      gv[0] = dy[r * lddy + c];
-    }
-#pragma unroll
-    for (int q = 0; q < V; ++q) {
-      const float is = invstd[c + q];
-      const float xh = (xv[q] - mean[c + q]) * is;
-      const float db = (float)sums[c + q];
-      const float dg = (float)sums[n_feat + c + q];
-      const float g = gamma ? gamma[c + q] : 1.f;
-      const float v = g * is * (gv[q] - db * inv_n - xh * dg * inv_n);
-      o[q] = (RELU && !(xv[q] > 0.f)) ? 0.f : v;
-    }
-    if constexpr (V == 4) {
-      *reinterpret_cast<float4*>(dx + r * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
-    } else {
-      dx[r * lddx + c] = o[0];
-    }
+__global__ void bn_bwd_params_kernel(const double* __restrict__ sums, int64_t n_rows, int n_feat,
+                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                     const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta, float* __restrict__ coef) {
+  const double inv_n = 1.0 / (double)n_rows;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_feat; c += gridDim.x * blockDim.x) {
+    const double db = sums[c], dg = sums[n_feat + c];
+    if (dbeta) dbeta[c] = (float)db;
+    if (dgamma) dgamma[c] = (float)dg;
+    const double is = (double)invstd[c];
+    const double A = (double)(gamma ? gamma[c] : 1.f) * is;
+    const double B = -A * is * dg * inv_n;
+    const double C = -A * db * inv_n - B * (double)mean[c];
+    coef[c] = (float)A;
+    coef[n_feat + c] = (float)B;
+    coef[2 * n_feat + c] = (float)C;
   }
 }
 
-__global__ void bn_bwd_params_kernel(const double* __restrict__ sums, int n_feat,
-                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_feat; c += gridDim.x * blockDim.x) {
-    if (dbeta) dbeta[c] = (float)sums[c];
-    if (dgamma) dgamma[c] = (float)sums[n_feat + c];
+constexpr int kDxRows = 256;  // rows per workgroup
+
+template <int V, bool RELU>
+__global__ void __launch_bounds__(kBBlock)
+bn_bwd_dx_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+                 int64_t ldx, int64_t n_rows, int n_feat, int lpr, int lx,
+                 const float* __restrict__ coef, float* __restrict__ dx, int64_t lddx) {
+  const int ry = kBBlock / lx;
+  const int ty = threadIdx.x / lx;
+  const int tx = threadIdx.x - ty * lx;
+  if (ty >= ry) return;
+  const int64_t r_begin = (int64_t)blockIdx.x * kDxRows;
+  const int64_t r_end = (r_begin + kDxRows < n_rows) ? r_begin + kDxRows : n_rows;
+  for (int cc = tx; cc < lpr; cc += lx) {
+    const int c = cc * V;
+    float A[V], B[V], C[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      A[q] = coef[c + q];
+      B[q] = coef[n_feat + c + q];
+      C[q] = coef[2 * n_feat + c + q];
+    }
+    for (int64_t r = r_begin + ty; r < r_end; r += ry) {
+      float xv[V], gv[V], o[V];
+      if constexpr (V == 4) {
+        const float4 a4 = *reinterpret_cast<const float4*>(x + r * ldx + c);
+        const float4 b4 = *reinterpret_cast<const float4*>(dy + r * lddy + c);
+        xv[0] = a4.x; xv[1] = a4.y; xv[2] = a4.z; xv[3] = a4.w;
+        gv[0] = b4.x; gv[1] = b4.y; gv[2] = b4.z; gv[3] = b4.w;
+      } else {
+        xv[0] = x[r * ldx + c];
+        gv[0] = dy[r * lddy + c];
+      }
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        const float v = fmaf(A[q], gv[q], fmaf(B[q], xv[q], C[q]));
+        o[q] = (RELU && !(xv[q] > 0.f)) ? 0.f : v;
+      }
+      if constexpr (V == 4) {
+        *reinterpret_cast<float4*>(dx + r * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+        dx[r * lddx + c] = o[0];
+      }
+    }
   }
 }
 
@@ -309,22 +332,22 @@ int gcmi_bn_bwd(const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx, 
   hipStream_t st = (hipStream_t)stream;
   int rc = launch_col_sums(1, d_dy, lddy, d_x, ldx, d_mean, d_invstd, n_rows, n_feat, d_acc, st);
   if (rc) return rc;
-  if (d_dgamma || d_dbeta) {
-    hipLaunchKernelGGL(bn_bwd_params_kernel, dim3((n_feat + 255) / 256), dim3(256), 0, st, d_acc,
-                       n_feat, d_dgamma, d_dbeta);
-    GCMI_CHECK_LAUNCH("bn_bwd_params");
-  }
+  // coefficient vectors live in the (now reduced, hence free) replica area of the scratch
+  float* coef = reinterpret_cast<float*>(d_acc + 2 * (size_t)n_feat);
+  hipLaunchKernelGGL(bn_bwd_params_kernel, dim3((n_feat + 255) / 256), dim3(256), 0, st, d_acc, n_rows,
+                     n_feat, d_gamma, d_mean, d_invstd, d_dgamma, d_dbeta, coef);
+  GCMI_CHECK_LAUNCH("bn_bwd_params");
   if (d_dx) {
     const int V = (vec_width(d_dx, lddx, n_feat) == 4 && vec_width(d_dy, lddy, n_feat) == 4 &&
                    vec_width(d_x, ldx, n_feat) == 4)
                       ? 4
                       : 1;
     const int lpr = n_feat / V;
-    const int64_t slots = n_rows * lpr;
-#define LAUNCH_DX(VV, RR)                                                                        \
-  hipLaunchKernelGGL((bn_bwd_dx_kernel<VV, RR>), dim3(grid_for(slots, kBBlock)), dim3(kBBlock), 0, \
-                     st, d_dy, lddy, d_x, ldx, n_rows, n_feat, slots, lpr, d_gamma, d_mean,       \
-                     d_invstd, d_acc, d_dx, lddx)
+    const int lx = lpr < kBBlock ? lpr : kBBlock;
+    const int blocks = (int)((n_rows + kDxRows - 1) / kDxRows);
+#define LAUNCH_DX(VV, RR)                                                                     \
+  hipLaunchKernelGGL((bn_bwd_dx_kernel<VV, RR>), dim3(blocks), dim3(kBBlock), 0, st, d_dy, lddy, \
+                     d_x, ldx, n_rows, n_feat, lpr, lx, coef, d_dx, lddx)
     if (V == 4) {
       if (relu_mask) LAUNCH_DX(4, true); else LAUNCH_DX(4, false);
     } else {

@@ -66,8 +66,13 @@ __device__ __forceinline__ void stage_a(float (*As)[KC + 1], const float* __rest
     for (int pass = 0; pass < 2; ++pass) {
       const int r = (tid >> 3) + pass * 32;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < rows_valid && k0 + kq < K) {  // K % 4 == 0 here, so the whole float4 is in range
+      if (r < rows_valid && k0 + kq < K) {
+        // lda % 4 == 0 and lda >= K: the 16 bytes stay inside the row even when K % 4 != 0;
+        // columns >= K (row padding) are forced to zero
         v = *reinterpret_cast<const float4*>(a + (int64_t)(row0 + r) * lda + k0 + kq);
+        if (k0 + kq + 1 >= K) v.y = 0.f;
+        if (k0 + kq + 2 >= K) v.z = 0.f;
+        if (k0 + kq + 3 >= K) v.w = 0.f;
       }
       As[r][kq + 0] = v.x;
       As[r][kq + 1] = v.y;
@@ -217,23 +222,44 @@ wgrad_kernel(SlabTable st, const float* __restrict__ a, int64_t lda, int k, int 
     kcol[t] = (kt0 + t) * 32 + (lane & 31);
     k_ok[t] = kcol[t] < k;
   }
-  constexpr int U = 4;  // row pairs in flight
-  for (int r = r_begin; r < r_end; r += 2 * U) {
-    float av[U][KT], bv[U];
+  // Row pairs are loaded U at a time into one register set while the MFMAs of the previous
+  // set run (software double buffering): with 2-4 waves per SIMD that keeps enough bytes in
+  // flight to cover HBM latency.
+  constexpr int U = KT <= 4 ? 8 : 4;
+  float av[2][U][KT], bv[2][U];
+  auto load_set = [&](int buf, int r) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int rr = r + 2 * u + half;
       const bool ok = rr < r_end;
-      bv[u] = (ok && n_ok) ? g[(int64_t)rr * ldg + ncol] : 0.f;
-#pragma unroll
-      for (int t = 0; t < KT; ++t) av[u][t] = (ok && k_ok[t]) ? a[(int64_t)rr * lda + kcol[t]] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      bsum += bv[u];
+      bv[buf][u] = (ok && n_ok) ? g[(int64_t)rr * ldg + ncol] : 0.f;
 #pragma unroll
       for (int t = 0; t < KT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][t], bv[u], acc[t], 0, 0, 0);
+        av[buf][u][t] = (ok && k_ok[t]) ? a[(int64_t)rr * lda + kcol[t]] : 0.f;
+    }
+  };
+  auto mma_set = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      bsum += bv[buf][u];
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u][t], bv[buf][u], acc[t], 0, 0, 0);
+    }
+  };
+  if (r_begin < r_end) {
+    load_set(0, r_begin);
+    int r = r_begin;
+    while (true) {
+      const int r1 = r + 2 * U;
+      if (r1 < r_end) load_set(1, r1);
+      mma_set(0);
+      if (r1 >= r_end) break;
+      const int r2 = r1 + 2 * U;
+      if (r2 < r_end) load_set(0, r2);
+      mma_set(1);
+      if (r2 >= r_end) break;
+      r = r2;
     }
   }
   // combine the row parts of this workgroup through LDS, so that ONE wave per n-tile
@@ -348,8 +374,8 @@ int gcmi_seg_gemm(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_en
   st.tile_start[kMaxSeg] = (int32_t)tiles;
   if (tiles == 0) return GCMI_OK;
   hipStream_t sm = (hipStream_t)stream;
-  const bool vec4 = (d_a1 == nullptr || (aligned16(d_a1) && lda1 % 4 == 0 && k1 % 4 == 0)) &&
-                    (d_a2 == nullptr || (aligned16(d_a2) && lda2 % 4 == 0 && k2 % 4 == 0));
+  const bool vec4 = (d_a1 == nullptr || (aligned16(d_a1) && lda1 % 4 == 0)) &&
+                    (d_a2 == nullptr || (aligned16(d_a2) && lda2 % 4 == 0));
   dim3 grid((unsigned)tiles, (unsigned)((n_out + BNT - 1) / BNT));
   TimedScope ts(GCMI_K_SEG_GEMM, sm);
 #define LAUNCH_SG(TT, VV)                                                                       \
@@ -383,11 +409,12 @@ int gcmi_seg_gemm_wgrad(int32_t n_seg, const int32_t* seg_begin, const int32_t* 
     total_rows += seg_end[s] - seg_begin[s];
   }
   if (total_rows == 0) return GCMI_OK;
-  // slab size: about two workgroups per CU, but never so small that the atomic epilogue
-  // (k x n adds per workgroup into one small block) outweighs the row loop
-  int64_t slab = (total_rows + 511) / 512;
+  // slab size: about eight workgroups per CU (the row loop is latency-bound: it wants many
+  // waves), but never so small that the atomic epilogue (k x n adds per workgroup into one
+  // small block) outweighs the row loop
+  int64_t slab = (total_rows + 2047) / 2048;
   slab = ((slab + 63) / 64) * 64;
-  if (slab < 512) slab = 512;
+  if (slab < 256) slab = 256;
   if (slab > 4096) slab = 4096;
   st.slab_rows = (int32_t)slab;
   int64_t slabs = 0;
