@@ -35,8 +35,56 @@ class GcmiGraph(Structure):
     ]
 
 
+MAX_CONV_LAYERS = 4
+
+
+class GcmiModelDesc(Structure):
+    """struct gcmi_model_desc (include/gcmi.h)."""
+    _fields_ = [
+        ("n_layers", c_int32),
+        ("max_deg", c_int32),
+        ("n_feat_in", c_int32),
+        ("conv_width", c_int32 * MAX_CONV_LAYERS),
+        ("dense_width", c_int32),
+        ("n_tasks", c_int32),
+        ("n_classes", c_int32),
+        ("mode", c_int32),
+        ("batch_norm", c_int32),
+        ("grad_mode", c_int32),
+        ("bn_eps", c_float),
+        ("bn_momentum", c_float),
+        ("off_conv_w", c_int64 * MAX_CONV_LAYERS),
+        ("off_conv_b", c_int64 * MAX_CONV_LAYERS),
+        ("off_bn_gamma", c_int64 * (MAX_CONV_LAYERS + 1)),
+        ("off_bn_beta", c_int64 * (MAX_CONV_LAYERS + 1)),
+        ("off_dense_w", c_int64),
+        ("off_dense_b", c_int64),
+        ("off_head_w", c_int64),
+        ("off_head_b", c_int64),
+        ("n_params", c_int64),
+    ]
+
+
+class GcmiModelIO(Structure):
+    """struct gcmi_model_io (include/gcmi.h)."""
+    _fields_ = [
+        ("d_atom_features", c_void_p),
+        ("ld_features", c_int64),
+        ("d_workspace", c_void_p),
+        ("d_bn_running_mean", c_void_p * (MAX_CONV_LAYERS + 1)),
+        ("d_bn_running_var", c_void_p * (MAX_CONV_LAYERS + 1)),
+        ("d_bn_batches_tracked", c_void_p * (MAX_CONV_LAYERS + 1)),
+        ("d_logits", c_void_p),
+        ("d_probs", c_void_p),
+        ("d_fingerprint", c_void_p),
+        ("d_loss", c_void_p),
+    ]
+
+
 _P = c_void_p
 _G = POINTER(GcmiGraph)
+_MD = POINTER(GcmiModelDesc)
+_MIO = POINTER(GcmiModelIO)
 _I32P = POINTER(c_int32)
 _I64P = POINTER(c_int64)
 
@@ -67,11 +115,13 @@ _SIGNATURES = {
     "gcmi_loss_fwd_bwd": [c_int32, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P],
     "gcmi_softmax": [_P, c_int64, c_int32, _P, _P],
     "gcmi_adam_step": [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int64, _P],
+    "gcmi_model_forward": [_MD, _G, _P, _MIO, c_int32, _P],
+    "gcmi_model_loss_backward": [_MD, _G, _P, _P, _MIO, _P, _P, c_int64, _I64P, _I64P, _P],
     "gcmi_timing_enable": [c_int32, c_int32],
     "gcmi_timing_read": [c_int32, _I64P, POINTER(c_double), c_int32],
 }
 
-EXPORTS = ["gcmi_version", "gcmi_last_error"] + sorted(_SIGNATURES)
+EXPORTS = ["gcmi_version", "gcmi_last_error", "gcmi_model_workspace_floats"] + sorted(_SIGNATURES)
 
 _lib = None
 
@@ -104,6 +154,8 @@ def load():
         raise GcmiError("cannot load %s: %s" % (path, e))
     lib.gcmi_version.restype = ctypes.c_int
     lib.gcmi_last_error.restype = c_char_p
+    lib.gcmi_model_workspace_floats.restype = c_int64
+    lib.gcmi_model_workspace_floats.argtypes = [_MD, c_int64, c_int64]
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes

@@ -1,0 +1,364 @@
+// Whole-model sequencing: _GraphConvTorchModel.forward
+// (models/torch_models/graphconvmodel.py:188-249) and the loss + backward of one
+// fit_generator step (models/torch_models/torch_model.py:436-442) as one C call each.
+// Host code only enqueues the kernels of this library on the caller's stream; the few
+// device functions here are parameter-layout helpers (bias packing, counters).
+#include "common.h"
+
+namespace gcmi {
+
+constexpr int kMaxL = GCMI_MAX_CONV_LAYERS;
+
+__global__ void bias_pack_kernel(const float* __restrict__ b_list, int max_deg, int width,
+                                 float* __restrict__ bsum) {
+  // b_list: (2*max_deg+1, width) in reference order; bsum[d] = b_rel_d + b_self_d, bsum[0] = b_self_0
+  const int n = (max_deg + 1) * width;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int d = i / width, c = i - d * width;
+    bsum[i] = d == 0 ? b_list[(2 * max_deg) * width + c]
+                     : b_list[(2 * (d - 1)) * width + c] + b_list[(2 * (d - 1) + 1) * width + c];
+  }
+}
+
+__global__ void bias_unpack_kernel(const float* __restrict__ dbsum, int max_deg, int width,
+                                   float* __restrict__ db_list) {
+  const int n = (2 * max_deg + 1) * width;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int k = i / width, c = i - k * width;
+    const int d = k == 2 * max_deg ? 0 : k / 2 + 1;
+    db_list[i] = dbsum[d * width + c];
+  }
+}
+
+struct CounterPtrs {
+  int64_t* p[kMaxL + 1];
+  int n;
+};
+__global__ void bump_counters_kernel(CounterPtrs c) {
+  const int i = threadIdx.x;
+  if (i < c.n && c.p[i] != nullptr) *c.p[i] += 1;
+}
+
+static inline int64_t up4(int64_t n) { return (n + 3) / 4 * 4; }
+
+// Workspace carve-up (floats).  Everything the backward needs from the forward, plus the
+// backward's temporaries.  All blocks start 16-byte aligned.
+struct Ws {
+  int64_t S[kMaxL], gc[kMaxL], pool[kMaxL], arg[kMaxL], bsum[kMaxL], bnv[kMaxL + 1];
+  int64_t ldS[kMaxL], ngather[kMaxL];
+  int64_t dense, arg_r, dlogits, dfp, tA, tB, tC, tD, tE, dbsum, acc, total;
+};
+
+static Ws carve(const gcmi_model_desc* m, int64_t N, int64_t B, int64_t ld_features) {
+  Ws w;
+  memset(&w, 0, sizeof(w));
+  int64_t off = 0;
+  auto take = [&](int64_t n) {
+    int64_t o = off;
+    off += up4(n);
+    return o;
+  };
+  const int L = m->n_layers;
+  int64_t wmax = m->dense_width, kmax = up4(m->n_feat_in);
+  for (int l = 0; l < L; ++l) {
+    const int64_t k = l == 0 ? m->n_feat_in : m->conv_width[l - 1];
+    const int64_t ldx = l == 0 ? ld_features : m->conv_width[l - 1];
+    // gather over the padded width when the rows are 16-byte addressable (pad columns are 0)
+    w.ngather[l] = (l == 0 && ldx % 4 == 0 && ldx < k + 4) ? ldx : k;
+    w.ldS[l] = up4(w.ngather[l]);
+    const int64_t wd = m->conv_width[l];
+    w.S[l] = take(N * w.ldS[l]);
+    w.gc[l] = take(N * wd);
+    w.pool[l] = take(N * wd);
+    w.arg[l] = take((N * wd + 3) / 4);
+    w.bsum[l] = take((int64_t)(m->max_deg + 1) * wd);
+    w.bnv[l] = take(4 * wd);
+    if (wd > wmax) wmax = wd;
+    if (w.ldS[l] > kmax) kmax = w.ldS[l];
+  }
+  const int64_t D = m->dense_width;
+  const int64_t TC = (int64_t)m->n_tasks * m->n_classes;
+  w.bnv[L] = take(4 * D);
+  w.dense = take(N * D);
+  w.arg_r = take(B * D);
+  w.dlogits = take(B * TC);
+  w.dfp = take(B * 2 * D);
+  w.tA = take(N * wmax);
+  w.tB = take(N * wmax);
+  w.tC = take(N * wmax);
+  w.tD = take(N * wmax);
+  w.tE = take(N * kmax);
+  w.dbsum = take((int64_t)(m->max_deg + 1) * wmax);
+  w.acc = take(2 * GCMI_BN_ACC_DOUBLES(wmax));
+  w.total = off;
+  return w;
+}
+
+static int check_desc(const gcmi_model_desc* m) {
+  GCMI_CHECK_ARG(m != nullptr, "model desc is NULL");
+  GCMI_CHECK_ARG(m->n_layers >= 1 && m->n_layers <= kMaxL, "n_layers %d outside [1,%d]", m->n_layers, kMaxL);
+  GCMI_CHECK_ARG(m->max_deg >= 0 && m->max_deg <= GCMI_MAX_DEG, "bad max_deg");
+  GCMI_CHECK_ARG(m->n_feat_in > 0 && m->dense_width > 0 && m->n_tasks > 0 && m->n_classes > 0, "bad widths");
+  GCMI_CHECK_ARG(m->mode == 0 || m->mode == 1, "mode must be 0 (classification) or 1 (regression)");
+  GCMI_CHECK_ARG(m->mode == 0 || m->n_classes == 1, "regression needs n_classes == 1");
+  for (int l = 0; l < m->n_layers; ++l) GCMI_CHECK_ARG(m->conv_width[l] > 0, "bad conv width");
+  return GCMI_OK;
+}
+
+struct Segs {
+  int32_t begin[GCMI_MAX_DEG + 1], end[GCMI_MAX_DEG + 1];
+  int64_t w_rel[GCMI_MAX_DEG + 1], w_self[GCMI_MAX_DEG + 1], b_off[GCMI_MAX_DEG + 1];
+  int n;
+};
+
+static Segs make_segs(const gcmi_graph* g, int64_t k, int64_t width) {
+  Segs s;
+  s.n = g->max_deg + 1;
+  const int64_t blk = k * width;
+  for (int d = 0; d <= g->max_deg; ++d) {
+    s.begin[d] = g->deg_start[d];
+    s.end[d] = g->deg_start[d + 1];
+    s.w_rel[d] = d == 0 ? -1 : (int64_t)(2 * (d - 1)) * blk;
+    s.w_self[d] = d == 0 ? (int64_t)(2 * g->max_deg) * blk : (int64_t)(2 * (d - 1) + 1) * blk;
+    s.b_off[d] = (int64_t)d * width;
+  }
+  return s;
+}
+
+#define RUN(call)            \
+  do {                       \
+    int rc__ = (call);       \
+    if (rc__) return rc__;   \
+  } while (0)
+
+}  // namespace gcmi
+
+using namespace gcmi;
+
+extern "C" {
+
+int64_t gcmi_model_workspace_floats(const gcmi_model_desc* m, int64_t n_atoms, int64_t n_mols) {
+  if (check_desc(m) != GCMI_OK || n_atoms < 0 || n_mols < 0) return -1;
+  // ld of the features is not known here: assume the padded width (worst case)
+  return carve(m, n_atoms, n_mols, up4(m->n_feat_in)).total;
+}
+
+int gcmi_model_forward(const gcmi_model_desc* m, const gcmi_graph* g, const float* d_params,
+                       const gcmi_model_io* io, int32_t training, void* stream) {
+  RUN(check_desc(m));
+  RUN(check_graph(g, true));
+  GCMI_CHECK_ARG(io && d_params && io->d_workspace && io->d_logits && io->d_fingerprint,
+                 "model_forward: NULL buffer");
+  GCMI_CHECK_ARG(g->max_deg == m->max_deg, "graph max_deg %d != model max_deg %d", g->max_deg, m->max_deg);
+  GCMI_CHECK_ARG(g->n_mols > 1, "graph_gather requires batches larger than 1");
+  GCMI_CHECK_ARG(g->n_atoms == 0 || io->d_atom_features, "model_forward: NULL atom features");
+  GCMI_CHECK_ARG(io->ld_features >= m->n_feat_in, "ld_features < n_feat_in");
+  hipStream_t st = (hipStream_t)stream;
+  const int L = m->n_layers;
+  const int64_t N = g->n_atoms, B = g->n_mols;
+  const Ws w = carve(m, N, B, io->ld_features);
+  float* ws = io->d_workspace;
+  const float* x = io->d_atom_features;
+  int64_t ldx = io->ld_features;
+  for (int l = 0; l < L; ++l) {
+    const int K = l == 0 ? m->n_feat_in : m->conv_width[l - 1];
+    const int W = m->conv_width[l];
+    const Segs sg = make_segs(g, K, W);
+    hipLaunchKernelGGL(bias_pack_kernel, dim3(4), dim3(256), 0, st, d_params + m->off_conv_b[l],
+                       m->max_deg, W, ws + w.bsum[l]);
+    GCMI_CHECK_LAUNCH("bias_pack");
+    if (N > 0) {
+      RUN(gcmi_gather_sum_fwd(g, x, ldx, (int32_t)w.ngather[l], ws + w.S[l], w.ldS[l], 0, stream));
+      RUN(gcmi_seg_gemm(sg.n, sg.begin, sg.end, ws + w.S[l], w.ldS[l], K, d_params + m->off_conv_w[l],
+                        sg.w_rel, x, ldx, K, d_params + m->off_conv_w[l], sg.w_self, ws + w.bsum[l],
+                        sg.b_off, W, 0, 1, ws + w.gc[l], W, stream));
+    }
+    float* scale = nullptr;
+    float* shift = nullptr;
+    if (m->batch_norm && N > 0) {
+      float* bnv = ws + w.bnv[l];
+      scale = bnv + 2 * W;
+      shift = bnv + 3 * W;
+      if (training) {
+        RUN(gcmi_bn_stats(ws + w.gc[l], W, N, W, d_params + m->off_bn_gamma[l],
+                          d_params + m->off_bn_beta[l], m->bn_eps, m->bn_momentum,
+                          io->d_bn_running_mean[l], io->d_bn_running_var[l], bnv, bnv + W, scale, shift,
+                          reinterpret_cast<double*>(ws + w.acc), stream));
+      } else {
+        RUN(gcmi_bn_fold_eval(d_params + m->off_bn_gamma[l], d_params + m->off_bn_beta[l],
+                              io->d_bn_running_mean[l], io->d_bn_running_var[l], m->bn_eps, W, scale,
+                              shift, stream));
+      }
+    }
+    if (N > 0)
+      RUN(gcmi_gather_max_fwd(g, ws + w.gc[l], W, W, scale, shift, ws + w.pool[l], W,
+                              training ? reinterpret_cast<uint8_t*>(ws + w.arg[l]) : nullptr, stream));
+    x = ws + w.pool[l];
+    ldx = W;
+  }
+  const int Wl = m->conv_width[L - 1];
+  const int D = m->dense_width;
+  const int32_t zero32 = 0;
+  const int64_t zero64 = 0;
+  if (N > 0) {
+    const int32_t nN = (int32_t)N;
+    RUN(gcmi_seg_gemm(1, &zero32, &nN, x, ldx, Wl, d_params + m->off_dense_w, &zero64, nullptr, 0, 0,
+                      nullptr, nullptr, d_params + m->off_dense_b, &zero64, D, 1, 1, ws + w.dense, D,
+                      stream));
+  }
+  float* scale = nullptr;
+  float* shift = nullptr;
+  if (m->batch_norm && N > 0) {
+    float* bnv = ws + w.bnv[L];
+    scale = bnv + 2 * D;
+    shift = bnv + 3 * D;
+    if (training) {
+      RUN(gcmi_bn_stats(ws + w.dense, D, N, D, d_params + m->off_bn_gamma[L], d_params + m->off_bn_beta[L],
+                        m->bn_eps, m->bn_momentum, io->d_bn_running_mean[L], io->d_bn_running_var[L], bnv,
+                        bnv + D, scale, shift, reinterpret_cast<double*>(ws + w.acc), stream));
+    } else {
+      RUN(gcmi_bn_fold_eval(d_params + m->off_bn_gamma[L], d_params + m->off_bn_beta[L],
+                            io->d_bn_running_mean[L], io->d_bn_running_var[L], m->bn_eps, D, scale, shift,
+                            stream));
+    }
+  }
+  RUN(gcmi_readout_fwd(g, ws + w.dense, D, D, scale, shift, 1, io->d_fingerprint, 2 * D,
+                       reinterpret_cast<int32_t*>(ws + w.arg_r), stream));
+  const int TC = m->n_tasks * m->n_classes;
+  const int32_t nB = (int32_t)B;
+  RUN(gcmi_seg_gemm(1, &zero32, &nB, io->d_fingerprint, 2 * D, 2 * D, d_params + m->off_head_w, &zero64,
+                    nullptr, 0, 0, nullptr, nullptr, d_params + m->off_head_b, &zero64, TC, 1, 0,
+                    io->d_logits, TC, stream));
+  if (m->mode == 0 && io->d_probs)
+    RUN(gcmi_softmax(io->d_logits, B * m->n_tasks, m->n_classes, io->d_probs, stream));
+  if (training && m->batch_norm) {
+    CounterPtrs c;
+    c.n = L + 1;
+    bool any = false;
+    for (int i = 0; i <= kMaxL; ++i) {
+      c.p[i] = i <= L ? io->d_bn_batches_tracked[i] : nullptr;
+      any = any || c.p[i] != nullptr;
+    }
+    if (any) {
+      hipLaunchKernelGGL(bump_counters_kernel, dim3(1), dim3(64), 0, st, c);
+      GCMI_CHECK_LAUNCH("bump_counters");
+    }
+  }
+  return GCMI_OK;
+}
+
+int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, const float* d_params,
+                             float* d_grads, const gcmi_model_io* io, const float* d_labels,
+                             const float* d_weights, int64_t n_rows, int64_t* grad_lo,
+                             int64_t* grad_hi, void* stream) {
+  RUN(check_desc(m));
+  RUN(check_graph(g, true));
+  GCMI_CHECK_ARG(io && d_params && d_grads && io->d_workspace && io->d_logits && io->d_fingerprint &&
+                     io->d_loss && d_labels,
+                 "model_loss_backward: NULL buffer");
+  GCMI_CHECK_ARG(n_rows > 0 && n_rows <= g->n_mols, "n_rows %lld outside (0, n_mols=%d]", (long long)n_rows,
+                 g->n_mols);
+  hipStream_t st = (hipStream_t)stream;
+  const int L = m->n_layers;
+  const int64_t N = g->n_atoms, B = g->n_mols;
+  const Ws w = carve(m, N, B, io->ld_features);
+  float* ws = io->d_workspace;
+  const int D = m->dense_width;
+  const int TC = m->n_tasks * m->n_classes;
+  const bool full = m->grad_mode == 1;
+  const bool sym = g->d_rev_pos != nullptr || g->n_edges == 0;
+  const int64_t lo = full ? 0 : (m->batch_norm ? m->off_bn_gamma[L - 1] : m->off_dense_w);
+  const int64_t hi = m->n_params;
+  if (grad_lo) *grad_lo = lo;
+  if (grad_hi) *grad_hi = hi;
+  auto zero = [&](void* p, size_t bytes) -> int {
+    if (bytes && hipMemsetAsync(p, 0, bytes, st) != hipSuccess) {
+      set_error("model_loss_backward: memset failed");
+      return GCMI_ERR_LAUNCH;
+    }
+    return GCMI_OK;
+  };
+  RUN(zero(d_grads + lo, sizeof(float) * (size_t)(hi - lo)));
+  // ---- loss on the first n_rows molecules; rows beyond carry no gradient
+  RUN(zero(ws + w.dlogits, sizeof(float) * (size_t)(B * TC)));
+  RUN(gcmi_loss_fwd_bwd(m->mode == 0 ? 0 : 1, io->d_logits, d_labels, d_weights, n_rows, m->n_tasks,
+                        m->n_classes, io->d_loss, ws + w.dlogits, nullptr,
+                        reinterpret_cast<double*>(ws + w.acc), stream));
+  const int32_t zero32 = 0;
+  const int64_t zero64 = 0;
+  const int32_t nB = (int32_t)B, nN = (int32_t)N;
+  // ---- head
+  RUN(gcmi_seg_gemm_wgrad(1, &zero32, &nB, io->d_fingerprint, 2 * D, 2 * D, ws + w.dlogits, TC, TC,
+                          d_grads + m->off_head_w, &zero64, d_grads + m->off_head_b, &zero64, 1, stream));
+  RUN(gcmi_seg_gemm(1, &zero32, &nB, ws + w.dlogits, TC, TC, d_params + m->off_head_w, &zero64, nullptr, 0,
+                    0, nullptr, nullptr, nullptr, nullptr, 2 * D, 0, 0, ws + w.dfp, 2 * D, stream));
+  if (N == 0) return GCMI_OK;
+  // ---- readout (+ folded BatchNorm of the dense layer, + its ReLU mask)
+  float* dyD = ws + w.tA;   // grad w.r.t. the (normalised) readout input
+  float* dxD = ws + w.tB;   // grad w.r.t. the dense pre-activation
+  RUN(gcmi_readout_bwd(g, ws + w.dfp, 2 * D, io->d_fingerprint, 2 * D, D, 1,
+                       reinterpret_cast<const int32_t*>(ws + w.arg_r), dyD, D, stream));
+  if (m->batch_norm) {
+    const float* bnv = ws + w.bnv[L];
+    RUN(gcmi_bn_bwd(dyD, D, ws + w.dense, D, N, D, d_params + m->off_bn_gamma[L], bnv, bnv + D,
+                    d_grads + m->off_bn_gamma[L], d_grads + m->off_bn_beta[L], dxD, D, 1,
+                    reinterpret_cast<double*>(ws + w.acc), stream));
+  } else {
+    RUN(gcmi_relu_bwd(dyD, D, ws + w.dense, D, N, D, stream));
+    dxD = dyD;
+  }
+  // ---- dense layer
+  const int Wl = m->conv_width[L - 1];
+  RUN(gcmi_seg_gemm_wgrad(1, &zero32, &nN, ws + w.pool[L - 1], Wl, Wl, dxD, D, D, d_grads + m->off_dense_w,
+                          &zero64, d_grads + m->off_dense_b, &zero64, 1, stream));
+  float* dpool = ws + w.tC;  // grad w.r.t. the output of the last GraphPool
+  RUN(gcmi_seg_gemm(1, &zero32, &nN, dxD, D, D, d_params + m->off_dense_w, &zero64, nullptr, 0, 0, nullptr,
+                    nullptr, nullptr, nullptr, Wl, 0, 0, dpool, Wl, stream));
+  // ---- GraphConv / BatchNorm / GraphPool blocks, last to first
+  for (int l = L - 1; l >= 0; --l) {
+    if (!full && !m->batch_norm) break;  // nothing trainable in front of the dense layer
+    const int W = m->conv_width[l];
+    const int K = l == 0 ? m->n_feat_in : m->conv_width[l - 1];
+    float* dy = ws + w.tD;  // grad w.r.t. the (normalised) pool input
+    if (!sym) RUN(zero(dy, sizeof(float) * (size_t)(N * W)));
+    RUN(gcmi_gather_max_bwd(g, dpool, W, W, reinterpret_cast<const uint8_t*>(ws + w.arg[l]), dy, W, stream));
+    float* dgc = ws + w.tA;  // grad w.r.t. the GraphConv pre-activation
+    if (m->batch_norm) {
+      const float* bnv = ws + w.bnv[l];
+      RUN(gcmi_bn_bwd(dy, W, ws + w.gc[l], W, N, W, d_params + m->off_bn_gamma[l], bnv, bnv + W,
+                      d_grads + m->off_bn_gamma[l], d_grads + m->off_bn_beta[l], full ? dgc : nullptr, W, 1,
+                      reinterpret_cast<double*>(ws + w.acc), stream));
+    } else if (full) {
+      RUN(gcmi_relu_bwd(dy, W, ws + w.gc[l], W, N, W, stream));
+      dgc = dy;
+    }
+    if (!full) break;  // reference semantics: nothing in front of a GraphConv output trains
+    const Segs sg = make_segs(g, K, W);
+    const float* xin = l == 0 ? io->d_atom_features : ws + w.pool[l - 1];
+    const int64_t ldx = l == 0 ? io->ld_features : m->conv_width[l - 1];
+    RUN(zero(ws + w.dbsum, sizeof(float) * (size_t)((m->max_deg + 1) * W)));
+    RUN(gcmi_seg_gemm_wgrad(sg.n, sg.begin, sg.end, ws + w.S[l], w.ldS[l], K, dgc, W, W,
+                            d_grads + m->off_conv_w[l], sg.w_rel, nullptr, nullptr, 0, stream));
+    RUN(gcmi_seg_gemm_wgrad(sg.n, sg.begin, sg.end, xin, ldx, K, dgc, W, W, d_grads + m->off_conv_w[l],
+                            sg.w_self, ws + w.dbsum, sg.b_off, 0, stream));
+    hipLaunchKernelGGL(bias_unpack_kernel, dim3(4), dim3(256), 0, st, ws + w.dbsum, m->max_deg, W,
+                       d_grads + m->off_conv_b[l]);
+    GCMI_CHECK_LAUNCH("bias_unpack");
+    if (l == 0) break;  // the atom features need no gradient
+    // dS = dgc . W_rel^T ; dX = dgc . W_self^T + (transposed gather of dS)
+    float* dS = ws + w.tE;
+    float* dX = ws + w.tC;
+    RUN(gcmi_seg_gemm(sg.n, sg.begin, sg.end, dgc, W, W, d_params + m->off_conv_w[l], sg.w_rel, nullptr, 0,
+                      0, nullptr, nullptr, nullptr, nullptr, K, 1, 0, dS, K, stream));
+    RUN(gcmi_seg_gemm(sg.n, sg.begin, sg.end, dgc, W, W, d_params + m->off_conv_w[l], sg.w_self, nullptr, 0,
+                      0, nullptr, nullptr, nullptr, nullptr, K, 1, 0, dX, K, stream));
+    if (sym)
+      RUN(gcmi_gather_sum_fwd(g, dS, K, K, dX, K, 1, stream));
+    else
+      RUN(gcmi_scatter_add(g, dS, K, K, dX, K, stream));
+    dpool = dX;
+  }
+  return GCMI_OK;
+}
+
+}  // extern "C"

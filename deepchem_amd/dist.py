@@ -47,6 +47,13 @@ class FlatGradAllReduce:
         self.world_size = world_size if world_size is not None else dist.get_world_size(group)
         self._bucket: Optional[torch.Tensor] = None
 
+    def reduce_flat(self, bucket: torch.Tensor) -> None:
+        """Gradients that already live in one flat arena: all-reduce the trained range in place."""
+        if self.world_size == 1 or bucket.numel() == 0:
+            return
+        dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
+        bucket.mul_(1.0 / self.world_size)
+
     def __call__(self, module: torch.nn.Module) -> None:
         grads: List[torch.Tensor] = [p.grad for p in module.parameters() if p.grad is not None]
         if not grads or self.world_size == 1:

@@ -40,6 +40,69 @@ class GcmiAdam(torch.optim.Optimizer):
                         maximize=False, foreach=None, capturable=False, differentiable=False,
                         fused=None)
         super().__init__(params, defaults)
+        self._flat = None
+
+    def attach_flat(self, param_flat: torch.Tensor, grad_flat: torch.Tensor, slices):
+        """All parameters (in order) are views of ``param_flat`` and their gradients views of
+        ``grad_flat`` (``slices``: (offset, numel) per parameter): ``step_flat`` then updates any
+        contiguous range with ONE launch.  exp_avg / exp_avg_sq become views of two flat buffers,
+        so ``state_dict()`` keeps torch.optim.Adam's per-parameter layout."""
+        params = [p for g in self.param_groups for p in g["params"]]
+        if len(params) != len(slices):
+            raise ValueError("attach_flat: %d parameters, %d slices" % (len(params), len(slices)))
+        m = torch.zeros_like(param_flat)
+        v = torch.zeros_like(param_flat)
+        # carry over any state that already exists (restore() before the first native step)
+        for p, (off, n) in zip(params, slices):
+            st = self.state.get(p)
+            if st:
+                m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+        self._flat = dict(p=param_flat, g=grad_flat, m=m, v=v, slices=list(slices), params=params)
+
+    def _flat_state(self, p, off, n, step_value):
+        st = self.state[p]
+        if len(st) == 0 or st["exp_avg"].data_ptr() != self._flat["m"].data_ptr() + 4 * off:
+            old_step = float(st["step"]) if "step" in st else step_value
+            st["step"] = torch.tensor(old_step, dtype=torch.float32)
+            st["exp_avg"] = self._flat["m"][off:off + n].view(p.shape)
+            st["exp_avg_sq"] = self._flat["v"][off:off + n].view(p.shape)
+        return st
+
+    @torch.no_grad()
+    def step_flat(self, lo: int, hi: int):
+        """Adam on the flat range [lo, hi) (floats): one kernel launch.  Every parameter inside the
+        range must have taken part in every flat step so far (same step count)."""
+        f = self._flat
+        group = self.param_groups[0]
+        beta1, beta2 = group["betas"]
+        step = None
+        for p, (off, n) in zip(f["params"], f["slices"]):
+            if lo <= off and off + n <= hi:
+                st = self._flat_state(p, off, n, 0.0)
+                st["step"] += 1
+                s = int(st["step"].item())
+                if step is None:
+                    step = s
+                elif s != step:
+                    raise RuntimeError("parameters of one flat range have different Adam step counts")
+        if step is None:
+            return
+        ops.adam_step_(f["p"][lo:hi], f["g"][lo:hi], f["m"][lo:hi], f["v"][lo:hi], group["lr"], beta1,
+                       beta2, group["eps"], step)
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        if self._flat is not None:  # re-home the loaded moments into the flat buffers
+            f = self._flat
+            for p, (off, n) in zip(f["params"], f["slices"]):
+                st = self.state.get(p)
+                if st and "exp_avg" in st:
+                    f["m"][off:off + n].copy_(st["exp_avg"].reshape(-1))
+                    f["v"][off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                    st["exp_avg"] = f["m"][off:off + n].view(p.shape)
+                    st["exp_avg_sq"] = f["v"][off:off + n].view(p.shape)
+                    st["step"] = torch.as_tensor(st["step"], dtype=torch.float32).cpu()
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -143,17 +143,7 @@ class TorchModel(Model):
             inputs, labels, weights = self._prepare_batch(batch)
             if isinstance(inputs, list) and len(inputs) == 1:
                 inputs = inputs[0]
-            optimizer.zero_grad()
-            outputs = self.model(inputs)
-            if isinstance(outputs, torch.Tensor):
-                outputs = [outputs]
-            if self._loss_outputs is not None:
-                outputs = [outputs[i] for i in self._loss_outputs]
-            batch_loss = loss(outputs, labels, weights)
-            batch_loss.backward()
-            if self._grad_sync is not None:
-                self._grad_sync(self.model)  # data-parallel ranks: one flat all-reduce per step
-            optimizer.step()
+            batch_loss = self._train_step(inputs, labels, weights, loss, optimizer)
             if lr_schedule is not None:
                 lr_schedule.step()
             self._global_step += 1
@@ -189,6 +179,22 @@ class TorchModel(Model):
         time2 = time.time()
         logger.info("TIMING: model fitting took %0.3f s" % (time2 - time1))
         return last_avg_loss
+
+    def _train_step(self, inputs, labels, weights, loss, optimizer):
+        """zero_grad, forward, loss, backward, (gradient all-reduce), optimizer step
+        (torch_model.py:435-443).  Subclasses may replace it by a fused native step."""
+        optimizer.zero_grad()
+        outputs = self.model(inputs)
+        if isinstance(outputs, torch.Tensor):
+            outputs = [outputs]
+        if self._loss_outputs is not None:
+            outputs = [outputs[i] for i in self._loss_outputs]
+        batch_loss = loss(outputs, labels, weights)
+        batch_loss.backward()
+        if self._grad_sync is not None:
+            self._grad_sync(self.model)  # data-parallel ranks: one flat all-reduce per step
+        optimizer.step()
+        return batch_loss
 
     def fit_on_batch(self, X: Sequence, y: Sequence, w: Sequence, variables=None, loss=None,
                      callbacks: Union[Callable, List[Callable]] = [], checkpoint: bool = True,

@@ -232,6 +232,68 @@ int gcmi_softmax(const float* d_logits, int64_t n_rows_tasks, int32_t n_classes,
 int gcmi_adam_step(float* d_param, const float* d_grad, float* d_m, float* d_v, int64_t n,
                    float lr, float beta1, float beta2, float eps, int64_t step, void* stream);
 
+/* ---------------------------------------------------------------- whole-model sequencing
+ * _GraphConvTorchModel.forward (models/torch_models/graphconvmodel.py:188-249) and the
+ * loss + backward of one fit_generator step (models/torch_models/torch_model.py:436-442)
+ * as ONE call each: the library enqueues every kernel back to back on `stream`, so a
+ * training step costs three C calls (forward, loss_backward, gcmi_adam_step on the flat
+ * gradient range) instead of ~150 Python-driven launches.  Nothing here allocates: the
+ * caller owns the parameter arena, the gradient arena and the workspace.
+ *
+ * Parameters live in ONE flat fp32 arena in nn.Module.parameters() order; the offsets
+ * below (in floats) locate each block.  GraphConv layer l: 2*max_deg+1 weight blocks
+ * (K_l x width_l each) in the reference order rel_1, self_1, ..., self_0, then the
+ * 2*max_deg+1 bias vectors.  nn.Linear blocks are (out, in).  The gradient arena has
+ * the same layout.
+ */
+#define GCMI_MAX_CONV_LAYERS 4
+typedef struct gcmi_model_desc {
+  int32_t n_layers;                      /* GraphConv layers, <= GCMI_MAX_CONV_LAYERS        */
+  int32_t max_deg;                       /* 10                                               */
+  int32_t n_feat_in;                     /* atom feature width (75)                          */
+  int32_t conv_width[GCMI_MAX_CONV_LAYERS];
+  int32_t dense_width;                   /* 128                                              */
+  int32_t n_tasks;
+  int32_t n_classes;                     /* classification: >= 2; regression: 1              */
+  int32_t mode;                          /* 0 classification, 1 regression                   */
+  int32_t batch_norm;                    /* 0 / 1                                            */
+  int32_t grad_mode;                     /* 0 reference (autograd cut at GraphConv), 1 full  */
+  float bn_eps, bn_momentum;
+  int64_t off_conv_w[GCMI_MAX_CONV_LAYERS], off_conv_b[GCMI_MAX_CONV_LAYERS];
+  int64_t off_bn_gamma[GCMI_MAX_CONV_LAYERS + 1], off_bn_beta[GCMI_MAX_CONV_LAYERS + 1];
+  int64_t off_dense_w, off_dense_b, off_head_w, off_head_b;
+  int64_t n_params;
+} gcmi_model_desc;
+
+typedef struct gcmi_model_io {
+  const float* d_atom_features;          /* N x ld_features                                  */
+  int64_t ld_features;
+  float* d_workspace;                    /* gcmi_model_workspace_floats() floats             */
+  float* d_bn_running_mean[GCMI_MAX_CONV_LAYERS + 1];
+  float* d_bn_running_var[GCMI_MAX_CONV_LAYERS + 1];
+  int64_t* d_bn_batches_tracked[GCMI_MAX_CONV_LAYERS + 1]; /* may be NULL                    */
+  /* outputs, all g->n_mols rows (TrimGraphOutput is a view the caller takes):               */
+  float* d_logits;                       /* n_mols x (n_tasks*n_classes)  (regression: n_tasks) */
+  float* d_probs;                        /* classification softmax; may be NULL              */
+  float* d_fingerprint;                  /* n_mols x 2*dense_width                           */
+  float* d_loss;                         /* 1 float (loss_backward)                          */
+} gcmi_model_io;
+
+/* floats of workspace needed for a batch of n_atoms / n_mols (forward + backward). */
+int64_t gcmi_model_workspace_floats(const gcmi_model_desc* m, int64_t n_atoms, int64_t n_mols);
+/* training != 0: BatchNorm uses batch statistics and updates the running ones. The
+ * graph needs d_mol_runs; the backward additionally uses d_rev_pos when present.            */
+int gcmi_model_forward(const gcmi_model_desc* m, const gcmi_graph* g, const float* d_params,
+                       const gcmi_model_io* io, int32_t training, void* stream);
+/* After a training-mode gcmi_model_forward on the same workspace: loss over the first
+ * n_rows molecules (SoftmaxCrossEntropy / L2Loss through _StandardLoss) -> io->d_loss, then
+ * the backward pass; gradients are WRITTEN (not accumulated) into d_grads for every
+ * parameter the gradient mode trains; [*grad_lo, *grad_hi) returns that range (floats).     */
+int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, const float* d_params,
+                             float* d_grads, const gcmi_model_io* io, const float* d_labels,
+                             const float* d_weights, int64_t n_rows, int64_t* grad_lo,
+                             int64_t* grad_hi, void* stream);
+
 /* ---------------------------------------------------------------- measurement
  * Optional per-kernel timing with hipEvents recorded on `stream` around the
  * launches of one kernel family (bench.py roofline).  id: see GCMI_K_*.       */

