@@ -117,6 +117,7 @@ _SIGNATURES = {
     "gcmi_adam_step": [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int64, _P],
     "gcmi_model_forward": [_MD, _G, _P, _MIO, c_int32, _P],
     "gcmi_model_loss_backward": [_MD, _G, _P, _P, _MIO, _P, _P, c_int64, _I64P, _I64P, _P],
+    "gcmi_diag_mfma_peak": [c_int32, c_int32, _P, _P],
     "gcmi_timing_enable": [c_int32, c_int32],
     "gcmi_timing_read": [c_int32, _I64P, POINTER(c_double), c_int32],
 }

@@ -29,6 +29,7 @@ constexpr int kGBlock = 256;
 constexpr int BM = 64;
 constexpr int BNT = 64;
 constexpr int KC = 32;
+constexpr int BM2 = 128;
 
 struct SegTable {
   int32_t n_seg;
@@ -175,6 +176,216 @@ seg_gemm_kernel(SegTable st, const float* __restrict__ a1, int64_t lda1, int k1,
   }
 }
 
+// ------------------------------------------------------------------ forward, pipelined
+// Same contract as seg_gemm_kernel for 16-byte addressable rows, restructured for the matrix
+// pipe: 128 rows x (NT*32) columns per workgroup (each wave 32 rows x all columns: one A
+// fragment feeds NT MFMAs), and the NEXT K-chunk is fetched from global memory into registers
+// while the MFMAs of the current chunk run, so HBM/L2 latency overlaps the matrix work of the
+// same workgroup instead of relying on other workgroups to cover it.
+
+template <bool TRANS, int NT, int BMT, bool FRAG, int KCT>
+__global__ void __launch_bounds__(kGBlock)
+seg_gemm2_kernel(SegTable st, const float* __restrict__ a1, int64_t lda1, int k1,
+                 const float* __restrict__ w1, const float* __restrict__ a2, int64_t lda2, int k2,
+                 const float* __restrict__ w2, const float* __restrict__ bias, int n_out, int act,
+                 float* __restrict__ out, int64_t ldo, int diag) {
+  constexpr int BN2 = NT * 32;
+  constexpr int BPASS = (KCT * BN2) / kGBlock;  // B elements per thread per chunk
+  constexpr int LPRW = KCT / 4;          // lanes per A row (16 bytes each)
+  constexpr int RPP = kGBlock / LPRW;    // A rows per pass
+  constexpr int APASS = BMT / RPP;   // A float4 per thread per chunk
+  constexpr int WR = BMT / 32;      // wave rows: BMT=128 -> 4 waves x 32 rows; BMT=64 -> 2 x 2 waves
+  constexpr int WC = 4 / WR;        // waves side by side along the columns
+  constexpr int NTW = NT / WC > 0 ? NT / WC : 1;  // 32-column tiles per wave
+  __shared__ float As[BMT][KCT + 1];
+  __shared__ float Bs[KCT][BN2 + 1];
+  const int b = blockIdx.x;
+  const int s = seg_of_tile(st, b);
+  const int row0 = pick_seg(st.seg_begin, s) + (b - pick_seg(st.tile_start, s)) * BMT;
+  const int seg_end = pick_seg(st.seg_end, s);
+  const int rows_valid = (seg_end - row0 < BMT) ? seg_end - row0 : BMT;
+  const int col0 = blockIdx.y * BN2;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int half = lane >> 5;
+  const int wrow = wave % WR, wcol = wave / WR;
+  f32x16 acc[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  const int64_t woff1 = pick_seg(st.w1_off, s), woff2 = pick_seg(st.w2_off, s);
+  const bool on1 = a1 != nullptr && w1 != nullptr && woff1 >= 0;
+  const bool on2 = a2 != nullptr && w2 != nullptr && woff2 >= 0;
+  const int n1 = on1 ? (k1 + KCT - 1) / KCT : 0;
+  const int n2 = on2 ? (k2 + KCT - 1) / KCT : 0;
+  const int nchunks = n1 + n2;
+
+  // Prefetch registers.  Loads are UNCONDITIONAL from clamped (always valid) addresses and
+  // nothing consumes them until sstore(): a guarded load ("cond ? load : 0") makes hipcc branch
+  // around it and wait vmcnt(0) on the spot, which serialises the prefetch.  Out-of-range rows,
+  // columns >= K and columns >= n_out are zeroed when the registers go to LDS.
+  float4 ra[APASS];
+  float rb[BPASS];
+  int pend_k0 = 0, pend_K = 0;
+  auto gload = [&](int c) {
+    const bool first = c < n1;
+    const float* a = first ? a1 : a2;
+    const int64_t lda = first ? lda1 : lda2;
+    const int K = first ? k1 : k2;
+    const float* w = first ? w1 + woff1 : w2 + woff2;
+    const int k0 = (first ? c : c - n1) * KCT;
+    pend_k0 = k0;
+    pend_K = K;
+    const int kcol = k0 + (tid % LPRW) * 4;
+    const int kc = kcol < K ? kcol : 0;
+#pragma unroll
+    for (int pass = 0; pass < APASS; ++pass) {
+      const int r = tid / LPRW + pass * RPP;
+      const int rc = r < rows_valid ? r : rows_valid - 1;
+      ra[pass] = *reinterpret_cast<const float4*>(a + (int64_t)(row0 + rc) * lda + kc);
+    }
+    if constexpr (!TRANS) {  // w is K x n_out
+      const int j = col0 + tid % BN2;
+      const int jc = j < n_out ? j : n_out - 1;
+#pragma unroll
+      for (int pass = 0; pass < BPASS; ++pass) {
+        const int kk = k0 + tid / BN2 + pass * (kGBlock / BN2);
+        const int kkc = kk < K ? kk : K - 1;
+        rb[pass] = w[(int64_t)kkc * n_out + jc];
+      }
+    } else {  // w is n_out x K
+      const int kk = k0 + (tid % KCT);
+      const int kkc = kk < K ? kk : K - 1;
+#pragma unroll
+      for (int pass = 0; pass < BPASS; ++pass) {
+        const int j = col0 + tid / KCT + pass * (kGBlock / KCT);
+        const int jc = j < n_out ? j : n_out - 1;
+        rb[pass] = w[(int64_t)jc * K + kkc];
+      }
+    }
+  };
+  auto sstore = [&]() {
+    const int kq = (tid % LPRW) * 4;
+    const int tail = pend_K - (pend_k0 + kq);  // columns of this float4 inside the matrix
+#pragma unroll
+    for (int pass = 0; pass < APASS; ++pass) {
+      const int r = tid / LPRW + pass * RPP;
+      const bool ok = r < rows_valid;
+      As[r][kq + 0] = (ok && tail > 0) ? ra[pass].x : 0.f;
+      As[r][kq + 1] = (ok && tail > 1) ? ra[pass].y : 0.f;
+      As[r][kq + 2] = (ok && tail > 2) ? ra[pass].z : 0.f;
+      As[r][kq + 3] = (ok && tail > 3) ? ra[pass].w : 0.f;
+    }
+    if constexpr (!TRANS) {
+      const int j = tid % BN2;
+      const bool jok = col0 + j < n_out;
+#pragma unroll
+      for (int pass = 0; pass < BPASS; ++pass) {
+        const int kk = tid / BN2 + pass * (kGBlock / BN2);
+        Bs[kk][j] = (jok && pend_k0 + kk < pend_K) ? rb[pass] : 0.f;
+      }
+    } else {
+      const int kk = tid % KCT;
+      const bool kok = pend_k0 + kk < pend_K;
+#pragma unroll
+      for (int pass = 0; pass < BPASS; ++pass) {
+        const int j = tid / KCT + pass * (kGBlock / KCT);
+        Bs[kk][j] = (kok && col0 + j < n_out) ? rb[pass] : 0.f;
+      }
+    }
+  };
+
+  if (nchunks > 0) {
+    gload(0);
+    sstore();
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+      if (c + 1 < nchunks && !(diag & 2)) gload(c + 1);  // in flight while the matrix pipe works on chunk c
+      if (!(diag & 1)) {
+        if constexpr (FRAG) {
+          // fragments of half a chunk first, then the MFMAs back to back: the LDS latency is
+          // paid once per 8 k-steps instead of once per k-step
+#pragma unroll
+          for (int h = 0; h < KCT / 16; ++h) {
+            float af[8], bf[NTW][8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int kk = h * 16 + q * 2;
+              af[q] = As[wrow * 32 + (lane & 31)][kk + half];
+#pragma unroll
+              for (int t = 0; t < NTW; ++t) bf[t][q] = Bs[kk + half][(wcol * NTW + t) * 32 + (lane & 31)];
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+              for (int t = 0; t < NTW; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[t][q], af[q], acc[t], 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < KCT; kk += 2) {
+            const float av = As[wrow * 32 + (lane & 31)][kk + half];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+              const float bv = Bs[kk + half][(wcol * NTW + t) * 32 + (lane & 31)];
+              // operands swapped on purpose: the accumulator holds out^T -- lane = atom row, 4
+              // consecutive registers = 4 consecutive output columns -> 16-byte stores per lane
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc[t], 0, 0, 0);
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (c + 1 < nchunks && !(diag & 2)) {
+        sstore();
+        __syncthreads();
+      }
+    }
+  }
+  const int64_t boff = pick_seg(st.bias_off, s);
+  const bool has_bias = bias != nullptr && boff >= 0;
+  const int r = wrow * 32 + (lane & 31);
+  float bv[NTW][4][4];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t)
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = col0 + (wcol * NTW + t) * 32 + 8 * rg + 4 * half + q;
+        bv[t][rg][q] = has_bias ? bias[boff + (c < n_out ? c : n_out - 1)] : 0.f;
+      }
+  if (r < rows_valid) {
+    float* orow = out + (int64_t)(row0 + r) * ldo;
+    const bool vec_out = (ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int c = col0 + (wcol * NTW + t) * 32 + 8 * rg + 4 * half;  // columns c .. c+3 = registers 4rg .. 4rg+3
+        float v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float x = acc[t][4 * rg + q] + bv[t][rg][q];
+          if (act == 1) x = x > 0.f ? x : 0.f;
+          v[q] = x;
+        }
+        if (vec_out && c + 3 < n_out) {
+          *reinterpret_cast<float4*>(orow + c) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (c + q < n_out) orow[c + q] = v[q];
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ wgrad
 struct SlabTable {
   int32_t n_seg;
@@ -243,8 +454,16 @@ wgrad_kernel(SlabTable st, const float* __restrict__ a, int64_t lda, int k, int 
     for (int u = 0; u < U; ++u) {
       bsum += bv[buf][u];
 #pragma unroll
-      for (int t = 0; t < KT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u][t], bv[buf][u], acc[t], 0, 0, 0);
+      for (int t = 0; t < KT; ++t) {
+        // TRANS (nn.Linear layout, dW stored n x k): swap the operands so that the accumulator
+        // holds dW^T -- its lane index is then the k-feature, i.e. the CONTIGUOUS index of the
+        // destination, and every atomic wave-instruction covers two 128-byte runs instead of 64
+        // different rows (which the memory-side atomic units serve an order of magnitude slower)
+        if constexpr (TRANS)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[buf][u], av[buf][u][t], acc[t], 0, 0, 0);
+        else
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u][t], bv[buf][u], acc[t], 0, 0, 0);
+      }
     }
   };
   if (r_begin < r_end) {
@@ -290,15 +509,18 @@ wgrad_kernel(SlabTable st, const float* __restrict__ a, int64_t lda, int k, int 
   }
   if (slab0 >= seg_end) return;
   const int64_t woff = pick_seg(st.dw_off, s);
-  if (n_ok && woff >= 0) {
+  if (woff >= 0) {
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
-        const int kf = (kt0 + t) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * half;
-        if (kf < k) {
-          const int64_t idx = TRANS ? (int64_t)ncol * k + kf : (int64_t)kf * n + ncol;
-          atomicAdd(dw + woff + idx, acc[t][reg]);
+        const int rix = (reg & 3) + 8 * (reg >> 2) + 4 * half;  // accumulator row of this register
+        if constexpr (TRANS) {
+          const int nc = nt * 32 + rix;  // rows of dW^T = output columns n
+          if (nc < n && k_ok[t]) atomicAdd(dw + woff + (int64_t)nc * k + kcol[t], acc[t][reg]);
+        } else {
+          const int kf = (kt0 + t) * 32 + rix;
+          if (kf < k && n_ok) atomicAdd(dw + woff + (int64_t)kf * n + ncol, acc[t][reg]);
         }
       }
     }
@@ -353,6 +575,16 @@ int gcmi_seg_gemm(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_en
   GCMI_CHECK_ARG(d_a1 || d_a2, "seg_gemm: no operand");
   GCMI_CHECK_ARG(d_bias == nullptr || bias_off != nullptr, "seg_gemm: bias without offsets");
   GCMI_CHECK_ARG(act == 0 || act == 1, "seg_gemm: act must be 0 or 1");
+  hipStream_t sm = (hipStream_t)stream;
+  const bool vec4 = (d_a1 == nullptr || (aligned16(d_a1) && lda1 % 4 == 0)) &&
+                    (d_a2 == nullptr || (aligned16(d_a2) && lda2 % 4 == 0));
+  static const bool use_v1 = getenv("GCMI_GEMM_V1") != nullptr;  // A/B switches for tools/kbench.py
+  static const int bm_env = getenv("GCMI_GEMM_BM") ? atoi(getenv("GCMI_GEMM_BM")) : 128;
+  static const int frag_env = getenv("GCMI_GEMM_FRAG") ? atoi(getenv("GCMI_GEMM_FRAG")) : 1;
+  static const int diag = getenv("GCMI_GEMM_DIAG") ? atoi(getenv("GCMI_GEMM_DIAG")) : 0;
+  const bool v2 = vec4 && !use_v1;
+  const int nt = n_out <= 32 ? 1 : (n_out <= 64 ? 2 : 4);
+  const int bm = v2 ? ((bm_env == 64 && nt >= 2) ? 64 : BM2) : BM;
   SegTable st;
   memset(&st, 0, sizeof(st));
   st.n_seg = n_seg;
@@ -366,27 +598,49 @@ int gcmi_seg_gemm(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_en
       st.w1_off[s] = (d_a1 && w1_off) ? w1_off[s] : -1;
       st.w2_off[s] = (d_a2 && w2_off) ? w2_off[s] : -1;
       st.bias_off[s] = (d_bias && bias_off) ? bias_off[s] : -1;
-      tiles += (seg_end[s] - seg_begin[s] + BM - 1) / BM;
+      tiles += (seg_end[s] - seg_begin[s] + bm - 1) / bm;
     } else {
       st.w1_off[s] = st.w2_off[s] = st.bias_off[s] = -1;
     }
   }
   st.tile_start[kMaxSeg] = (int32_t)tiles;
   if (tiles == 0) return GCMI_OK;
-  hipStream_t sm = (hipStream_t)stream;
-  const bool vec4 = (d_a1 == nullptr || (aligned16(d_a1) && lda1 % 4 == 0)) &&
-                    (d_a2 == nullptr || (aligned16(d_a2) && lda2 % 4 == 0));
-  dim3 grid((unsigned)tiles, (unsigned)((n_out + BNT - 1) / BNT));
   TimedScope ts(GCMI_K_SEG_GEMM, sm);
+  if (v2) {
+    dim3 grid((unsigned)tiles, (unsigned)((n_out + nt * 32 - 1) / (nt * 32)));
+    static const int kc_env = getenv("GCMI_GEMM_KC") ? atoi(getenv("GCMI_GEMM_KC")) : 32;
+#define LAUNCH_SG2(TT, NN, BB, FF)                                                                \
+  do {                                                                                            \
+    if (kc_env == 64)                                                                             \
+      hipLaunchKernelGGL((seg_gemm2_kernel<TT, NN, BB, FF, 64>), grid, dim3(kGBlock), 0, sm, st, d_a1, \
+                         lda1, k1, d_w1, d_a2, lda2, k2, d_w2, d_bias, n_out, act, d_out, ldo, diag); \
+    else                                                                                          \
+      hipLaunchKernelGGL((seg_gemm2_kernel<TT, NN, BB, FF, 32>), grid, dim3(kGBlock), 0, sm, st, d_a1, \
+                         lda1, k1, d_w1, d_a2, lda2, k2, d_w2, d_bias, n_out, act, d_out, ldo, diag); \
+  } while (0)
+#define LAUNCH_SG2_T(TT)                                                                     \
+  do {                                                                                       \
+    if (nt == 1) { if (frag_env) LAUNCH_SG2(TT, 1, 128, true); else LAUNCH_SG2(TT, 1, 128, false); }         \
+    else if (nt == 2 && bm == 128) { if (frag_env) LAUNCH_SG2(TT, 2, 128, true); else LAUNCH_SG2(TT, 2, 128, false); } \
+    else if (nt == 2) { if (frag_env) LAUNCH_SG2(TT, 2, 64, true); else LAUNCH_SG2(TT, 2, 64, false); }    \
+    else if (bm == 128) { if (frag_env) LAUNCH_SG2(TT, 4, 128, true); else LAUNCH_SG2(TT, 4, 128, false); } \
+    else { if (frag_env) LAUNCH_SG2(TT, 4, 64, true); else LAUNCH_SG2(TT, 4, 64, false); }               \
+  } while (0)
+    if (trans_w) LAUNCH_SG2_T(true); else LAUNCH_SG2_T(false);
+#undef LAUNCH_SG2_T
+#undef LAUNCH_SG2
+  } else {
+    dim3 grid((unsigned)tiles, (unsigned)((n_out + BNT - 1) / BNT));
 #define LAUNCH_SG(TT, VV)                                                                       \
   hipLaunchKernelGGL((seg_gemm_kernel<TT, VV>), grid, dim3(kGBlock), 0, sm, st, d_a1, lda1, k1,  \
                      d_w1, d_a2, lda2, k2, d_w2, d_bias, n_out, act, d_out, ldo)
-  if (trans_w) {
-    if (vec4) LAUNCH_SG(true, true); else LAUNCH_SG(true, false);
-  } else {
-    if (vec4) LAUNCH_SG(false, true); else LAUNCH_SG(false, false);
-  }
+    if (trans_w) {
+      if (vec4) LAUNCH_SG(true, true); else LAUNCH_SG(true, false);
+    } else {
+      if (vec4) LAUNCH_SG(false, true); else LAUNCH_SG(false, false);
+    }
 #undef LAUNCH_SG
+  }
   GCMI_CHECK_LAUNCH("seg_gemm");
   return GCMI_OK;
 }
@@ -485,3 +739,35 @@ int gcmi_relu_bwd(float* d_g, int64_t ldg, const float* d_y, int64_t ldy, int64_
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------ diagnostics
+// Peak rate of v_mfma_f32_32x32x2_f32 from registers (no memory traffic): the ceiling the
+// GEMM kernels are priced against on THIS device (tools/kbench.py --only mfma_peak).
+namespace gcmi {
+__global__ void __launch_bounds__(256) mfma_peak_kernel(int iters, float* out) {
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  float a = (float)(threadIdx.x & 7) * 0.25f, b = (float)(threadIdx.x & 3) * 0.5f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[t][i];
+  if (s == 12345.678f) out[0] = s;  // keep the chain alive
+}
+}  // namespace gcmi
+
+extern "C" int gcmi_diag_mfma_peak(int32_t blocks, int32_t iters, float* d_out, void* stream) {
+  hipLaunchKernelGGL(gcmi::mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, d_out);
+  GCMI_CHECK_LAUNCH("mfma_peak");
+  return GCMI_OK;
+}

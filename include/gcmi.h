@@ -307,6 +307,9 @@ enum {
   GCMI_K_COUNT = 8
 };
 int gcmi_timing_enable(int32_t kernel_id, int32_t on);
+/* Diagnostic: `blocks` workgroups of 4 waves each issue iters*32 register-only
+ * v_mfma_f32_32x32x2_f32 per wave (4096 flops each): the fp32 MFMA ceiling of the device.  */
+int gcmi_diag_mfma_peak(int32_t blocks, int32_t iters, float* d_out, void* stream);
 /* Synchronises the recorded events; returns launches and total milliseconds. */
 int gcmi_timing_read(int32_t kernel_id, int64_t* n_launches, double* total_ms, int32_t reset);
 

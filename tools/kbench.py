@@ -124,6 +124,16 @@ def main():
             else:
                 fn = lambda: ops.seg_gemm_wgrad([0], [rows], a, gg, dw, [0], db, [0], trans)
             rec("wgrad_" + label, timeit(fn, args.iters), rows * 4 * (k + n), 2.0 * rows * k * n)
+    if want("mfma_peak"):
+        import ctypes
+        from deepchem_amd import _lib
+        from deepchem_amd.graph import _stream
+        o = torch.zeros(4, device=dev)
+        for blocks in (256, 1024, 2048):
+            iters = 2000
+            fn = lambda: _lib.call("gcmi_diag_mfma_peak", blocks, iters, ctypes.c_void_p(o.data_ptr()), _stream())
+            us = timeit(fn, 5)
+            rec("mfma_peak_blocks%d" % blocks, us, None, blocks * 4 * iters * 32 * 4096.0)
     if want("adam"):
         p, gr, m, v = rnd(204504), rnd(204504), torch.zeros(204504, device=dev), torch.zeros(204504, device=dev)
         rec("adam_flat_204k", timeit(lambda: ops.adam_step_(p, gr, m, v, 1e-3, 0.9, 0.999, 1e-8, 3), args.iters), 204504 * 28)
