@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--grad-mode", default="full", choices=["full", "reference"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fit-pipeline", type=int, default=1,
+                    help="also time end-to-end fit() (collation + H2D + step) on a PackedDataset")
     ap.add_argument("--small-batch", type=int, default=100,
                     help="also report mol/s at the reference's default batch size (0 = skip)")
     return ap.parse_args()
@@ -255,6 +257,27 @@ def main():
         torch.cuda.synchronize()
         out["config"]["molecules_per_s_at_batch_%d" % args.small_batch] = round(
             args.small_batch * n_small / (time.perf_counter() - t1), 1)
+
+    if rank == 0 and world == 1 and args.fit_pipeline:
+        # end-to-end fit(): native collation + H2D (prefetched on a worker thread) + training step
+        import deepchem_amd as dc
+        from deepchem_amd.utils.synthetic import synthetic_labels, synthetic_molecules
+        n_fit = 32768
+        packed = synthetic_molecules(n_fit, seed=5)
+        y, w = synthetic_labels(n_fit, args.tasks, "classification", seed=5)
+        ds = dc.data.PackedDataset(packed, y, w)
+        for bsz in (100, 4096):
+            m3 = dc.models.torch_models.GraphConvModel(args.tasks, number_input_features=[75, 64],
+                                                       batch_size=bsz, grad_mode=args.grad_mode,
+                                                       device=device, log_frequency=10**9)
+            n_part = 4096 if bsz == 100 else n_fit
+            part = dc.data.PackedDataset(packed.select(np.arange(n_part)), y[:n_part], w[:n_part])
+            m3.fit(part, nb_epoch=1, checkpoint_interval=0)  # warm-up
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            m3.fit(part, nb_epoch=2, checkpoint_interval=0)
+            torch.cuda.synchronize()
+            out["config"]["fit_molecules_per_s_batch_%d" % bsz] = round(2 * n_part / (time.perf_counter() - t1), 1)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)

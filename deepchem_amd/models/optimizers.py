@@ -60,36 +60,46 @@ class GcmiAdam(torch.optim.Optimizer):
                 v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
         self._flat = dict(p=param_flat, g=grad_flat, m=m, v=v, slices=list(slices), params=params)
 
-    def _flat_state(self, p, off, n, step_value):
-        st = self.state[p]
-        if len(st) == 0 or st["exp_avg"].data_ptr() != self._flat["m"].data_ptr() + 4 * off:
-            old_step = float(st["step"]) if "step" in st else step_value
-            st["step"] = torch.tensor(old_step, dtype=torch.float32)
-            st["exp_avg"] = self._flat["m"][off:off + n].view(p.shape)
-            st["exp_avg_sq"] = self._flat["v"][off:off + n].view(p.shape)
-        return st
+    def _setup_flat_range(self, lo: int, hi: int):
+        """State entries (views of the flat moments) for every parameter inside [lo, hi); all of
+        them share ONE step tensor, so a step costs one increment instead of a loop."""
+        f = self._flat
+        step_t = None
+        inside = []
+        for p, (off, n) in zip(f["params"], f["slices"]):
+            if lo <= off and off + n <= hi:
+                st = self.state[p]
+                if "step" in st:
+                    s = float(st["step"])
+                    if step_t is None:
+                        step_t = torch.tensor(s, dtype=torch.float32)
+                    elif float(step_t) != s:
+                        raise RuntimeError("parameters of one flat range have different Adam step counts")
+                inside.append((p, off, n))
+        if step_t is None:
+            step_t = torch.tensor(0.0, dtype=torch.float32)
+        for p, off, n in inside:
+            st = self.state[p]
+            st["step"] = step_t
+            st["exp_avg"] = f["m"][off:off + n].view(p.shape)
+            st["exp_avg_sq"] = f["v"][off:off + n].view(p.shape)
+        f["range"] = (lo, hi)
+        f["step_t"] = step_t
+        f["n_inside"] = len(inside)
 
     @torch.no_grad()
     def step_flat(self, lo: int, hi: int):
-        """Adam on the flat range [lo, hi) (floats): one kernel launch.  Every parameter inside the
-        range must have taken part in every flat step so far (same step count)."""
+        """Adam on the flat range [lo, hi) (floats): one kernel launch."""
         f = self._flat
+        if f.get("range") != (lo, hi):
+            self._setup_flat_range(lo, hi)
+        if f["n_inside"] == 0:
+            return
         group = self.param_groups[0]
         beta1, beta2 = group["betas"]
-        step = None
-        for p, (off, n) in zip(f["params"], f["slices"]):
-            if lo <= off and off + n <= hi:
-                st = self._flat_state(p, off, n, 0.0)
-                st["step"] += 1
-                s = int(st["step"].item())
-                if step is None:
-                    step = s
-                elif s != step:
-                    raise RuntimeError("parameters of one flat range have different Adam step counts")
-        if step is None:
-            return
+        f["step_t"] += 1
         ops.adam_step_(f["p"][lo:hi], f["g"][lo:hi], f["m"][lo:hi], f["v"][lo:hi], group["lr"], beta1,
-                       beta2, group["eps"], step)
+                       beta2, group["eps"], int(f["step_t"].item()))
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
@@ -103,6 +113,7 @@ class GcmiAdam(torch.optim.Optimizer):
                     st["exp_avg"] = f["m"][off:off + n].view(p.shape)
                     st["exp_avg_sq"] = f["v"][off:off + n].view(p.shape)
                     st["step"] = torch.as_tensor(st["step"], dtype=torch.float32).cpu()
+            f.pop("range", None)  # re-derive the shared step tensor on the next flat step
 
     @torch.no_grad()
     def step(self, closure=None):

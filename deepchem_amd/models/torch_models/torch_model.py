@@ -54,6 +54,8 @@ class TorchModel(Model):
         self.regularization_loss = regularization_loss
         if device is None:
             device = torch.device('cuda') if torch.cuda.is_available() else torch.device('cpu')
+        if device.type == 'cuda' and device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
         self.device = device
         self.model = model.to(device)
         self.log_frequency = log_frequency
@@ -101,7 +103,7 @@ class TorchModel(Model):
             variables=None, loss=None, callbacks: Union[Callable, List[Callable]] = [],
             all_losses: Optional[List[float]] = None) -> float:
         return self.fit_generator(
-            self.default_generator(dataset, epochs=nb_epoch, deterministic=deterministic),
+            self._batch_generator(dataset, epochs=nb_epoch, deterministic=deterministic),
             max_checkpoints_to_keep, checkpoint_interval, restore, variables, loss, callbacks,
             all_losses)
 
@@ -282,12 +284,12 @@ class TorchModel(Model):
         return self.predict_uncertainty(dataset, masks)
 
     def predict(self, dataset, transformers: List = [], output_types: Optional[List[str]] = None):
-        generator = self.default_generator(dataset, mode='predict', pad_batches=False)
+        generator = self._batch_generator(dataset, mode='predict', pad_batches=False)
         return self.predict_on_generator(generator, transformers=transformers,
                                          output_types=output_types)
 
     def predict_embedding(self, dataset):
-        generator = self.default_generator(dataset, mode='predict', pad_batches=False)
+        generator = self._batch_generator(dataset, mode='predict', pad_batches=False)
         return self._predict(generator, [], False, ['embedding'])
 
     def predict_uncertainty(self, dataset, masks: int = 50):
@@ -295,7 +297,7 @@ class TorchModel(Model):
         sum_sq_pred: List[np.ndarray] = []
         sum_var: List[np.ndarray] = []
         for i in range(masks):
-            generator = self.default_generator(dataset, mode='uncertainty', pad_batches=False)
+            generator = self._batch_generator(dataset, mode='uncertainty', pad_batches=False)
             results = self._predict(generator, [], True, None)
             if len(sum_pred) == 0:
                 for p, v in results:
@@ -337,6 +339,13 @@ class TorchModel(Model):
         label_tensors = [self._to_device(x) for x in labels] if labels is not None else []
         weight_tensors = [self._to_device(x) for x in weights] if weights is not None else []
         return (input_tensors, label_tensors, weight_tensors)
+
+    def _batch_generator(self, dataset, epochs: int = 1, mode: str = 'fit', deterministic: bool = True,
+                         pad_batches: bool = True):
+        """The generator fit()/predict*() use; subclasses may substitute a faster equivalent of
+        ``default_generator``."""
+        return self.default_generator(dataset, epochs=epochs, mode=mode, deterministic=deterministic,
+                                      pad_batches=pad_batches)
 
     def default_generator(self, dataset, epochs: int = 1, mode: str = 'fit',
                           deterministic: bool = True, pad_batches: bool = True):

@@ -355,3 +355,59 @@ def test_native_survives_parameter_replacement_and_checkpoint_restore(tmp_path):
     la = model.fit(ds, nb_epoch=1, deterministic=True, checkpoint_interval=0)
     lb = model2.fit(ds, nb_epoch=1, deterministic=True, checkpoint_interval=0)
     assert abs(la - lb) < 1e-5 * max(1.0, abs(la))
+
+
+def test_packed_dataset_pipeline_equals_python_collation():
+    """fit/predict through the native collation + prefetch pipeline (PackedDataset, or a
+    NumpyDataset of ConvMol converted once) against the reference-style per-batch Python
+    collation of the same model."""
+    from deepchem_amd.data import NumpyDataset, PackedDataset
+    from deepchem_amd.models.torch_models import GraphConvModel
+    g = load_golden("model_cls_bn.npz")
+    packed = packed_from(g)
+    y, w = g["in_y"], g["in_w"]
+    outs = []
+    for kind in ("python", "convmol_fast", "packed"):
+        model, cfg, state = build_model(g, "full")
+        if kind == "python":
+            model.native_batches = False
+        ds = PackedDataset(packed, y, w) if kind == "packed" else NumpyDataset(product_convmols(packed), y, w)
+        losses = []
+        model.fit(ds, nb_epoch=2, deterministic=True, checkpoint_interval=0,
+                  callbacks=[lambda m, s, iteration_loss=None: losses.append(float(iteration_loss))])
+        outs.append((losses, model.predict(ds), model.predict_embedding(ds)))
+    for losses, pred, emb in outs[1:]:
+        assert np.allclose(losses, outs[0][0], rtol=1e-5, atol=1e-7)
+        assert np.allclose(pred, outs[0][1], atol=1e-6) and pred.shape == outs[0][1].shape
+        assert np.allclose(emb, outs[0][2], atol=1e-6) and emb.shape == outs[0][2].shape
+    # shuffled epochs draw the same permutations as NumpyDataset.iterbatches
+    np.random.seed(3)
+    a = [i.tolist() for i, _ in PackedDataset(packed, y, w).iter_index_batches(10, 2, False, True)]
+    np.random.seed(3)
+    nd = NumpyDataset(np.arange(packed.n_mols), y, w)
+    b = [x.tolist() for x, _, _, _ in nd.iterbatches(10, 2, False, True)]
+    assert a == b
+
+
+def test_pcba_like_head_128_tasks():
+    """128 tasks x 2 classes (PCBA shape): head GEMM 256 -> 256, wgrad with 8 x 8 tiles."""
+    from deepchem_amd.data import PackedDataset
+    from deepchem_amd.models.torch_models import GraphConvModel
+    from deepchem_amd.utils.synthetic import synthetic_labels, synthetic_molecules
+    from tests.util import oracle_predict
+    n, T, B = 64, 128, 32
+    packed = synthetic_molecules(n, seed=31, max_atoms=50)
+    y, w = synthetic_labels(n, T, "classification", 31, pos_rate=0.2)
+    cfg = O.ModelConfig(T, batch_size=B)
+    state = O.init_state(cfg, 31)
+    tr, ref_losses = oracle_fit(cfg, state, oracle_convmols(packed), y, w, 2, "full")
+    model = GraphConvModel(T, number_input_features=[75, 64], batch_size=B, grad_mode="full",
+                           device=torch.device(DEV))
+    model.model.load_state_dict({k: v.clone() for k, v in state.items()})
+    losses = []
+    model.fit(PackedDataset(packed, y, w), nb_epoch=2, deterministic=True, checkpoint_interval=0,
+              callbacks=[lambda m, s, iteration_loss=None: losses.append(float(iteration_loss))])
+    assert np.allclose(losses, ref_losses, rtol=2e-3, atol=1e-5), (losses, ref_losses)
+    pred = model.predict(PackedDataset(packed, y, w))
+    ref = oracle_predict(tr, cfg, oracle_convmols(packed), 0)
+    assert pred.shape == (n, T, 2) and np.abs(pred - ref).max() < 5e-3
