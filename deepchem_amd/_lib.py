@@ -19,6 +19,10 @@ def bn_acc_doubles(n_feat: int) -> int:
 K_GATHER_SUM, K_GATHER_MAX, K_READOUT, K_SEG_GEMM, K_WGRAD, K_GATHER_MAX_BWD = 0, 1, 2, 3, 4, 5
 
 
+GCMI_WIN_META_INTS = 24
+GCMI_WIN_MAX_SLOTS = 4095
+
+
 class GcmiGraph(Structure):
     """struct gcmi_graph (include/gcmi.h)."""
     _fields_ = [
@@ -32,6 +36,15 @@ class GcmiGraph(Structure):
         ("d_membership", c_void_p),
         ("d_mol_runs", c_void_p),
         ("d_rev_pos", c_void_p),
+        ("n_win", c_int32),
+        ("n_win_big", c_int32),
+        ("win_alloc", c_int32),
+        ("win_ecap", c_int32),
+        ("win_alloc_big", c_int32),
+        ("win_ecap_big", c_int32),
+        ("win_reserved", c_int32 * 2),
+        ("d_win_meta", c_void_p),
+        ("d_win_edges", c_void_p),
     ]
 
 
@@ -93,6 +106,8 @@ _SIGNATURES = {
     "gcmi_collate_sizes": [_P, _P, _P, c_int64, _I64P, _I64P],
     "gcmi_collate": [_P, c_int64, _P, _P, _P, _P, c_int64, c_int32, _P, c_int64, c_int64, _P, _P,
                      c_int64, _P, _G],
+    "gcmi_collate_plans": [_P, c_int64, _P, _P, _P, _P, c_int64, c_int32, _P, c_int64, c_int64, _P, _P,
+                           c_int64, _P, _P, _I32P, c_int32, _P, _P, _G],
     "gcmi_build_mol_runs": [_G, _P, _P, _P],
     "gcmi_build_rev_pos": [_G, _P, _P, _P],
     "gcmi_gather_sum_fwd": [_G, _P, c_int64, c_int32, _P, c_int64, c_int32, _P],

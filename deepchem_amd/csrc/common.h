@@ -1,6 +1,8 @@
 // Shared host/device helpers for libgcmi.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <stdlib.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -58,6 +60,16 @@ inline DegTable make_deg_table(const gcmi_graph* g) {
 }
 
 int check_graph(const gcmi_graph* g, bool need_cols);
+
+// LDS-window forms of the gather kernels (gather_lds.hip)
+bool win_usable(const gcmi_graph* g, int n_feat, bool aux);
+bool win_has_width(int n_feat);
+int win_gather_sum(const gcmi_graph* g, const float* d_x, int64_t ldx, int n_feat, float* d_s,
+                   int64_t lds, hipStream_t st);
+int win_gather_max(const gcmi_graph* g, const float* d_x, int64_t ldx, int n_feat, const float* d_scale,
+                   const float* d_shift, float* d_out, int64_t ldo, uint8_t* d_arg, hipStream_t st);
+int win_gather_max_bwd(const gcmi_graph* g, const float* d_dout, int64_t lddo, int n_feat,
+                       const uint8_t* d_arg, float* d_dx, int64_t lddx, hipStream_t st);
 
 // degree of batch row i: the number of block starts (d >= 1) that are <= i.
 __device__ __forceinline__ int degree_of_row(const DegTable& t, int i) {

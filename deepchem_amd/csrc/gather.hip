@@ -364,6 +364,10 @@ int gcmi_gather_sum_fwd(const gcmi_graph* g, const float* d_x, int64_t ldx, int3
   if (g->n_atoms == 0) return GCMI_OK;
   hipStream_t st = (hipStream_t)stream;
   const int V = (vec_width(d_x, ldx, n_feat) == 4 && vec_width(d_s, lds, n_feat) == 4) ? 4 : 1;
+  if (V == 4 && !accumulate && win_has_width(n_feat) && win_usable(g, n_feat, false)) {
+    TimedScope ts(GCMI_K_GATHER_SUM, st);
+    return win_gather_sum(g, d_x, ldx, n_feat, d_s, lds, st);
+  }
   const int lpr = n_feat / V;
   TileTable tt;
   // accumulate: degree-0 rows receive nothing, so their tiles are skipped
@@ -421,6 +425,11 @@ int gcmi_gather_max_fwd(const gcmi_graph* g, const float* d_x, int64_t ldx, int3
                  (d_arg == nullptr || (reinterpret_cast<uintptr_t>(d_arg) & 3u) == 0))
                     ? 4
                     : 1;
+  if (V == 4 && win_has_width(n_feat) && win_usable(g, n_feat, false) &&
+      (d_scale == nullptr || (aligned16(d_scale) && aligned16(d_shift)))) {
+    TimedScope ts(GCMI_K_GATHER_MAX, st);
+    return win_gather_max(g, d_x, ldx, n_feat, d_scale, d_shift, d_out, ldo, d_arg, st);
+  }
   const int lpr = n_feat / V;
   TileTable tt;
   const int tiles = make_tiles(g, lpr, false, &tt);
@@ -474,6 +483,11 @@ int gcmi_gather_max_bwd(const gcmi_graph* g, const float* d_dout, int64_t lddo, 
   TileTable tt;
   const int tiles = make_tiles(g, lpr, false, &tt);
   DegTable t = make_deg_table(g);
+  if (V == 4 && (g->d_rev_pos != nullptr || g->n_edges == 0) && win_has_width(n_feat) &&
+      win_usable(g, n_feat, true)) {
+    TimedScope ts(GCMI_K_GATHER_MAX_BWD, st);
+    return win_gather_max_bwd(g, d_dout, lddo, n_feat, d_arg, d_dx, lddx, st);
+  }
   if (g->d_rev_pos != nullptr || g->n_edges == 0) {
     TimedScope ts(GCMI_K_GATHER_MAX_BWD, st);
     if (V == 4)

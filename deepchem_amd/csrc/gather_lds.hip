@@ -1,0 +1,446 @@
+// LDS-window forms of the three gather kernels: GraphConv.sum_neigh
+// (models/torch_models/layers.py:6236-6246), GraphPool.forward (:6319-6367) and its backward.
+//
+// Every neighbour of an atom belongs to the atom's own molecule.  The collation
+// (gcmi_collate_plans) groups consecutive molecules into windows of ~win_cap atoms; because each
+// degree block of the batch is sorted by molecule, the atoms of a window are <= 11 CONTIGUOUS row
+// ranges (one per degree block).  A persistent workgroup walks windows:
+//
+//   * the rows of window i+1 stream HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, the
+//     per-lane SOURCE address does the row-range lookup, the LDS image is slot-major and
+//     lane-linear) while window i is being computed from the other LDS buffer;
+//   * the neighbour lists of the window (uint16 LDS slots, window-major in HBM) arrive the same
+//     way, so the compute phase touches HBM only to store results;
+//   * the window descriptors (24 ints) are fetched three windows ahead into an LDS ring.
+//
+// HBM traffic drops from E*(4F+4) + N*4F (every neighbour row fetched once per edge) to
+// N*4F + 2E + N*4F: each row is read ONCE; the (1+E/N)-fold re-reads are served by LDS.  The
+// algorithmic figure of SURVEY.md 8d is therefore delivered above the HBM roofline.
+#include "common.h"
+
+namespace gcmi {
+
+constexpr int kND = GCMI_MAX_DEG + 1;
+constexpr int kLdsPerCU = 160 * 1024;
+constexpr int kRingBytes = 320;                 // 3 descriptors of GCMI_WIN_META_INTS ints, 16-byte padded
+constexpr int kHeadBytes = kRingBytes + 2048;   // + 512 floats of per-op constants
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+// LDS-DMA: 64 lanes x 16 (4) bytes from per-lane global addresses to LDS [dst, dst + 1024 (256)).
+// Written as asm on purpose: for the builtin hipcc (ROCm 7.2) waits vmcnt(0) before EVERY later
+// ds_read of the same LDS array (it cannot tell the buffer being filled from the one being read),
+// which would serialise the fill of window i+1 with the compute of window i.  The kernel waits
+// for these loads itself (wait_dma) before the barrier that publishes a buffer.
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_ptr_t)p);
+}
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);  // wave-uniform by construction
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// The row ranges of one window, read from the LDS ring of window descriptors.
+struct WinMeta {
+  int rb[kND];      // global row of slot s (degree d) = rb[d] + s
+  int sb[kND + 1];  // first slot of degree d; sb[kND] = atoms in the window
+  int eoff;         // first entry of the window in win_edges (multiple of 8)
+  int ne;           // edge entries of the window
+};
+
+__device__ __forceinline__ WinMeta read_meta(const int* ring_slot) {
+  WinMeta m;
+#pragma unroll
+  for (int d = 0; d < kND; ++d) m.rb[d] = ring_slot[d];
+  m.sb[0] = 0;
+#pragma unroll
+  for (int d = 1; d <= kND; ++d) m.sb[d] = ring_slot[kND - 1 + d];
+  m.eoff = ring_slot[2 * kND];
+  m.ne = ring_slot[2 * kND + 1];
+  return m;
+}
+
+// slot -> (degree, global row, first entry of its neighbour list inside the window);
+// maxd = highest degree present in the batch (uniform)
+__device__ __forceinline__ void locate(const WinMeta& m, int maxd, int slot, int& d, int& row, int& eloc) {
+  d = 0;
+  int rb = m.rb[0], eb = 0, eacc = 0;
+#pragma unroll
+  for (int k = 1; k < kND; ++k) {
+    if (k <= maxd) {
+      eacc += (m.sb[k] - m.sb[k - 1]) * (k - 1);  // entries of the degrees below k
+      const bool ge = slot >= m.sb[k];
+      d = ge ? k : d;
+      rb = ge ? m.rb[k] : rb;
+      eb = ge ? eacc - m.sb[k] * k : eb;
+    }
+  }
+  row = rb + slot;
+  eloc = eb + slot * d;
+}
+
+__device__ __forceinline__ int row_of_slot(const WinMeta& m, int maxd, int slot) {
+  int rb = m.rb[0];
+#pragma unroll
+  for (int k = 1; k < kND; ++k)
+    if (k <= maxd) rb = slot >= m.sb[k] ? m.rb[k] : rb;
+  return rb + slot;
+}
+
+// LDS image of one buffer: [tile: alloc*LPR float4][aux: alloc*LPR*4 bytes (optional)][edges]
+struct Layout {
+  int tile_bytes, aux_bytes, edge_bytes, maxd;
+  __host__ __device__ int buf_bytes() const { return tile_bytes + aux_bytes + edge_bytes; }
+};
+
+// Issue the LDS-DMA of one window: rows of `x` (and of the byte matrix `aux`, F bytes per row)
+// and the window's neighbour entries.  Nothing waits here.
+template <int WT, int LPR, bool AUX>
+__device__ __forceinline__ void stage(char* buf, const Layout& L, const WinMeta& m,
+                                      const float* __restrict__ x, int64_t ldx,
+                                      const uint8_t* __restrict__ aux,
+                                      const uint16_t* __restrict__ edges) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int n16 = m.sb[kND] * LPR;
+  const unsigned base = lds_addr(buf);
+  for (int e0 = tid - lane; e0 < n16; e0 += WT) {  // e0: wave-uniform first chunk of this piece
+    const int e = e0 + lane;
+    if (e < n16) {
+      const int slot = e / LPR;
+      const int c = e - slot * LPR;
+      const int row = row_of_slot(m, L.maxd, slot);
+      glds16(x + (int64_t)row * ldx + c * 4, base + e0 * 16);
+      if (AUX) glds4(aux + (int64_t)row * (LPR * 4) + c * 4, base + L.tile_bytes + e0 * 4);
+    }
+  }
+  const int nq = (m.ne + 7) >> 3;  // 16-byte pieces of the neighbour entries
+  const uint16_t* src = edges + m.eoff;
+  for (int q0 = tid - lane; q0 < nq; q0 += WT) {
+    const int q = q0 + lane;
+    if (q < nq) glds16(src + (size_t)q * 8, base + L.tile_bytes + L.aux_bytes + q0 * 16);
+  }
+}
+
+// ---------------------------------------------------------------- per-window compute phases
+struct SumOp {
+  float* __restrict__ s;
+  int64_t lds;
+  template <int WT>
+  __device__ __forceinline__ void init(float*, int) const {}
+  template <int WT, int LPR>
+  __device__ __forceinline__ void run(const char* buf, const Layout& L, const WinMeta& m, const float*) const {
+    const float4* tile = reinterpret_cast<const float4*>(buf);
+    const uint16_t* ent = reinterpret_cast<const uint16_t*>(buf + L.tile_bytes + L.aux_bytes);
+    const int n16 = m.sb[kND] * LPR;
+    for (int e = threadIdx.x; e < n16; e += WT) {
+      const int slot = e / LPR;
+      const int c = e - slot * LPR;
+      int d, row, eloc;
+      locate(m, L.maxd, slot, d, row, eloc);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);  // lone atoms: zero
+      for (int j = 0; j < d; ++j) {
+        const int sl = ent[eloc + j] & GCMI_WIN_MAX_SLOTS;
+        const float4 v = tile[sl * LPR + c];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      *reinterpret_cast<float4*>(s + (int64_t)row * lds + c * 4) = acc;
+    }
+  }
+};
+
+template <bool BN>
+struct MaxOp {
+  const float* __restrict__ scale;
+  const float* __restrict__ shift;
+  float* __restrict__ out;
+  int64_t ldo;
+  uint8_t* __restrict__ arg;
+  // the folded BatchNorm vectors live in LDS: a global load in the compute phase would make the
+  // compiler wait for the LDS-DMA in flight as well
+  template <int WT>
+  __device__ __forceinline__ void init(float* sh_lds, int n_feat) const {
+    if (BN)
+      for (int i = threadIdx.x; i < n_feat; i += WT) {
+        sh_lds[i] = scale[i];
+        sh_lds[256 + i] = shift[i];
+      }
+  }
+  template <int WT, int LPR>
+  __device__ __forceinline__ void run(const char* buf, const Layout& L, const WinMeta& m,
+                                      const float* sh_lds) const {
+    const float4* tile = reinterpret_cast<const float4*>(buf);
+    const uint16_t* ent = reinterpret_cast<const uint16_t*>(buf + L.tile_bytes + L.aux_bytes);
+    const int n16 = m.sb[kND] * LPR;
+    for (int e = threadIdx.x; e < n16; e += WT) {
+      const int slot = e / LPR;
+      const int c = e - slot * LPR;
+      int d, row, eloc;
+      locate(m, L.maxd, slot, d, row, eloc);
+      float4 sc, sh;
+      if (BN) {
+        sc = *reinterpret_cast<const float4*>(sh_lds + c * 4);
+        sh = *reinterpret_cast<const float4*>(sh_lds + 256 + c * 4);
+      }
+      float4 best = tile[e];  // self first
+      if (BN) {
+        best.x = fmaf(best.x, sc.x, sh.x); best.y = fmaf(best.y, sc.y, sh.y);
+        best.z = fmaf(best.z, sc.z, sh.z); best.w = fmaf(best.w, sc.w, sh.w);
+      }
+      uchar4 ba = make_uchar4(0, 0, 0, 0);
+      for (int j = 0; j < d; ++j) {
+        const int sl = ent[eloc + j] & GCMI_WIN_MAX_SLOTS;
+        float4 v = tile[sl * LPR + c];
+        if (BN) {
+          v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y);
+          v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+        }
+        const unsigned char a = (unsigned char)(j + 1);
+        if (v.x > best.x) { best.x = v.x; ba.x = a; }  // strict >: the first maximum wins
+        if (v.y > best.y) { best.y = v.y; ba.y = a; }
+        if (v.z > best.z) { best.z = v.z; ba.z = a; }
+        if (v.w > best.w) { best.w = v.w; ba.w = a; }
+      }
+      *reinterpret_cast<float4*>(out + (int64_t)row * ldo + c * 4) = best;
+      if (arg) *reinterpret_cast<uchar4*>(arg + (int64_t)row * (LPR * 4) + c * 4) = ba;
+    }
+  }
+};
+
+// dx[k] = dout[k]*[arg[k]==0] + sum_j dout[i_j]*[arg[i_j] == rev_pos(k,j)+1]: tile = dout rows,
+// aux = arg rows of the window.
+struct MaxBwdOp {
+  float* __restrict__ dx;
+  int64_t lddx;
+  template <int WT>
+  __device__ __forceinline__ void init(float*, int) const {}
+  template <int WT, int LPR>
+  __device__ __forceinline__ void run(const char* buf, const Layout& L, const WinMeta& m, const float*) const {
+    const float4* tile = reinterpret_cast<const float4*>(buf);
+    const uchar4* atile = reinterpret_cast<const uchar4*>(buf + L.tile_bytes);
+    const uint16_t* ent = reinterpret_cast<const uint16_t*>(buf + L.tile_bytes + L.aux_bytes);
+    const int n16 = m.sb[kND] * LPR;
+    for (int e = threadIdx.x; e < n16; e += WT) {
+      const int slot = e / LPR;
+      const int c = e - slot * LPR;
+      int d, row, eloc;
+      locate(m, L.maxd, slot, d, row, eloc);
+      float4 g = tile[e];
+      uchar4 a = atile[e];
+      float4 acc;
+      acc.x = a.x == 0 ? g.x : 0.f;
+      acc.y = a.y == 0 ? g.y : 0.f;
+      acc.z = a.z == 0 ? g.z : 0.f;
+      acc.w = a.w == 0 ? g.w : 0.f;
+      for (int j = 0; j < d; ++j) {
+        const int en = ent[eloc + j];
+        const int sl = en & GCMI_WIN_MAX_SLOTS;
+        const unsigned char want = (unsigned char)((en >> GCMI_WIN_SLOT_BITS) + 1);
+        g = tile[sl * LPR + c];
+        a = atile[sl * LPR + c];
+        acc.x += a.x == want ? g.x : 0.f;
+        acc.y += a.y == want ? g.y : 0.f;
+        acc.z += a.z == want ? g.z : 0.f;
+        acc.w += a.w == want ? g.w : 0.f;
+      }
+      *reinterpret_cast<float4*>(dx + (int64_t)row * lddx + c * 4) = acc;
+    }
+  }
+};
+
+// ---------------------------------------------------------------- the persistent window walker
+// Workgroups [0, g_norm) walk the ordinary windows double-buffered; workgroups [g_norm, gridDim)
+// walk the oversized windows (one big molecule each) using both buffers as one.
+template <int WT, int LPR, bool AUX, class Op>
+__global__ void __launch_bounds__(WT)
+win_kernel(const int32_t* __restrict__ meta, const uint16_t* __restrict__ edges, int n_norm, int n_win,
+           int g_norm, Layout L, Layout Lbig, const float* __restrict__ x, int64_t ldx,
+           const uint8_t* __restrict__ aux, Op op) {
+  // ALL LDS is one array (a second __shared__ object beside an LDS-DMA target makes hipcc wait
+  // vmcnt(0) before every ds_read): [window descriptors: it, it+1, it+2][op constants][2 buffers]
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
+  int(*ring)[GCMI_WIN_META_INTS] = reinterpret_cast<int(*)[GCMI_WIN_META_INTS]>(smem_all);
+  float* op_lds = reinterpret_cast<float*>(smem_all + kRingBytes);
+  char* smem = smem_all + kHeadBytes;
+  op.template init<WT>(op_lds, LPR * 4);
+  const int t = threadIdx.x;
+  if ((int)blockIdx.x >= g_norm) {  // oversized windows: stage, wait, compute
+    const int G = gridDim.x - g_norm;
+    for (int w = n_norm + (int)blockIdx.x - g_norm; w < n_win; w += G) {
+      if (t < GCMI_WIN_META_INTS) ring[0][t] = meta[(size_t)w * GCMI_WIN_META_INTS + t];
+      __syncthreads();
+      const WinMeta m = read_meta(ring[0]);
+      stage<WT, LPR, AUX>(smem, Lbig, m, x, ldx, aux, edges);
+      wait_dma();
+      __syncthreads();
+      op.template run<WT, LPR>(smem, Lbig, m, op_lds);
+      __syncthreads();
+    }
+    return;
+  }
+  const int G = g_norm;
+  int w = blockIdx.x;  // < n_norm by construction of the grid
+  const int bb = L.buf_bytes();
+  int metareg = 0;
+  if (t < GCMI_WIN_META_INTS) {
+    ring[0][t] = meta[(size_t)w * GCMI_WIN_META_INTS + t];
+    if (w + G < n_norm) ring[1][t] = meta[(size_t)(w + G) * GCMI_WIN_META_INTS + t];
+    if (w + 2 * G < n_norm) metareg = meta[(size_t)(w + 2 * G) * GCMI_WIN_META_INTS + t];
+  }
+  __syncthreads();
+  stage<WT, LPR, AUX>(smem, L, read_meta(ring[0]), x, ldx, aux, edges);
+  int it = 0;
+  for (;;) {
+    wait_dma();
+    __syncthreads();  // buffer it&1 has landed, the other one is free
+    const bool has_next = w + G < n_norm;
+    if (t < GCMI_WIN_META_INTS) {
+      ring[(it + 2) % 3][t] = metareg;  // read from the next round on
+      if (w + 3 * G < n_norm) metareg = meta[(size_t)(w + 3 * G) * GCMI_WIN_META_INTS + t];
+    }
+    if (has_next)
+      stage<WT, LPR, AUX>(smem + ((it + 1) & 1) * bb, L, read_meta(ring[(it + 1) % 3]), x, ldx, aux, edges);
+    op.template run<WT, LPR>(smem + (it & 1) * bb, L, read_meta(ring[it % 3]), op_lds);
+    if (!has_next) break;
+    w += G;
+    ++it;
+  }
+}
+
+// ------------------------------------------------------------------ host-side dispatch helpers
+static bool windows_disabled() {
+  static int v = -1;
+  if (v < 0) v = getenv("GCMI_NO_WINDOWS") != nullptr ? 1 : 0;
+  return v == 1;
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+static Layout make_layout(int alloc, int ecap, int maxd, int n_feat, bool aux) {
+  Layout L;
+  L.tile_bytes = alloc * n_feat * 4;
+  L.aux_bytes = aux ? (alloc * n_feat + 15) / 16 * 16 : 0;
+  L.edge_bytes = (ecap > 8 ? ecap : 8) * 2;
+  L.maxd = maxd;
+  return L;
+}
+
+struct WinPlan {
+  Layout L, Lbig;
+  size_t shmem;
+  bool ok;
+};
+
+// LDS shapes: the two buffers of the ordinary windows must also hold one oversized window.
+static WinPlan make_plan(const gcmi_graph* g, int n_feat, bool aux) {
+  int maxd = 0;
+  for (int d = 1; d <= g->max_deg; ++d)
+    if (g->deg_start[d + 1] > g->deg_start[d]) maxd = d;
+  WinPlan p;
+  p.Lbig = make_layout(g->win_alloc_big, g->win_ecap_big, maxd, n_feat, aux);
+  int alloc = std::max(g->win_alloc, 1);
+  p.L = make_layout(alloc, g->win_ecap, maxd, n_feat, aux);
+  if (g->n_win_big > 0) {
+    while (2 * p.L.buf_bytes() < p.Lbig.buf_bytes()) {
+      alloc += 8;
+      p.L = make_layout(alloc, g->win_ecap, maxd, n_feat, aux);
+    }
+  }
+  p.shmem = 2 * (size_t)p.L.buf_bytes() + kHeadBytes;
+  p.ok = p.shmem <= (size_t)kLdsPerCU;
+  return p;
+}
+
+bool win_usable(const gcmi_graph* g, int n_feat, bool aux) {
+  if (windows_disabled() || g->d_win_meta == nullptr || g->n_win <= 0) return false;
+  if (g->d_win_edges == nullptr || g->n_win_big < 0 || g->n_win_big > g->n_win) return false;
+  if (n_feat % 4 != 0 || n_feat > 256) return false;
+  return make_plan(g, n_feat, aux).ok;
+}
+
+template <int WT, int LPR, bool AUX, class Op>
+static int launch_wt(const gcmi_graph* g, const WinPlan& p, const float* x, int64_t ldx, const uint8_t* aux,
+                     const Op& op, hipStream_t st, const char* what) {
+  auto kern = win_kernel<WT, LPR, AUX, Op>;
+  static bool attr_done = false;  // per instantiation
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kLdsPerCU) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("%s: cannot raise the dynamic LDS limit", what);
+      return GCMI_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  const int n_norm = g->n_win - g->n_win_big;
+  const int by_lds = (int)((size_t)kLdsPerCU / p.shmem);
+  const int by_threads = 2048 / WT;
+  const int per_cu = std::max(1, std::min(env_int("GCMI_WIN_PER_CU", 8), std::min(by_lds, by_threads)));
+  const int g_norm = std::min(n_norm, 256 * per_cu);
+  const int g_big = std::min(g->n_win_big, 64);
+  if (g_norm + g_big == 0) return GCMI_OK;
+  hipLaunchKernelGGL(kern, dim3(g_norm + g_big), dim3(WT), p.shmem, st, g->d_win_meta, g->d_win_edges, n_norm,
+                     g->n_win, g_norm, p.L, p.Lbig, x, ldx, aux, op);
+  GCMI_CHECK_LAUNCH(what);
+  return GCMI_OK;
+}
+
+template <int LPR, bool AUX, class Op>
+static int launch_lpr(const gcmi_graph* g, const WinPlan& p, const float* x, int64_t ldx, const uint8_t* aux,
+                      const Op& op, hipStream_t st, const char* what) {
+  static const int wt = env_int("GCMI_WIN_THREADS", 512);
+  if (wt == 256) return launch_wt<256, LPR, AUX, Op>(g, p, x, ldx, aux, op, st, what);
+  return launch_wt<512, LPR, AUX, Op>(g, p, x, ldx, aux, op, st, what);
+}
+
+template <bool AUX, class Op>
+static int launch(const gcmi_graph* g, int n_feat, const float* x, int64_t ldx, const uint8_t* aux,
+                  const Op& op, hipStream_t st, const char* what) {
+  const WinPlan p = make_plan(g, n_feat, AUX);
+  switch (n_feat / 4) {
+    case 16: return launch_lpr<16, AUX, Op>(g, p, x, ldx, aux, op, st, what);
+    case 19: return launch_lpr<19, AUX, Op>(g, p, x, ldx, aux, op, st, what);
+    case 32: return launch_lpr<32, AUX, Op>(g, p, x, ldx, aux, op, st, what);
+    default: break;
+  }
+  set_error("%s: no window kernel for %d features", what, n_feat);
+  return GCMI_ERR_UNSUPPORTED;
+}
+
+bool win_has_width(int n_feat) { return n_feat == 64 || n_feat == 76 || n_feat == 128; }
+
+int win_gather_sum(const gcmi_graph* g, const float* d_x, int64_t ldx, int n_feat, float* d_s,
+                   int64_t lds, hipStream_t st) {
+  SumOp op{d_s, lds};
+  return launch<false>(g, n_feat, d_x, ldx, nullptr, op, st, "win_gather_sum");
+}
+
+int win_gather_max(const gcmi_graph* g, const float* d_x, int64_t ldx, int n_feat, const float* d_scale,
+                   const float* d_shift, float* d_out, int64_t ldo, uint8_t* d_arg, hipStream_t st) {
+  if (d_scale) {
+    MaxOp<true> op{d_scale, d_shift, d_out, ldo, d_arg};
+    return launch<false>(g, n_feat, d_x, ldx, nullptr, op, st, "win_gather_max");
+  }
+  MaxOp<false> op{nullptr, nullptr, d_out, ldo, d_arg};
+  return launch<false>(g, n_feat, d_x, ldx, nullptr, op, st, "win_gather_max");
+}
+
+int win_gather_max_bwd(const gcmi_graph* g, const float* d_dout, int64_t lddo, int n_feat,
+                       const uint8_t* d_arg, float* d_dx, int64_t lddx, hipStream_t st) {
+  MaxBwdOp op{d_dx, lddx};
+  return launch<true>(g, n_feat, d_dout, lddo, d_arg, op, st, "win_gather_max_bwd");
+}
+
+}  // namespace gcmi

@@ -170,6 +170,7 @@ seg_gemm_kernel(SegTable st, const float* __restrict__ a1, int64_t lda1, int k1,
       if (r < rows_valid) {
         float v = acc[reg] + bv;
         if (act == 1) v = v > 0.f ? v : 0.f;
+        if (act == 2) v += out[(int64_t)(row0 + r) * ldo + col];
         out[(int64_t)(row0 + r) * ldo + col] = v;
       }
     }
@@ -375,11 +376,15 @@ seg_gemm2_kernel(SegTable st, const float* __restrict__ a1, int64_t lda1, int k1
           v[q] = x;
         }
         if (vec_out && c + 3 < n_out) {
+          if (act == 2) {
+            const float4 o = *reinterpret_cast<const float4*>(orow + c);
+            v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+          }
           *reinterpret_cast<float4*>(orow + c) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            if (c + q < n_out) orow[c + q] = v[q];
+            if (c + q < n_out) orow[c + q] = act == 2 ? v[q] + orow[c + q] : v[q];
         }
       }
     }
@@ -574,7 +579,7 @@ int gcmi_seg_gemm(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_en
                  "seg_gemm: bad second operand");
   GCMI_CHECK_ARG(d_a1 || d_a2, "seg_gemm: no operand");
   GCMI_CHECK_ARG(d_bias == nullptr || bias_off != nullptr, "seg_gemm: bias without offsets");
-  GCMI_CHECK_ARG(act == 0 || act == 1, "seg_gemm: act must be 0 or 1");
+  GCMI_CHECK_ARG(act >= 0 && act <= 2, "seg_gemm: act must be 0 (none), 1 (ReLU) or 2 (out += result)");
   hipStream_t sm = (hipStream_t)stream;
   const bool vec4 = (d_a1 == nullptr || (aligned16(d_a1) && lda1 % 4 == 0)) &&
                     (d_a2 == nullptr || (aligned16(d_a2) && lda2 % 4 == 0));

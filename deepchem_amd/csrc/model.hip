@@ -350,12 +350,12 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
     float* dX = ws + w.tC;
     RUN(gcmi_seg_gemm(sg.n, sg.begin, sg.end, dgc, W, W, d_params + m->off_conv_w[l], sg.w_rel, nullptr, 0,
                       0, nullptr, nullptr, nullptr, nullptr, K, 1, 0, dS, K, stream));
+    // bonds listed from both ends: the scatter of dS is a gather (LDS-window kernel), and the
+    // self term accumulates onto it in the GEMM epilogue
+    if (sym) RUN(gcmi_gather_sum_fwd(g, dS, K, K, dX, K, 0, stream));
     RUN(gcmi_seg_gemm(sg.n, sg.begin, sg.end, dgc, W, W, d_params + m->off_conv_w[l], sg.w_self, nullptr, 0,
-                      0, nullptr, nullptr, nullptr, nullptr, K, 1, 0, dX, K, stream));
-    if (sym)
-      RUN(gcmi_gather_sum_fwd(g, dS, K, K, dX, K, 1, stream));
-    else
-      RUN(gcmi_scatter_add(g, dS, K, K, dX, K, stream));
+                      0, nullptr, nullptr, nullptr, nullptr, K, 1, sym ? 2 : 0, dX, K, stream));
+    if (!sym) RUN(gcmi_scatter_add(g, dS, K, K, dX, K, stream));
     dpool = dX;
   }
   return GCMI_OK;

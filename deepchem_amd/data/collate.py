@@ -74,9 +74,52 @@ class PinnedRing:
         self.events[self._last] = ev
 
 
-def collate_to_device(packed: PackedMols, sel: Optional[np.ndarray], device: torch.device,
-                      n_samples: Optional[int] = None, max_deg: int = 10,
-                      pad_features_to: int = 4, ring: Optional[PinnedRing] = None) -> DeviceBatch:
+class HostBatch:
+    """What ``gcmi_collate_plans`` wrote into one (pinned) host arena: float32 words
+    [features | membership | col_idx | mol_runs | win_meta | win_edges (uint16) | rev_pos (uint8)],
+    every part 16-byte aligned.  ``part(name)`` gives typed views of the arena (host) or of its
+    device copy."""
+
+    def __init__(self, arena, offsets, n_atoms, n_edges, n_sel, n_feat, ld, n_deg, deg_counts,
+                 symmetric, plan):
+        self.arena, self.off = arena, offsets
+        self.n_atoms, self.n_edges, self.n_sel = n_atoms, n_edges, n_sel
+        self.n_feat, self.ld, self.n_deg = n_feat, ld, n_deg
+        self.deg_counts, self.symmetric = deg_counts, symmetric
+        self.plan = plan                      # GcmiGraph as gcmi_collate_plans filled it
+        self.n_win, self.n_win_big = int(plan.n_win), int(plan.n_win_big)
+        self.win_alloc, self.win_ecap = int(plan.win_alloc), int(plan.win_ecap)
+        self.win_alloc_big, self.win_ecap_big = int(plan.win_alloc_big), int(plan.win_ecap_big)
+
+    @property
+    def n_words(self) -> int:
+        return self.off["end"]
+
+    def part(self, name: str, arena: Optional[torch.Tensor] = None) -> torch.Tensor:
+        a = self.arena if arena is None else arena
+        i32 = a.view(torch.int32)
+        o = self.off
+        if name == "features":
+            return a[:self.n_atoms * self.ld].view(self.n_atoms, self.ld)
+        if name == "membership":
+            return i32[o["mem"]:o["mem"] + self.n_atoms]
+        if name == "col_idx":
+            return i32[o["col"]:o["col"] + self.n_edges]
+        if name == "mol_runs":
+            return i32[o["runs"]:o["runs"] + self.n_sel * self.n_deg * 2]
+        if name == "win_meta":
+            return i32[o["win"]:o["win"] + self.n_win * _lib.GCMI_WIN_META_INTS]
+        if name == "win_edges":
+            return a[o["loc"]:o["rev"]].view(torch.int16)
+        if name == "rev_pos":
+            return a[o["rev"]:o["end"]].view(torch.uint8)[:self.n_edges]
+        raise KeyError(name)
+
+
+def collate_host(packed: PackedMols, sel: Optional[np.ndarray], max_deg: int = 10,
+                 pad_features_to: int = 4, ring: Optional[PinnedRing] = None,
+                 win_cap: int = 96, pin: Optional[bool] = None) -> HostBatch:
+    """Run the native collation into one host arena (no GPU involved)."""
     if sel is None:
         sel = np.arange(packed.n_mols, dtype=np.int64)
     sel = np.ascontiguousarray(sel, np.int64)
@@ -90,40 +133,56 @@ def collate_to_device(packed: PackedMols, sel: Optional[np.ndarray], device: tor
     n_feat = packed.n_feat
     ld = ((n_feat + pad_features_to - 1) // pad_features_to) * pad_features_to
     n_deg = max_deg + 1
-    # one arena: [features | membership | col_idx | mol_runs], every part 16-byte aligned
+
     def up4(n):
         return (n + 3) // 4 * 4
-    off_mem = n_atoms * ld
-    off_col = off_mem + up4(n_atoms)
-    off_runs = off_col + up4(n_edges)
-    total = off_runs + up4(n_sel * n_deg * 2)
-    pin = torch.cuda.is_available()
+    off = {"mem": n_atoms * ld}
+    off["col"] = off["mem"] + up4(n_atoms)
+    off["runs"] = off["col"] + up4(n_edges)
+    off["win"] = off["runs"] + up4(n_sel * n_deg * 2)
+    off["loc"] = off["win"] + n_sel * _lib.GCMI_WIN_META_INTS   # at most one window per molecule
+    off["rev"] = off["loc"] + up4((n_edges + 8 * n_sel + 1) // 2)  # every window padded to 8 entries
+    off["end"] = max(off["rev"] + up4((n_edges + 3) // 4), 4)
+    total = off["end"]
+    if pin is None:
+        pin = torch.cuda.is_available()
     if ring is not None:
-        arena = ring.get(max(total, 4))[:max(total, 4)]
+        arena = ring.get(total)[:total]
     else:
-        arena = torch.empty(max(total, 4), dtype=torch.float32, pin_memory=pin)
+        arena = torch.empty(total, dtype=torch.float32, pin_memory=pin)
     base = arena.data_ptr()
     feats = np.ascontiguousarray(packed.atom_features, np.float32)
     atom_ptr = np.ascontiguousarray(packed.atom_ptr, np.int64)
     adj_ptr = np.ascontiguousarray(packed.adj_ptr, np.int64)
     adj_idx = np.ascontiguousarray(packed.adj_idx, np.int32)
     g = _lib.GcmiGraph()
-    _lib.call("gcmi_collate", feats.ctypes.data, n_feat, atom_ptr.ctypes.data, adj_ptr.ctypes.data,
+    sym = ctypes.c_int32(1)
+    _lib.call("gcmi_collate_plans", feats.ctypes.data, n_feat, atom_ptr.ctypes.data, adj_ptr.ctypes.data,
               adj_idx.ctypes.data, sel.ctypes.data, n_sel, max_deg, base, ld, n_atoms,
-              base + 4 * off_mem, base + 4 * off_col, n_edges, base + 4 * off_runs, ctypes.byref(g))
-    dev_arena = arena.to(device, non_blocking=True)
+              base + 4 * off["mem"], base + 4 * off["col"], n_edges, base + 4 * off["runs"],
+              base + 4 * off["rev"], ctypes.byref(sym), int(win_cap), base + 4 * off["win"],
+              base + 4 * off["loc"], ctypes.byref(g))
+    counts = [g.deg_start[d + 1] - g.deg_start[d] for d in range(n_deg)]
+    return HostBatch(arena, off, n_atoms, n_edges, n_sel, n_feat, ld, n_deg, counts, bool(sym.value), g)
+
+
+def collate_to_device(packed: PackedMols, sel: Optional[np.ndarray], device: torch.device,
+                      n_samples: Optional[int] = None, max_deg: int = 10,
+                      pad_features_to: int = 4, ring: Optional[PinnedRing] = None,
+                      win_cap: int = 96) -> DeviceBatch:
+    hb = collate_host(packed, sel, max_deg, pad_features_to, ring, win_cap)
+    dev_arena = hb.arena.to(device, non_blocking=True)
     if ring is not None:
         ring.mark()
-    as_i32 = dev_arena.view(torch.int32)
-    x = dev_arena[:n_atoms * ld].view(n_atoms, ld)
-    membership = as_i32[off_mem:off_mem + n_atoms]
-    col_idx = as_i32[off_col:off_col + n_edges]
-    mol_runs = as_i32[off_runs:off_runs + n_sel * n_deg * 2]
-    counts = [g.deg_start[d + 1] - g.deg_start[d] for d in range(n_deg)]
-    graph = BatchGraph(counts, col_idx, membership, n_mols=n_sel, mol_runs=mol_runs, symmetric=None)
+    graph = BatchGraph(hb.deg_counts, hb.part("col_idx", dev_arena), hb.part("membership", dev_arena),
+                       n_mols=hb.n_sel, mol_runs=hb.part("mol_runs", dev_arena), symmetric=hb.symmetric)
     graph._arena = dev_arena  # keep the storage alive with the graph
-    graph.symmetric = _is_symmetric(packed)
-    return DeviceBatch(x, graph, n_sel if n_samples is None else n_samples, n_feat)
+    if hb.symmetric and hb.n_edges:
+        graph.attach_rev_pos(hb.part("rev_pos", dev_arena))
+    if hb.n_win > 0:
+        graph.attach_windows(hb.plan, hb.part("win_meta", dev_arena), hb.part("win_edges", dev_arena))
+    return DeviceBatch(hb.part("features", dev_arena), graph, hb.n_sel if n_samples is None else n_samples,
+                       hb.n_feat)
 
 
 def _is_symmetric(packed: PackedMols) -> bool:

@@ -73,6 +73,16 @@ class BatchGraph:
         self.c.d_mol_runs = None
         self.c.d_rev_pos = None
         self.rev_pos = None
+        self.c.n_win = 0
+        self.c.n_win_big = 0
+        self.c.win_alloc = 0
+        self.c.win_ecap = 0
+        self.c.win_alloc_big = 0
+        self.c.win_ecap_big = 0
+        self.c.d_win_meta = None
+        self.c.d_win_edges = None
+        self.win_meta = None
+        self.win_edges = None
         # segment tables of the per-degree GEMMs: segment d = rows of degree d
         n_seg = max_deg + 1
         self.seg_begin = (ctypes.c_int32 * n_seg)(*self.deg_start[:-1])
@@ -106,6 +116,32 @@ class BatchGraph:
         self.n_mols = int(n_mols)
         self.mol_runs = mol_runs
         self.c.d_mol_runs = mol_runs.data_ptr()
+
+    def attach_rev_pos(self, rev: torch.Tensor):
+        """Reverse edge slots computed by the host collation (symmetric adjacency)."""
+        if rev.dtype != torch.uint8 or rev.numel() != self.n_edges or not rev.is_cuda:
+            raise ValueError("bad rev_pos tensor")
+        self.rev_pos = rev
+        self.symmetric = True
+        self.c.d_rev_pos = rev.data_ptr()
+
+    def attach_windows(self, plan: GcmiGraph, win_meta: torch.Tensor, win_edges: torch.Tensor):
+        """Molecule windows for the LDS-staged gather kernels (see struct gcmi_graph); ``plan`` is
+        the descriptor gcmi_collate_plans filled."""
+        if win_meta.dtype != torch.int32 or win_meta.numel() != plan.n_win * _lib.GCMI_WIN_META_INTS \
+                or not win_meta.is_cuda:
+            raise ValueError("bad win_meta tensor")
+        if win_edges.dtype != torch.int16 or not win_edges.is_cuda or win_edges.numel() % 8 \
+                or win_edges.data_ptr() % 16:
+            raise ValueError("bad win_edges tensor")
+        if max(plan.win_alloc, plan.win_alloc_big) > _lib.GCMI_WIN_MAX_SLOTS or plan.win_ecap % 8 \
+                or plan.win_ecap_big % 8 or not (0 <= plan.n_win_big <= plan.n_win):
+            raise ValueError("bad window sizes")
+        self.win_meta, self.win_edges = win_meta, win_edges
+        for f in ("n_win", "n_win_big", "win_alloc", "win_ecap", "win_alloc_big", "win_ecap_big"):
+            setattr(self.c, f, int(getattr(plan, f)))
+        self.c.d_win_meta = win_meta.data_ptr()
+        self.c.d_win_edges = win_edges.data_ptr()
 
     def ensure_rev_pos(self) -> bool:
         """Build (once) the reverse-slot table that lets the scatter backwards run as

@@ -52,6 +52,10 @@ typedef enum gcmi_status {
  * edge_start[d].  That is a CSR whose row pointer is implicit:
  *   row_ptr(i) = edge_start[d] + (i - deg_start[d]) * d.
  */
+#define GCMI_WIN_META_INTS 24
+#define GCMI_WIN_SLOT_BITS 12
+#define GCMI_WIN_MAX_SLOTS 4095
+
 typedef struct gcmi_graph {
   int32_t n_atoms;                      /* N                                        */
   int32_t n_edges;                      /* E = sum_d d * n_d  (directed)            */
@@ -69,7 +73,33 @@ typedef struct gcmi_graph {
                                            with i = col_idx[row_ptr(k)+j], the slot of
                                            k in i's own neighbour list; exists when
                                            every bond is listed from both ends; built
-                                           by gcmi_build_rev_pos                    */
+                                           by gcmi_build_rev_pos or gcmi_collate    */
+  /* Molecule windows (optional; produced by gcmi_collate_plans): consecutive molecules grouped
+   * so that a window holds <= win_cap atoms (a larger molecule gets a window of its own; those
+   * oversized windows come last in d_win_meta).
+   * Because every degree block is sorted by molecule, the atoms of a window are <= max_deg+1
+   * CONTIGUOUS row ranges, one per degree block.  A workgroup streams those ranges into LDS
+   * once ("slots", numbered degree block by degree block) and serves every neighbour read of
+   * the window from LDS: all neighbours of an atom belong to its own molecule, hence to its
+   * window.
+   *   d_win_meta[w][GCMI_WIN_META_INTS]:
+   *     [0..10]  row_of_slot_base[d] = first row of the window in degree block d - slot_start[d]
+   *              (global row of slot s of degree d = base[d] + s)
+   *     [11..21] slot_start[1..11]  (slot_start[0] = 0, slot_start[11] = atoms in the window)
+   *     [22]     first entry of the window in d_win_edges (a multiple of 8)
+   *     [23]     edge entries of the window (unpadded)
+   *   d_win_edges: the neighbour lists window by window, inside a window in (degree, row, j)
+   *     order, every window padded to a multiple of 8 entries; entry = LDS slot of the
+   *     neighbour | rev_pos << 12 (rev_pos = 15: no partner).                                */
+  int32_t n_win;                        /* all windows: ordinary ones first, then     */
+  int32_t n_win_big;                    /* the oversized ones (one molecule > win_cap) */
+  int32_t win_alloc;                    /* atoms of the largest ordinary window       */
+  int32_t win_ecap;                     /* its padded edge entries (largest)          */
+  int32_t win_alloc_big;                /* the same for the oversized windows         */
+  int32_t win_ecap_big;
+  int32_t win_reserved[2];
+  const int32_t* d_win_meta;            /* n_win * GCMI_WIN_META_INTS                */
+  const uint16_t* d_win_edges;          /* <= E + 8 * n_win                          */
 } gcmi_graph;
 
 int gcmi_version(void);
@@ -94,6 +124,20 @@ int gcmi_collate(const float* atom_features, int64_t n_feat, const int64_t* atom
                  int64_t n_sel, int32_t max_deg, float* out_features, int64_t out_ld,
                  int64_t cap_atoms, int32_t* out_membership, int32_t* out_col_idx,
                  int64_t cap_edges, int32_t* out_mol_runs, gcmi_graph* graph);
+/* The same plus the plans of the LDS-window kernels and of the gather-form backwards, all
+ * optional (NULL = skip):
+ *   out_rev_pos   [E]  uint8; *out_symmetric = 0 when some bond is not listed from both ends
+ *                      (the table is then unusable);
+ *   win_cap > 0:   out_win_meta [<= n_sel*GCMI_WIN_META_INTS], out_win_edges
+ *                  [<= E + 8*n_sel] uint16; graph->n_win, n_win_big, win_alloc*, win_ecap* are filled
+ *                  (n_win = 0 when a molecule exceeds GCMI_WIN_MAX_SLOTS atoms).               */
+int gcmi_collate_plans(const float* atom_features, int64_t n_feat, const int64_t* atom_ptr,
+                       const int64_t* adj_ptr, const int32_t* adj_idx, const int64_t* sel,
+                       int64_t n_sel, int32_t max_deg, float* out_features, int64_t out_ld,
+                       int64_t cap_atoms, int32_t* out_membership, int32_t* out_col_idx,
+                       int64_t cap_edges, int32_t* out_mol_runs, uint8_t* out_rev_pos,
+                       int32_t* out_symmetric, int32_t win_cap, int32_t* out_win_meta,
+                       uint16_t* out_win_edges, gcmi_graph* graph);
 
 /* ---------------------------------------------------------------- graph plan
  * d_mol_runs from d_membership (device).  d_flag (1 int, device) is set to 1
@@ -184,7 +228,7 @@ int gcmi_bn_bwd(const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx, 
  * W1_s is the k1 x n_out row-major block at d_w1 + w1_off[s] (floats); a
  * negative offset drops that term for the segment.  a2/w2 may be NULL.
  * bias_s = d_bias + bias_off[s] (n_out floats; negative offset: none).
- * act: 0 none, 1 relu.  trans_w != 0: the blocks are stored n_out x k
+ * act: 0 none, 1 relu, 2 accumulate (out += the result; no activation).  trans_w != 0: the blocks are stored n_out x k
  * (nn.Linear layout, or the transposed product of a backward pass).
  * seg_begin, seg_end, *_off are HOST arrays of n_seg entries.
  *

@@ -37,11 +37,14 @@ def main():
     ap.add_argument("--mols", type=int, default=65536)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--win-cap", type=int, default=None)
     args = ap.parse_args()
     only = set(x for x in args.only.split(",") if x)
     dev = torch.device("cuda:0")
     packed = synthetic_molecules(args.mols, seed=1)
-    b = collate_to_device(packed, None, dev)
+    b = collate_to_device(packed, None, dev, **({} if args.win_cap is None else {"win_cap": args.win_cap}))
+    print("windows:", b.graph.c.n_win, "big:", b.graph.c.n_win_big, "alloc:", b.graph.c.win_alloc,
+          b.graph.c.win_alloc_big, flush=True)
     g = b.graph
     g.ensure_rev_pos()
     N, E, B = g.n_atoms, g.n_edges, g.n_mols
