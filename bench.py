@@ -45,9 +45,14 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fit-pipeline", type=int, default=1,
                     help="also time end-to-end fit() (collation + H2D + step) on a PackedDataset")
+    ap.add_argument("--profile-only", action="store_true",
+                    help="only the large-batch steps (for rocprofv3 passes): no small-batch, fit or CPU legs")
     ap.add_argument("--small-batch", type=int, default=100,
                     help="also report mol/s at the reference's default batch size (0 = skip)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.profile_only:
+        args.small_batch, args.fit_pipeline, args.no_cpu_baseline = 0, 0, True
+    return args
 
 
 def gather_sum_bytes(n_atoms, n_edges, n_deg0, feats, accumulate):
@@ -57,6 +62,24 @@ def gather_sum_bytes(n_atoms, n_edges, n_deg0, feats, accumulate):
     else:
         b += n_deg0 * 4 * feats  # zero rows of lone atoms
     return b
+
+
+def measured_traffic(launches_per_step):
+    """HBM bytes per gather-sum launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 +
+    WRITE_SIZE, tools/pmc_traffic.py) -- counters cannot be read from inside the process."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            kernels = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    tot, n = 0, 0
+    for name, rec in kernels.items():
+        if "SumOp" in name and "hbm_bytes_per_launch" in rec:
+            k = rec.get("fetch_launches", 1)
+            tot += rec["hbm_bytes_per_launch"] * k
+            n += k
+    return int(tot / n) if n else None
 
 
 def make_workload(args, rank, device, batch):
@@ -200,12 +223,13 @@ def main():
     g = dbatch.graph
     n0 = g.deg_counts[0]
     # gather-sum launches of one step: forward layer 0 (F=75), forward layer 1 (F=64) and, in
-    # "full" mode, the backward of layer 1 as a gather of dS (F=64, accumulating)
+    # "full" mode, the backward of layer 1 as a gather of dS (F=64; the self term is added by the
+    # epilogue of the following GEMM)
     per_step = gather_sum_bytes(g.n_atoms, g.n_edges, n0, 75, False) + \
         gather_sum_bytes(g.n_atoms, g.n_edges, n0, 64, False)
     launches_per_step = 2
     if args.grad_mode == "full":
-        per_step += gather_sum_bytes(g.n_atoms, g.n_edges, n0, 64, True)
+        per_step += gather_sum_bytes(g.n_atoms, g.n_edges, n0, 64, False)
         launches_per_step = 3
     n_launch, ms = ktimes["gather_sum"]
     achieved = (per_step * args.steps) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -239,7 +263,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None,
+            "traffic": measured_traffic(launches_per_step),
             "algorithmic_bytes_per_step": int(per_step),
             "launches_per_step": launches_per_step,
             "avg_launch_us": round(ms * 1e3 / max(n_launch, 1), 2),
