@@ -197,9 +197,11 @@ def main():
 
     kernel_ids = {"gather_sum": K_GATHER_SUM, "gather_max": K_GATHER_MAX, "gather_max_bwd": K_GATHER_MAX_BWD,
                   "readout": K_READOUT, "seg_gemm": K_SEG_GEMM, "wgrad": K_WGRAD}
-    for kid in kernel_ids.values():
-        ops.timing_enable(kid, True)
-        ops.timing_read(kid, reset=True)
+    # Inside the timed region only the roofline kernel is event-timed: every timed launch is
+    # bracketed by two event records on the launch stream, which costs ~10 us of queue time each.
+    # The other kernel families are measured in a second, untimed pass.
+    ops.timing_enable(K_GATHER_SUM, True)
+    ops.timing_read(K_GATHER_SUM, reset=True)
 
     def barrier():
         torch.cuda.synchronize()
@@ -212,6 +214,13 @@ def main():
     run_steps(model, dbatch, labels, weights, args.steps)
     barrier()
     wall = time.perf_counter() - t0
+    gather_time = ops.timing_read(K_GATHER_SUM, reset=True)
+    breakdown_steps = min(args.steps, 5)
+    for kid in kernel_ids.values():
+        ops.timing_enable(kid, True)
+        ops.timing_read(kid, reset=True)
+    run_steps(model, dbatch, labels, weights, breakdown_steps)
+    torch.cuda.synchronize()
     ktimes = {name: ops.timing_read(kid, reset=True) for name, kid in kernel_ids.items()}
     for kid in kernel_ids.values():
         ops.timing_enable(kid, False)
@@ -231,7 +240,7 @@ def main():
     if args.grad_mode == "full":
         per_step += gather_sum_bytes(g.n_atoms, g.n_edges, n0, 64, False)
         launches_per_step = 3
-    n_launch, ms = ktimes["gather_sum"]
+    n_launch, ms = gather_time
     achieved = (per_step * args.steps) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
 
     out = {
@@ -268,7 +277,7 @@ def main():
             "launches_per_step": launches_per_step,
             "avg_launch_us": round(ms * 1e3 / max(n_launch, 1), 2),
         },
-        "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in ktimes.items()},
+        "kernel_ms_per_step": {k: round(v[1] / breakdown_steps, 4) for k, v in ktimes.items()},
     }
 
     if rank == 0 and args.small_batch and world == 1:

@@ -18,7 +18,9 @@ namespace gcmi {
 constexpr int kBBlock = 256;
 constexpr int kRowsPerBlock = 512;
 constexpr int kReplicas = 32;  // accumulator replicas: same-address fp64 atomics serialise
-// scratch layout (doubles): [0, 2F) reduced sums, then kReplicas blocks of 2F partial sums
+// scratch layout (doubles): [0, 2F) backward coefficient vectors (3F floats), then kReplicas blocks
+// of 2F partial sums.  The kernels that consume the partial sums zero them again, so a scratch
+// that starts clean stays clean (the whole-model path zeroes it once per pass).
 
 // sums[0:F] += sum_r a[r,:],  sums[F:2F] += sum_r a[r,:]*b[r,:]
 // MODE 0: b = a (sum of squares).  MODE 1: b = (x - mean)*invstd (x given), a = dy.
@@ -94,15 +96,20 @@ col_sums_kernel(const float* __restrict__ a, int64_t lda, const float* __restric
   }
 }
 
-__global__ void sums_reduce_kernel(double* __restrict__ sums, int n_feat) {
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < 2 * n_feat; c += gridDim.x * blockDim.x) {
-    double t = 0.0;
-    for (int r = 0; r < kReplicas; ++r) t += sums[(size_t)2 * n_feat * (1 + r) + c];
-    sums[c] = t;
+// column c of the reduced sums: adds the replicas up and leaves them zero
+__device__ __forceinline__ void take_sums(double* __restrict__ sums, int n_feat, int c, double& t1, double& t2) {
+  t1 = 0.0;
+  t2 = 0.0;
+  for (int r = 0; r < kReplicas; ++r) {
+    double* rep = sums + (size_t)2 * n_feat * (1 + r);
+    t1 += rep[c];
+    t2 += rep[n_feat + c];
+    rep[c] = 0.0;
+    rep[n_feat + c] = 0.0;
   }
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, int64_t n_rows, int n_feat,
+__global__ void bn_finalize_kernel(double* __restrict__ sums, int64_t n_rows, int n_feat,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float eps, float momentum, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, float* __restrict__ mean,
@@ -110,8 +117,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int64_t n_ro
                                    float* __restrict__ shift) {
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_feat; c += gridDim.x * blockDim.x) {
     const double n = (double)n_rows;
-    const double m = sums[c] / n;
-    double var = sums[n_feat + c] / n - m * m;  // biased
+    double t1, t2;
+    take_sums(sums, n_feat, c, t1, t2);
+    const double m = t1 / n;
+    double var = t2 / n - m * m;  // biased
     if (var < 0.0) var = 0.0;
     const float mf = (float)m;
     const float is = (float)(1.0 / sqrt(var + (double)eps));
@@ -170,13 +179,14 @@ bn_apply_kernel(const float* __restrict__ x, int64_t ldx, int64_t slots, int lpr
 // The three coefficient vectors are produced once (bn_bwd_params_kernel); the streaming
 // kernel keeps them in registers: each thread owns one 16-byte column chunk and walks rows.
 // RELU: x is a ReLU output and dx is wanted w.r.t. the ReLU input: dx *= (x > 0).
-__global__ void bn_bwd_params_kernel(const double* __restrict__ sums, int64_t n_rows, int n_feat,
+__global__ void bn_bwd_params_kernel(double* __restrict__ sums, int64_t n_rows, int n_feat,
                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                      const float* __restrict__ invstd, float* __restrict__ dgamma,
                                      float* __restrict__ dbeta, float* __restrict__ coef) {
   const double inv_n = 1.0 / (double)n_rows;
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_feat; c += gridDim.x * blockDim.x) {
-    const double db = sums[c], dg = sums[n_feat + c];
+    double db, dg;
+    take_sums(sums, n_feat, c, db, dg);
     if (dbeta) dbeta[c] = (float)db;
     if (dgamma) dgamma[c] = (float)dg;
     const double is = (double)invstd[c];
@@ -238,8 +248,9 @@ bn_bwd_dx_kernel(const float* __restrict__ dy, int64_t lddy, const float* __rest
 
 static int launch_col_sums(int mode, const float* a, int64_t lda, const float* x, int64_t ldx,
                            const float* mean, const float* invstd, int64_t n_rows, int n_feat,
-                           double* sums, hipStream_t st) {
-  if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * n_feat * (1 + kReplicas), st) != hipSuccess) {
+                           double* sums, bool acc_clean, hipStream_t st) {
+  if (!acc_clean &&
+      hipMemsetAsync(sums, 0, sizeof(double) * 2 * n_feat * (1 + kReplicas), st) != hipSuccess) {
     set_error("bn: memset failed");
     return GCMI_ERR_LAUNCH;
   }
@@ -259,10 +270,30 @@ static int launch_col_sums(int mode, const float* a, int64_t lda, const float* x
   }
 #undef LAUNCH_CS
   GCMI_CHECK_LAUNCH("bn col_sums");
-  hipLaunchKernelGGL(sums_reduce_kernel, dim3((2 * n_feat + 255) / 256), dim3(256), 0, st, sums, n_feat);
-  GCMI_CHECK_LAUNCH("bn sums_reduce");
   return GCMI_OK;
 }
+
+int bn_stats_impl(const float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat,
+                  const float* d_gamma, const float* d_beta, float eps, float momentum,
+                  float* d_running_mean, float* d_running_var, float* d_mean, float* d_invstd,
+                  float* d_scale, float* d_shift, double* d_acc, bool acc_clean, void* stream) {
+  GCMI_CHECK_ARG(n_feat > 0 && n_rows > 0 && ldx >= n_feat, "bn_stats: bad shape (n_rows=%lld)",
+                 (long long)n_rows);
+  GCMI_CHECK_ARG(d_x && d_scale && d_shift && d_acc, "bn_stats: NULL buffer");
+  hipStream_t st = (hipStream_t)stream;
+  int rc = launch_col_sums(0, d_x, ldx, nullptr, 0, nullptr, nullptr, n_rows, n_feat, d_acc, acc_clean, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((n_feat + 255) / 256), dim3(256), 0, st, d_acc, n_rows,
+                     n_feat, d_gamma, d_beta, eps, momentum, d_running_mean, d_running_var, d_mean,
+                     d_invstd, d_scale, d_shift);
+  GCMI_CHECK_LAUNCH("bn_finalize");
+  return GCMI_OK;
+}
+
+int bn_bwd_impl(const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx, int64_t n_rows,
+                int32_t n_feat, const float* d_gamma, const float* d_mean,
+                const float* d_invstd, float* d_dgamma, float* d_dbeta, float* d_dx,
+                int64_t lddx, int32_t relu_mask, double* d_acc, bool acc_clean, void* stream);
 
 }  // namespace gcmi
 
@@ -274,17 +305,8 @@ int gcmi_bn_stats(const float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat,
                   const float* d_gamma, const float* d_beta, float eps, float momentum,
                   float* d_running_mean, float* d_running_var, float* d_mean, float* d_invstd,
                   float* d_scale, float* d_shift, double* d_acc, void* stream) {
-  GCMI_CHECK_ARG(n_feat > 0 && n_rows > 0 && ldx >= n_feat, "bn_stats: bad shape (n_rows=%lld)",
-                 (long long)n_rows);
-  GCMI_CHECK_ARG(d_x && d_scale && d_shift && d_acc, "bn_stats: NULL buffer");
-  hipStream_t st = (hipStream_t)stream;
-  int rc = launch_col_sums(0, d_x, ldx, nullptr, 0, nullptr, nullptr, n_rows, n_feat, d_acc, st);
-  if (rc) return rc;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((n_feat + 255) / 256), dim3(256), 0, st, d_acc, n_rows,
-                     n_feat, d_gamma, d_beta, eps, momentum, d_running_mean, d_running_var, d_mean,
-                     d_invstd, d_scale, d_shift);
-  GCMI_CHECK_LAUNCH("bn_finalize");
-  return GCMI_OK;
+  return bn_stats_impl(d_x, ldx, n_rows, n_feat, d_gamma, d_beta, eps, momentum, d_running_mean,
+                       d_running_var, d_mean, d_invstd, d_scale, d_shift, d_acc, false, stream);
 }
 
 int gcmi_bn_fold_eval(const float* d_gamma, const float* d_beta, const float* d_running_mean,
@@ -326,14 +348,26 @@ int gcmi_bn_bwd(const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx, 
                 int32_t n_feat, const float* d_gamma, const float* d_mean,
                 const float* d_invstd, float* d_dgamma, float* d_dbeta, float* d_dx,
                 int64_t lddx, int32_t relu_mask, double* d_acc, void* stream) {
+  return bn_bwd_impl(d_dy, lddy, d_x, ldx, n_rows, n_feat, d_gamma, d_mean, d_invstd, d_dgamma, d_dbeta,
+                     d_dx, lddx, relu_mask, d_acc, false, stream);
+}
+
+}  // extern "C"
+
+namespace gcmi {
+
+int bn_bwd_impl(const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx, int64_t n_rows,
+                int32_t n_feat, const float* d_gamma, const float* d_mean,
+                const float* d_invstd, float* d_dgamma, float* d_dbeta, float* d_dx,
+                int64_t lddx, int32_t relu_mask, double* d_acc, bool acc_clean, void* stream) {
   GCMI_CHECK_ARG(n_feat > 0 && n_rows > 0 && lddy >= n_feat && ldx >= n_feat, "bn_bwd: bad shape");
   GCMI_CHECK_ARG(d_dy && d_x && d_mean && d_invstd && d_acc, "bn_bwd: NULL buffer");
   GCMI_CHECK_ARG(d_dx == nullptr || lddx >= n_feat, "bn_bwd: bad lddx");
   hipStream_t st = (hipStream_t)stream;
-  int rc = launch_col_sums(1, d_dy, lddy, d_x, ldx, d_mean, d_invstd, n_rows, n_feat, d_acc, st);
+  int rc = launch_col_sums(1, d_dy, lddy, d_x, ldx, d_mean, d_invstd, n_rows, n_feat, d_acc, acc_clean, st);
   if (rc) return rc;
-  // coefficient vectors live in the (now reduced, hence free) replica area of the scratch
-  float* coef = reinterpret_cast<float*>(d_acc + 2 * (size_t)n_feat);
+  // coefficient vectors (3F floats) live in the first 2F doubles of the scratch
+  float* coef = reinterpret_cast<float*>(d_acc);
   hipLaunchKernelGGL(bn_bwd_params_kernel, dim3((n_feat + 255) / 256), dim3(256), 0, st, d_acc, n_rows,
                      n_feat, d_gamma, d_mean, d_invstd, d_dgamma, d_dbeta, coef);
   GCMI_CHECK_LAUNCH("bn_bwd_params");
@@ -359,4 +393,4 @@ int gcmi_bn_bwd(const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx, 
   return GCMI_OK;
 }
 
-}  // extern "C"
+}  // namespace gcmi

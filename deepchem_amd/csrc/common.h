@@ -71,6 +71,20 @@ int win_gather_max(const gcmi_graph* g, const float* d_x, int64_t ldx, int n_fea
 int win_gather_max_bwd(const gcmi_graph* g, const float* d_dout, int64_t lddo, int n_feat,
                        const uint8_t* d_arg, float* d_dx, int64_t lddx, hipStream_t st);
 
+// BatchNorm / loss with a caller-guaranteed clean accumulator scratch (bn.hip, loss.hip): the
+// whole-model path zeroes its scratch once per pass instead of once per call.
+int bn_stats_impl(const float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat, const float* d_gamma,
+                  const float* d_beta, float eps, float momentum, float* d_running_mean,
+                  float* d_running_var, float* d_mean, float* d_invstd, float* d_scale, float* d_shift,
+                  double* d_acc, bool acc_clean, void* stream);
+int bn_bwd_impl(const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx, int64_t n_rows,
+                int32_t n_feat, const float* d_gamma, const float* d_mean, const float* d_invstd,
+                float* d_dgamma, float* d_dbeta, float* d_dx, int64_t lddx, int32_t relu_mask,
+                double* d_acc, bool acc_clean, void* stream);
+int loss_impl(int32_t kind, const float* d_logits, const float* d_labels, const float* d_weights,
+              int64_t n_rows, int32_t n_tasks, int32_t n_classes, float* d_loss, float* d_dlogits,
+              float* d_probs, double* d_acc, bool acc_clean, void* stream);
+
 // degree of batch row i: the number of block starts (d >= 1) that are <= i.
 __device__ __forceinline__ int degree_of_row(const DegTable& t, int i) {
   int d = 0;

@@ -63,9 +63,12 @@ loss_kernel(int kind, const float* __restrict__ logits, const float* __restrict_
   if (threadIdx.x == 0) atomicAdd(acc, t);
 }
 
-__global__ void loss_finalize_kernel(const double* __restrict__ acc, float inv_count,
+__global__ void loss_finalize_kernel(double* __restrict__ acc, float inv_count,
                                      float* __restrict__ loss) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) *loss = (float)(*acc * (double)inv_count);
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    *loss = (float)(*acc * (double)inv_count);
+    *acc = 0.0;  // a scratch that starts clean stays clean
+  }
 }
 
 __global__ void __launch_bounds__(kLBlock)
@@ -99,21 +102,14 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
   }
 }
 
-}  // namespace gcmi
-
-using namespace gcmi;
-
-extern "C" {
-
-int gcmi_loss_fwd_bwd(int32_t kind, const float* d_logits, const float* d_labels,
-                      const float* d_weights, int64_t n_rows, int32_t n_tasks,
-                      int32_t n_classes, float* d_loss, float* d_dlogits, float* d_probs,
-                      double* d_acc, void* stream) {
+int loss_impl(int32_t kind, const float* d_logits, const float* d_labels, const float* d_weights,
+              int64_t n_rows, int32_t n_tasks, int32_t n_classes, float* d_loss, float* d_dlogits,
+              float* d_probs, double* d_acc, bool acc_clean, void* stream) {
   GCMI_CHECK_ARG(kind == 0 || kind == 1, "loss: kind must be 0 (softmax CE) or 1 (L2)");
   GCMI_CHECK_ARG(n_rows > 0 && n_tasks > 0 && (kind == 1 || n_classes > 0), "loss: bad shape");
   GCMI_CHECK_ARG(d_logits && d_labels && d_loss && d_acc, "loss: NULL buffer");
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(d_acc, 0, sizeof(double), st) != hipSuccess) {
+  if (!acc_clean && hipMemsetAsync(d_acc, 0, sizeof(double), st) != hipSuccess) {
     set_error("loss: memset failed");
     return GCMI_ERR_LAUNCH;
   }
@@ -126,6 +122,20 @@ int gcmi_loss_fwd_bwd(int32_t kind, const float* d_logits, const float* d_labels
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, d_acc, inv_count, d_loss);
   GCMI_CHECK_LAUNCH("loss_finalize");
   return GCMI_OK;
+}
+
+}  // namespace gcmi
+
+using namespace gcmi;
+
+extern "C" {
+
+int gcmi_loss_fwd_bwd(int32_t kind, const float* d_logits, const float* d_labels,
+                      const float* d_weights, int64_t n_rows, int32_t n_tasks,
+                      int32_t n_classes, float* d_loss, float* d_dlogits, float* d_probs,
+                      double* d_acc, void* stream) {
+  return loss_impl(kind, d_logits, d_labels, d_weights, n_rows, n_tasks, n_classes, d_loss, d_dlogits,
+                   d_probs, d_acc, false, stream);
 }
 
 int gcmi_softmax(const float* d_logits, int64_t n_rows_tasks, int32_t n_classes, float* d_probs,

@@ -46,7 +46,9 @@ static inline int64_t up4(int64_t n) { return (n + 3) / 4 * 4; }
 struct Ws {
   int64_t S[kMaxL], gc[kMaxL], pool[kMaxL], arg[kMaxL], bsum[kMaxL], bnv[kMaxL + 1];
   int64_t ldS[kMaxL], ngather[kMaxL];
-  int64_t dense, arg_r, dlogits, dfp, tA, tB, tC, tD, tE, dbsum, acc, total;
+  int64_t dense, arg_r, dfp, tA, tB, tC, tD, tE, total;
+  // one region the backward zeroes with a single memset: [dlogits | dbsum per layer | lacc | acc]
+  int64_t dlogits, dbsum[kMaxL], lacc, acc, z_end;
 };
 
 static Ws carve(const gcmi_model_desc* m, int64_t N, int64_t B, int64_t ld_features) {
@@ -81,15 +83,17 @@ static Ws carve(const gcmi_model_desc* m, int64_t N, int64_t B, int64_t ld_featu
   w.bnv[L] = take(4 * D);
   w.dense = take(N * D);
   w.arg_r = take(B * D);
-  w.dlogits = take(B * TC);
   w.dfp = take(B * 2 * D);
   w.tA = take(N * wmax);
   w.tB = take(N * wmax);
   w.tC = take(N * wmax);
   w.tD = take(N * wmax);
   w.tE = take(N * kmax);
-  w.dbsum = take((int64_t)(m->max_deg + 1) * wmax);
+  w.dlogits = take(B * TC);
+  for (int l = 0; l < L; ++l) w.dbsum[l] = take((int64_t)(m->max_deg + 1) * m->conv_width[l]);
+  w.lacc = take(4);
   w.acc = take(2 * GCMI_BN_ACC_DOUBLES(wmax));
+  w.z_end = off;
   w.total = off;
   return w;
 }
@@ -160,6 +164,11 @@ int gcmi_model_forward(const gcmi_model_desc* m, const gcmi_graph* g, const floa
   float* ws = io->d_workspace;
   const float* x = io->d_atom_features;
   int64_t ldx = io->ld_features;
+  if (training && m->batch_norm && N > 0 &&
+      hipMemsetAsync(ws + w.acc, 0, sizeof(float) * (size_t)(w.z_end - w.acc), st) != hipSuccess) {
+    set_error("model_forward: memset failed");
+    return GCMI_ERR_LAUNCH;
+  }
   for (int l = 0; l < L; ++l) {
     const int K = l == 0 ? m->n_feat_in : m->conv_width[l - 1];
     const int W = m->conv_width[l];
@@ -180,10 +189,10 @@ int gcmi_model_forward(const gcmi_model_desc* m, const gcmi_graph* g, const floa
       scale = bnv + 2 * W;
       shift = bnv + 3 * W;
       if (training) {
-        RUN(gcmi_bn_stats(ws + w.gc[l], W, N, W, d_params + m->off_bn_gamma[l],
+        RUN(bn_stats_impl(ws + w.gc[l], W, N, W, d_params + m->off_bn_gamma[l],
                           d_params + m->off_bn_beta[l], m->bn_eps, m->bn_momentum,
                           io->d_bn_running_mean[l], io->d_bn_running_var[l], bnv, bnv + W, scale, shift,
-                          reinterpret_cast<double*>(ws + w.acc), stream));
+                          reinterpret_cast<double*>(ws + w.acc), true, stream));
       } else {
         RUN(gcmi_bn_fold_eval(d_params + m->off_bn_gamma[l], d_params + m->off_bn_beta[l],
                               io->d_bn_running_mean[l], io->d_bn_running_var[l], m->bn_eps, W, scale,
@@ -213,9 +222,9 @@ int gcmi_model_forward(const gcmi_model_desc* m, const gcmi_graph* g, const floa
     scale = bnv + 2 * D;
     shift = bnv + 3 * D;
     if (training) {
-      RUN(gcmi_bn_stats(ws + w.dense, D, N, D, d_params + m->off_bn_gamma[L], d_params + m->off_bn_beta[L],
+      RUN(bn_stats_impl(ws + w.dense, D, N, D, d_params + m->off_bn_gamma[L], d_params + m->off_bn_beta[L],
                         m->bn_eps, m->bn_momentum, io->d_bn_running_mean[L], io->d_bn_running_var[L], bnv,
-                        bnv + D, scale, shift, reinterpret_cast<double*>(ws + w.acc), stream));
+                        bnv + D, scale, shift, reinterpret_cast<double*>(ws + w.acc), true, stream));
     } else {
       RUN(gcmi_bn_fold_eval(d_params + m->off_bn_gamma[L], d_params + m->off_bn_beta[L],
                             io->d_bn_running_mean[L], io->d_bn_running_var[L], m->bn_eps, D, scale, shift,
@@ -279,11 +288,12 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
     return GCMI_OK;
   };
   RUN(zero(d_grads + lo, sizeof(float) * (size_t)(hi - lo)));
-  // ---- loss on the first n_rows molecules; rows beyond carry no gradient
-  RUN(zero(ws + w.dlogits, sizeof(float) * (size_t)(B * TC)));
-  RUN(gcmi_loss_fwd_bwd(m->mode == 0 ? 0 : 1, io->d_logits, d_labels, d_weights, n_rows, m->n_tasks,
-                        m->n_classes, io->d_loss, ws + w.dlogits, nullptr,
-                        reinterpret_cast<double*>(ws + w.acc), stream));
+  // dlogits (rows beyond n_rows carry no gradient), the bias-gradient sums and every accumulator
+  RUN(zero(ws + w.dlogits, sizeof(float) * (size_t)(w.z_end - w.dlogits)));
+  // ---- loss on the first n_rows molecules
+  RUN(loss_impl(m->mode == 0 ? 0 : 1, io->d_logits, d_labels, d_weights, n_rows, m->n_tasks,
+                m->n_classes, io->d_loss, ws + w.dlogits, nullptr,
+                reinterpret_cast<double*>(ws + w.lacc), true, stream));
   const int32_t zero32 = 0;
   const int64_t zero64 = 0;
   const int32_t nB = (int32_t)B, nN = (int32_t)N;
@@ -300,9 +310,9 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
                        reinterpret_cast<const int32_t*>(ws + w.arg_r), dyD, D, stream));
   if (m->batch_norm) {
     const float* bnv = ws + w.bnv[L];
-    RUN(gcmi_bn_bwd(dyD, D, ws + w.dense, D, N, D, d_params + m->off_bn_gamma[L], bnv, bnv + D,
+    RUN(bn_bwd_impl(dyD, D, ws + w.dense, D, N, D, d_params + m->off_bn_gamma[L], bnv, bnv + D,
                     d_grads + m->off_bn_gamma[L], d_grads + m->off_bn_beta[L], dxD, D, 1,
-                    reinterpret_cast<double*>(ws + w.acc), stream));
+                    reinterpret_cast<double*>(ws + w.acc), true, stream));
   } else {
     RUN(gcmi_relu_bwd(dyD, D, ws + w.dense, D, N, D, stream));
     dxD = dyD;
@@ -325,9 +335,9 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
     float* dgc = ws + w.tA;  // grad w.r.t. the GraphConv pre-activation
     if (m->batch_norm) {
       const float* bnv = ws + w.bnv[l];
-      RUN(gcmi_bn_bwd(dy, W, ws + w.gc[l], W, N, W, d_params + m->off_bn_gamma[l], bnv, bnv + W,
+      RUN(bn_bwd_impl(dy, W, ws + w.gc[l], W, N, W, d_params + m->off_bn_gamma[l], bnv, bnv + W,
                       d_grads + m->off_bn_gamma[l], d_grads + m->off_bn_beta[l], full ? dgc : nullptr, W, 1,
-                      reinterpret_cast<double*>(ws + w.acc), stream));
+                      reinterpret_cast<double*>(ws + w.acc), true, stream));
     } else if (full) {
       RUN(gcmi_relu_bwd(dy, W, ws + w.gc[l], W, N, W, stream));
       dgc = dy;
@@ -336,12 +346,11 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
     const Segs sg = make_segs(g, K, W);
     const float* xin = l == 0 ? io->d_atom_features : ws + w.pool[l - 1];
     const int64_t ldx = l == 0 ? io->ld_features : m->conv_width[l - 1];
-    RUN(zero(ws + w.dbsum, sizeof(float) * (size_t)((m->max_deg + 1) * W)));
     RUN(gcmi_seg_gemm_wgrad(sg.n, sg.begin, sg.end, ws + w.S[l], w.ldS[l], K, dgc, W, W,
                             d_grads + m->off_conv_w[l], sg.w_rel, nullptr, nullptr, 0, stream));
     RUN(gcmi_seg_gemm_wgrad(sg.n, sg.begin, sg.end, xin, ldx, K, dgc, W, W, d_grads + m->off_conv_w[l],
-                            sg.w_self, ws + w.dbsum, sg.b_off, 0, stream));
-    hipLaunchKernelGGL(bias_unpack_kernel, dim3(4), dim3(256), 0, st, ws + w.dbsum, m->max_deg, W,
+                            sg.w_self, ws + w.dbsum[l], sg.b_off, 0, stream));
+    hipLaunchKernelGGL(bias_unpack_kernel, dim3(4), dim3(256), 0, st, ws + w.dbsum[l], m->max_deg, W,
                        d_grads + m->off_conv_b[l]);
     GCMI_CHECK_LAUNCH("bias_unpack");
     if (l == 0) break;  // the atom features need no gradient
