@@ -12,4 +12,4 @@ Everything else of DeepChem is out of scope.
 """
 __version__ = "0.1.0"
 
-from deepchem_amd import data, feat, metrics, models, utils  # noqa: E402,F401
+from deepchem_amd import data, feat, metrics, models, trans, utils  # noqa: E402,F401

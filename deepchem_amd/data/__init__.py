@@ -1,2 +1,3 @@
-from deepchem_amd.data.datasets import Dataset, NumpyDataset, pad_batch
-from deepchem_amd.data.packed_dataset import PackedDataset, packed_from_convmols
+from deepchem_amd.data.datasets import Dataset, DiskDataset, NumpyDataset, pad_batch  # noqa: F401
+from deepchem_amd.data.data_loader import CSVLoader, DataLoader  # noqa: F401
+from deepchem_amd.data.packed_dataset import PackedDataset, packed_from_convmols  # noqa: F401

@@ -112,6 +112,46 @@ def packed_from_convmols(X) -> PackedMols:
                       np.concatenate(idx) if idx else np.zeros(0, np.int32))
 
 
+def packed_from_disk(dataset):
+    """A DiskDataset of ConvMol objects as ONE PackedMols (+ labels, weights and the first molecule
+    index of every shard), converted shard by shard once and cached on the dataset object.
+    Returns None when the samples are not ConvMol-like."""
+    from deepchem_amd.utils.synthetic import concat_packed
+    cached = dataset.__dict__.get("_gcmi_packed")
+    if cached is not None and cached[4] == dataset.get_number_shards():
+        return cached[:4]
+    parts, ys, ws, lens = [], [], [], []
+    for X, y, w, _ in dataset.itershards():
+        if len(X) and not (getattr(X, "dtype", None) == object and hasattr(X[0], "get_atom_features")):
+            return None
+        lens.append(len(X))
+        if len(X):
+            parts.append(packed_from_convmols(X))
+            ys.append(y)
+            ws.append(w)
+    if not parts:
+        return None
+    packed = concat_packed(parts)
+    y = None if ys[0] is None else np.concatenate(ys, axis=0)
+    w = None if ws[0] is None else np.concatenate(ws, axis=0)
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    dataset.__dict__["_gcmi_packed"] = (packed, y, w, offsets, dataset.get_number_shards())
+    return packed, y, w, offsets
+
+
+def disk_index_batches(dataset, shard_offsets, batch_size, epochs, deterministic, pad_batches):
+    """``DiskDataset.batch_plan`` as (molecule indices into the packed set, real molecules) per
+    batch, one ``iterbatches`` pass per epoch like ``default_generator`` (graphconvmodel.py:395-398);
+    padding tiles the indices (pad_batch, data/datasets.py:142-218)."""
+    for _ in range(epochs):
+        for shard_of_row, row_in_shard, bs in dataset.batch_plan(None, batch_size, 1, deterministic):
+            idx = shard_offsets[shard_of_row] + row_in_shard
+            n_real = idx.shape[0]
+            if pad_batches and n_real < bs:
+                idx = idx[np.arange(bs) % n_real]
+            yield idx, n_real
+
+
 class DeviceBatchPipeline:
     """Iterate ``(DeviceBatch, labels, weights)`` with collation + H2D running ``depth`` batches
     ahead on a worker thread and its own stream."""

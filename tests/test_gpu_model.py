@@ -389,6 +389,35 @@ def test_packed_dataset_pipeline_equals_python_collation():
     assert a == b
 
 
+def test_disk_dataset_fast_path_equals_python_collation(tmp_path):
+    """fit() on a sharded DiskDataset of ConvMol objects: the native pipeline driven by the
+    reference's shard walk (shuffled shards, carry-over, padded last batch) against the per-batch
+    Python collation of DiskDataset.iterbatches, same np.random state."""
+    from deepchem_amd.data import DiskDataset
+    from deepchem_amd.models.torch_models import GraphConvModel
+    g = load_golden("model_cls_bn.npz")
+    packed = packed_from(g)
+    y, w = g["in_y"], g["in_w"]
+    mols = product_convmols(packed)
+    n = len(mols)
+    cuts = [0, n // 5, n // 5 + 3, (2 * n) // 3, n]
+    shards = [(mols[a:b], y[a:b], w[a:b], np.arange(a, b)) for a, b in zip(cuts[:-1], cuts[1:])]
+    ds = DiskDataset.create_dataset(shards, data_dir=str(tmp_path))
+    assert ds.get_number_shards() == 4 and len(ds) == n
+    outs = []
+    for fast in (False, True):
+        model, cfg, state = build_model(g, "full")
+        model.native_batches = fast
+        losses = []
+        np.random.seed(17)
+        model.fit(ds, nb_epoch=2, deterministic=False, checkpoint_interval=0,
+                  callbacks=[lambda m, s, iteration_loss=None: losses.append(float(iteration_loss))])
+        outs.append((losses, model.predict(ds)))
+    assert len(outs[0][0]) == len(outs[1][0]) > 0
+    assert np.allclose(outs[1][0], outs[0][0], rtol=1e-5, atol=1e-7)
+    assert np.allclose(outs[1][1], outs[0][1], atol=1e-6) and outs[1][1].shape[0] == n
+
+
 def test_pcba_like_head_128_tasks():
     """128 tasks x 2 classes (PCBA shape): head GEMM 256 -> 256, wgrad with 8 x 8 tiles."""
     from deepchem_amd.data import PackedDataset
