@@ -611,6 +611,16 @@ int gcmi_seg_gemm(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_en
   st.tile_start[kMaxSeg] = (int32_t)tiles;
   if (tiles == 0) return GCMI_OK;
   TimedScope ts(GCMI_K_SEG_GEMM, sm);
+  // GCMI_GEMM_V3=1: fp32-accurate product on the bf16 matrix cores (gemm_split.hip).  Measured on
+  // MI355X it is 20-28 % faster than the exact-fp32 MFMA kernels below on cache-warm operands
+  // (tools/kbench.py) and equal to them inside the model, where both are bound by their operand
+  // streams from HBM; the exact-fp32 chain stays the default.
+  static const bool v3 = getenv("GCMI_GEMM_V3") && atoi(getenv("GCMI_GEMM_V3")) == 1;
+  if (v3 && vec4) {
+    const int rc = launch_seg_gemm3(n_seg, seg_begin, seg_end, d_a1, lda1, k1, d_w1, w1_off, d_a2, lda2, k2,
+                                    d_w2, w2_off, d_bias, bias_off, n_out, trans_w, act, d_out, ldo, sm);
+    if (rc != GCMI_ERR_UNSUPPORTED) return rc;
+  }
   if (v2) {
     dim3 grid((unsigned)tiles, (unsigned)((n_out + nt * 32 - 1) / (nt * 32)));
     static const int kc_env = getenv("GCMI_GEMM_KC") ? atoi(getenv("GCMI_GEMM_KC")) : 32;

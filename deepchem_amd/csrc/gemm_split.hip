@@ -1,0 +1,398 @@
+// Row-segmented GEMM with fp32 accuracy on the bf16 matrix cores.
+//
+// The exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, gemm.hip) peaks at ~157 TFLOP/s, which for the
+// shapes of this model (K = 64..152, 64..128 output columns) is the same time as streaming the
+// operands from HBM: the kernel would have to sit at both ceilings at once.  Here every fp32
+// operand is split EXACTLY into three bf16 pieces (x = x1 + x2 + x3: each piece takes the top 8
+// significant bits of what is left, 3 x 8 = the 24 bits of an fp32 significand) and the product
+// is assembled from the six piece products that matter,
+//     a.b ~= a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1        (dropped terms <= 3 * 2^-24 |a||b|,
+//                                                            the size of an fp32 rounding)
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 6 bf16 MFMAs do the work of 8 fp32-MFMA
+// k-steps in 3/8 of the matrix-pipe time, so the kernel is bound by HBM alone.
+//
+// Structure: one workgroup = 128 rows of one segment x NT*32 output columns.
+//   * the segment's weight block(s) are split once per workgroup into LDS, stored [piece][column][k]
+//     (k contiguous, 16-byte padded rows): a lane's B-operand for a k-step is one ds_read_b128;
+//   * A is NOT staged: each lane reads the 8 consecutive floats of its own row that form its
+//     MFMA fragment (2 x 16 bytes) straight from global memory, one k-step ahead, and splits them
+//     in registers;
+//   * operands are swapped in the MFMA so the accumulator holds out^T: lane = atom row, four
+//     consecutive registers = four consecutive output columns -> 16-byte stores.
+#include "common.h"
+
+namespace gcmi {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kS3Block = 256;
+constexpr int kS3Rows = 128;
+constexpr int kS3MaxSeg = 16;
+
+struct SegTable3 {
+  int32_t n_seg;
+  int32_t seg_begin[kS3MaxSeg];
+  int32_t seg_end[kS3MaxSeg];
+  int32_t tile_start[kS3MaxSeg + 1];
+  int64_t w1_off[kS3MaxSeg];  // < 0: term absent
+  int64_t w2_off[kS3MaxSeg];
+  int64_t bias_off[kS3MaxSeg];
+};
+
+template <typename T>
+__device__ __forceinline__ T pick3(const T* a, int s) {
+  T v = a[0];
+#pragma unroll
+  for (int k = 1; k < kS3MaxSeg; ++k) v = (s == k) ? a[k] : v;
+  return v;
+}
+
+// x = p1 + p2 + p3 exactly, each piece a bf16 (the top 16 bits of an fp32 word)
+__device__ __forceinline__ void split3(float x, unsigned& p1, unsigned& p2, unsigned& p3) {
+  p1 = __float_as_uint(x) & 0xFFFF0000u;
+  const float r1 = x - __uint_as_float(p1);
+  p2 = __float_as_uint(r1) & 0xFFFF0000u;
+  const float r2 = r1 - __uint_as_float(p2);
+  p3 = __float_as_uint(r2) & 0xFFFF0000u;
+}
+
+// two pieces (high halves of two fp32 words) -> one dword holding [lo, hi] bf16
+__device__ __forceinline__ unsigned pack_hi(unsigned lo_word, unsigned hi_word) {
+  return (lo_word >> 16) | hi_word;
+}
+
+struct Frag3 {
+  u32x4 p[3];
+};
+
+__device__ __forceinline__ Frag3 split_frag(const float (&v)[8]) {
+  Frag3 f;
+  unsigned a[3][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) split3(v[i], a[0][i], a[1][i], a[2][i]);
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    f.p[s].x = pack_hi(a[s][0], a[s][1]);
+    f.p[s].y = pack_hi(a[s][2], a[s][3]);
+    f.p[s].z = pack_hi(a[s][4], a[s][5]);
+    f.p[s].w = pack_hi(a[s][6], a[s][7]);
+  }
+  return f;
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) {
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// WVEC: the weight blocks are 16-byte addressable along their contiguous dimension.
+template <bool TRANS, int NT, bool WVEC>
+__global__ void __launch_bounds__(kS3Block) __attribute__((amdgpu_waves_per_eu(NT <= 2 ? 3 : 2)))
+seg_gemm3_kernel(SegTable3 st, int n_tiles, const float* __restrict__ a1, int64_t lda1, int k1, int k1p,
+                 const float* __restrict__ w1, const float* __restrict__ a2, int64_t lda2, int k2, int k2p,
+                 const float* __restrict__ w2, const float* __restrict__ bias, int n_out, int act,
+                 float* __restrict__ out, int64_t ldo) {
+  constexpr int NB = NT * 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned short ws[];  // [3][NB][kp] bf16
+  const int col0 = blockIdx.y * NB;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int half = lane >> 5;
+  const int kp = k1p + k2p + 8;  // LDS row length (bf16 elements); + 8: rows start 16 bytes apart mod 128
+  const int ktot = k1p + k2p;
+
+  // this workgroup's contiguous range of 128-row tiles (tiles are ordered by segment, so the
+  // weights in LDS change at most a few times per workgroup)
+  const int t_begin = (int)((int64_t)blockIdx.x * n_tiles / gridDim.x);
+  const int t_end = (int)((int64_t)(blockIdx.x + 1) * n_tiles / gridDim.x);
+  int cur_seg = -1;
+  bool on1 = false, on2 = false;
+  int64_t boff = -1;
+  int seg_first_tile = 0, seg_next_tile = 0, seg_begin = 0, seg_end = 0;  // of the current segment
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    if (cur_seg < 0 || tile >= seg_next_tile) {
+      int s = 0;
+#pragma unroll
+      for (int k = 1; k < kS3MaxSeg; ++k) s += (k < st.n_seg && tile >= st.tile_start[k]) ? 1 : 0;
+      // ---- weights of segment s -> three bf16 images in LDS (zero outside the matrix)
+      if (cur_seg >= 0) __syncthreads();  // everyone is done reading the previous images
+      cur_seg = s;
+      seg_first_tile = pick3(st.tile_start, s);
+      seg_begin = pick3(st.seg_begin, s);
+      seg_end = pick3(st.seg_end, s);
+      seg_next_tile = seg_first_tile + (seg_end - seg_begin + kS3Rows - 1) / kS3Rows;
+      const int64_t woff1 = pick3(st.w1_off, s), woff2 = pick3(st.w2_off, s);
+      on1 = a1 != nullptr && w1 != nullptr && woff1 >= 0;
+      on2 = a2 != nullptr && w2 != nullptr && woff2 >= 0;
+      boff = pick3(st.bias_off, s);
+      if constexpr (WVEC) {
+        // four consecutive elements of the contiguous dimension per thread, 8 loads in flight
+        const int n4 = ktot * NB / 4;
+#pragma unroll 4
+        for (int e = tid; e < n4; e += kS3Block) {
+          int kk, j;
+          if (TRANS) {  // w is n_out x K: the quad runs along k
+            const int q = ktot / 4;
+            j = e / q;
+            kk = (e - j * q) * 4;
+          } else {  // w is K x n_out: the quad runs along the columns
+            const int q = NB / 4;
+            kk = e / q;
+            j = (e - kk * q) * 4;
+          }
+          const bool first = kk < k1p;
+          const int kr = first ? kk : kk - k1p;
+          const int K = first ? k1 : k2;
+          const bool on = first ? on1 : on2;
+          const float* w = first ? w1 + (on ? woff1 : 0) : w2 + (on ? woff2 : 0);
+          float v[4] = {0.f, 0.f, 0.f, 0.f};
+          if (TRANS) {
+            if (on && col0 + j < n_out && kr < K) {  // K % 4 == 0: the quad is inside the row
+              const float4 t4 = *reinterpret_cast<const float4*>(w + (int64_t)(col0 + j) * K + kr);
+              v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              unsigned p1, p2, p3;
+              split3(v[i], p1, p2, p3);
+              ws[(0 * NB + j) * kp + kk + i] = (unsigned short)(p1 >> 16);
+              ws[(1 * NB + j) * kp + kk + i] = (unsigned short)(p2 >> 16);
+              ws[(2 * NB + j) * kp + kk + i] = (unsigned short)(p3 >> 16);
+            }
+          } else {
+            if (on && kr < K && col0 + j < n_out) {  // n_out % 4 == 0: the quad is inside the row
+              const float4 t4 = *reinterpret_cast<const float4*>(w + (int64_t)kr * n_out + col0 + j);
+              v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              unsigned p1, p2, p3;
+              split3(v[i], p1, p2, p3);
+              ws[(0 * NB + j + i) * kp + kk] = (unsigned short)(p1 >> 16);
+              ws[(1 * NB + j + i) * kp + kk] = (unsigned short)(p2 >> 16);
+              ws[(2 * NB + j + i) * kp + kk] = (unsigned short)(p3 >> 16);
+            }
+          }
+        }
+      } else {
+#pragma unroll 2
+        for (int e = tid; e < ktot * NB; e += kS3Block) {
+          int kk, j;
+          if (TRANS) {
+            j = e / ktot;
+            kk = e - j * ktot;
+          } else {
+            kk = e / NB;
+            j = e - kk * NB;
+          }
+          const bool first = kk < k1p;
+          const int kr = first ? kk : kk - k1p;
+          const int K = first ? k1 : k2;
+          const bool on = first ? on1 : on2;
+          float v = 0.f;
+          if (on && kr < K && col0 + j < n_out) {
+            const float* w = first ? w1 + woff1 : w2 + woff2;
+            v = TRANS ? w[(int64_t)(col0 + j) * K + kr] : w[(int64_t)kr * n_out + col0 + j];
+          }
+          unsigned p1, p2, p3;
+          split3(v, p1, p2, p3);
+          ws[(0 * NB + j) * kp + kk] = (unsigned short)(p1 >> 16);
+          ws[(1 * NB + j) * kp + kk] = (unsigned short)(p2 >> 16);
+          ws[(2 * NB + j) * kp + kk] = (unsigned short)(p3 >> 16);
+        }
+      }
+      // the segment's bias row (zeros when absent) behind the weight images
+      float* bias_lds = reinterpret_cast<float*>(ws + (size_t)3 * NB * kp);
+      for (int j = tid; j < NB; j += kS3Block)
+        bias_lds[j] = (bias != nullptr && boff >= 0 && col0 + j < n_out) ? bias[boff + col0 + j] : 0.f;
+      __syncthreads();
+    }
+
+    const int row0 = seg_begin + (tile - seg_first_tile) * kS3Rows;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    const int r = row0 + wave * 32 + (lane & 31);
+    const bool row_ok = r < seg_end;
+    const int64_t rc = row_ok ? r : (seg_end - 1);  // clamped: loads stay in bounds, values are zeroed
+    const int steps1 = on1 ? k1p / 16 : 0;
+    const int steps2 = on2 ? k2p / 16 : 0;
+    const int steps = steps1 + steps2;
+
+    // One k-step (16 columns of one operand) = this lane's 8 consecutive floats.  The loads are
+    // UNCONDITIONAL from clamped, always valid addresses (a guarded load makes hipcc branch around
+    // it and wait vmcnt(0) on the spot, which would serialise the prefetch); what lies outside
+    // the matrix is zeroed by selects when the step is consumed.
+    auto fetch = [&](int step, float4& lo, float4& hi) {
+      const int sc = step < steps ? step : 0;  // an odd step count is padded with a masked step
+      const bool first = sc < steps1;
+      const float* a = first ? a1 : a2;
+      const int64_t lda = first ? lda1 : lda2;
+      const int kk = (first ? sc : sc - steps1) * 16 + 8 * half;
+      const float* row = a + rc * lda;
+      lo = *reinterpret_cast<const float4*>(row + (kk + 4 <= lda ? kk : 0));
+      hi = *reinterpret_cast<const float4*>(row + (kk + 8 <= lda ? kk + 4 : 0));
+    };
+    auto consume = [&](int step, const float4& lo, const float4& hi) {
+      if (step >= steps) return;  // uniform
+      const bool first = step < steps1;
+      const int K = first ? k1 : k2;
+      const int kk = (first ? step : step - steps1) * 16 + 8 * half;
+      float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = (row_ok && kk + i < K) ? v[i] : 0.f;
+      const Frag3 fa = split_frag(v);
+      // LDS column of this step: the second operand's rows follow the first's, whether or not
+      // the first operand is present for this segment
+      const int kl = (first ? step * 16 : k1p + (step - steps1) * 16) + 8 * half;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (t > 0) __builtin_amdgcn_sched_barrier(0);
+        const int j = t * 32 + (lane & 31);
+        const u32x4 b1 = *reinterpret_cast<const u32x4*>(&ws[(0 * NB + j) * kp + kl]);
+        const u32x4 b2 = *reinterpret_cast<const u32x4*>(&ws[(1 * NB + j) * kp + kl]);
+        const u32x4 b3 = *reinterpret_cast<const u32x4*>(&ws[(2 * NB + j) * kp + kl]);
+        // small terms first
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b3), as_bf16x8(fa.p[0]), acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b1), as_bf16x8(fa.p[2]), acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b2), as_bf16x8(fa.p[1]), acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b2), as_bf16x8(fa.p[0]), acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b1), as_bf16x8(fa.p[1]), acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b1), as_bf16x8(fa.p[0]), acc[t], 0, 0, 0);
+      }
+    };
+
+    // k-steps in pairs, the next pair's loads in flight while this pair runs on the matrix pipe
+    float4 l0, h0, l1, h1, m0, g0, m1, g1;
+    fetch(0, l0, h0);
+    fetch(1, l1, h1);
+#pragma unroll 1
+    for (int step = 0; step < steps; step += 2) {
+      fetch(step + 2, m0, g0);
+      fetch(step + 3, m1, g1);
+      __builtin_amdgcn_sched_barrier(0);  // keep the two steps apart: interleaving them doubles
+      consume(step, l0, h0);              // the live fragment registers and spills
+      __builtin_amdgcn_sched_barrier(0);
+      consume(step + 1, l1, h1);
+      __builtin_amdgcn_sched_barrier(0);
+      l0 = m0; h0 = g0; l1 = m1; h1 = g1;
+    }
+
+    // ---- epilogue: bias, activation / accumulate, 16-byte stores (lane = row).  n_out % 4 == 0 and
+    // 16-byte addressable output rows are preconditions of this kernel (checked by the launcher).
+    if (row_ok) {
+      float* orow = out + (int64_t)r * ldo + col0;
+      const float4* bias4 = reinterpret_cast<const float4*>(ws + (size_t)3 * NB * kp);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int cl = t * 32 + 8 * rg + 4 * half;  // columns cl .. cl+3 = registers 4rg .. 4rg+3
+          if (col0 + cl < n_out) {
+            const float4 bq = bias4[cl >> 2];
+            float4 v = make_float4(acc[t][4 * rg] + bq.x, acc[t][4 * rg + 1] + bq.y, acc[t][4 * rg + 2] + bq.z,
+                                   acc[t][4 * rg + 3] + bq.w);
+            if (act == 1) {
+              v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+              v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+            }
+            if (act == 2) {
+              const float4 o = *reinterpret_cast<const float4*>(orow + cl);
+              v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            *reinterpret_cast<float4*>(orow + cl) = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// Host side: returns GCMI_ERR_UNSUPPORTED when this kernel does not cover the shape (the caller
+// falls back to the exact-fp32 MFMA kernels of gemm.hip).
+int launch_seg_gemm3(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_end, const float* d_a1,
+                     int64_t lda1, int32_t k1, const float* d_w1, const int64_t* w1_off, const float* d_a2,
+                     int64_t lda2, int32_t k2, const float* d_w2, const int64_t* w2_off, const float* d_bias,
+                     const int64_t* bias_off, int32_t n_out, int32_t trans_w, int32_t act, float* d_out,
+                     int64_t ldo, hipStream_t sm) {
+  if (n_seg > kS3MaxSeg) return GCMI_ERR_UNSUPPORTED;
+  if ((d_a1 && (!aligned16(d_a1) || lda1 % 4)) || (d_a2 && (!aligned16(d_a2) || lda2 % 4)))
+    return GCMI_ERR_UNSUPPORTED;
+  if (n_out % 4 || ldo % 4 || !aligned16(d_out)) return GCMI_ERR_UNSUPPORTED;  // 16-byte stores only
+  const int k1p = d_a1 ? (k1 + 15) / 16 * 16 : 0;
+  const int k2p = d_a2 ? (k2 + 15) / 16 * 16 : 0;
+  const int kp = k1p + k2p + 8;
+  // widest column group whose three bf16 images fit LDS twice per CU
+  int nt = n_out <= 32 ? 1 : (n_out <= 64 ? 2 : 4);
+  while (nt > 1 && (size_t)3 * nt * 32 * kp * 2 > 72 * 1024) nt /= 2;
+  const size_t shmem = (size_t)3 * nt * 32 * kp * 2 + (size_t)nt * 32 * 4;  // images + bias row
+  if (shmem > 150 * 1024) return GCMI_ERR_UNSUPPORTED;
+  SegTable3 st;
+  memset(&st, 0, sizeof(st));
+  st.n_seg = n_seg;
+  int64_t tiles = 0;
+  for (int s = 0; s < kS3MaxSeg; ++s) {
+    st.tile_start[s] = (int32_t)tiles;
+    if (s < n_seg) {
+      st.seg_begin[s] = seg_begin[s];
+      st.seg_end[s] = seg_end[s];
+      st.w1_off[s] = (d_a1 && w1_off) ? w1_off[s] : -1;
+      st.w2_off[s] = (d_a2 && w2_off) ? w2_off[s] : -1;
+      st.bias_off[s] = (d_bias && bias_off) ? bias_off[s] : -1;
+      tiles += (seg_end[s] - seg_begin[s] + kS3Rows - 1) / kS3Rows;
+    } else {
+      st.w1_off[s] = st.w2_off[s] = st.bias_off[s] = -1;
+    }
+  }
+  st.tile_start[kS3MaxSeg] = (int32_t)tiles;
+  if (tiles == 0) return GCMI_OK;
+  // weights 16-byte addressable along their contiguous dimension?
+  bool wvec = trans_w ? ((d_a1 == nullptr || k1 % 4 == 0) && (d_a2 == nullptr || k2 % 4 == 0)) : (n_out % 4 == 0);
+  for (int s = 0; s < n_seg && wvec; ++s) {
+    if (st.w1_off[s] >= 0 && !aligned16(d_w1 + st.w1_off[s])) wvec = false;
+    if (st.w2_off[s] >= 0 && !aligned16(d_w2 + st.w2_off[s])) wvec = false;
+  }
+  // persistent workgroups over contiguous tile ranges: the weight images are rebuilt only when a
+  // range crosses a segment boundary
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / (shmem + 256)));
+  const int col_groups = (n_out + nt * 32 - 1) / (nt * 32);
+  const int gx = (int)std::min<int64_t>(tiles, std::max(1, 256 * per_cu / col_groups));
+  dim3 grid((unsigned)gx, (unsigned)col_groups);
+  const int n_tiles = (int)tiles;
+#define LAUNCH_S3(TT, NN)                                                                              \
+  do {                                                                                                 \
+    if (wvec) LAUNCH_S3W(TT, NN, true); else LAUNCH_S3W(TT, NN, false);                                \
+  } while (0)
+#define LAUNCH_S3W(TT, NN, WW)                                                                         \
+  do {                                                                                                 \
+    auto kern = seg_gemm3_kernel<TT, NN, WW>;                                                            \
+    static bool attr_done = false;                                                                     \
+    if (!attr_done) {                                                                                  \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                     \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { \
+        (void)hipGetLastError();                                                                       \
+        return GCMI_ERR_UNSUPPORTED;                                                                   \
+      }                                                                                                \
+      attr_done = true;                                                                                \
+    }                                                                                                  \
+    hipLaunchKernelGGL(kern, grid, dim3(kS3Block), shmem, sm, st, n_tiles, d_a1, lda1, k1, k1p, d_w1, d_a2, lda2, k2,  \
+                       k2p, d_w2, d_bias, n_out, act, d_out, ldo);                                     \
+  } while (0)
+  if (trans_w) {
+    if (nt == 1) LAUNCH_S3(true, 1); else if (nt == 2) LAUNCH_S3(true, 2); else LAUNCH_S3(true, 4);
+  } else {
+    if (nt == 1) LAUNCH_S3(false, 1); else if (nt == 2) LAUNCH_S3(false, 2); else LAUNCH_S3(false, 4);
+  }
+#undef LAUNCH_S3
+#undef LAUNCH_S3W
+  GCMI_CHECK_LAUNCH("seg_gemm3");
+  return GCMI_OK;
+}
+
+}  // namespace gcmi
