@@ -130,6 +130,12 @@ _SIGNATURES = {
     "gcmi_loss_fwd_bwd": [c_int32, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P],
     "gcmi_softmax": [_P, c_int64, c_int32, _P, _P],
     "gcmi_adam_step": [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int64, _P],
+    "gcmi_fold_affine": [_P, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P],
+    "gcmi_weave_pair_to_atom": [_P, c_int64, c_int32, _P, c_int32, _P, _P, c_int32, _P, c_int64, _P],
+    "gcmi_weave_pair_features": [_P, _P, c_int64, c_int32, _P, _P, c_int64, c_int32, _P, _P, c_int32, _P,
+                                 c_int64, _P, c_int64, _P],
+    "gcmi_weave_gather": [_P, c_int64, c_int32, _P, c_int32, c_int32, _P, c_int64, _P],
+    "gcmi_tanh_": [_P, c_int64, c_int64, c_int32, _P],
     "gcmi_model_forward": [_MD, _G, _P, _MIO, c_int32, _P],
     "gcmi_model_loss_backward": [_MD, _G, _P, _P, _MIO, _P, _P, c_int64, _I64P, _I64P, _P],
     "gcmi_diag_mfma_peak": [c_int32, c_int32, _P, _P],

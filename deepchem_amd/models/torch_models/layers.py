@@ -168,3 +168,6 @@ class GraphGather(nn.Module):
         if self.activation_fn is not None and not fused_tanh:
             out = self.activation_fn(out)
         return out
+
+
+from deepchem_amd.models.torch_models.weave_layers import WeaveGather, WeaveLayer  # noqa: E402,F401

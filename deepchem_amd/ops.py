@@ -304,6 +304,70 @@ def adam_step_(p, grad, m, v, lr, beta1, beta2, eps, step: int):
               float(beta2), float(eps), int(step), _stream())
 
 
+# ------------------------------------------------------------------ Weave
+def fold_affine(w: torch.Tensor, b: Optional[torch.Tensor], scale: Optional[torch.Tensor],
+                shift: Optional[torch.Tensor], trans_w: bool = False):
+    """(W * diag(scale), b*scale + shift): an eval-mode BatchNorm folded into the preceding product."""
+    w = _mat(w, "w")
+    k, n = (w.shape[1], w.shape[0]) if trans_w else (w.shape[0], w.shape[1])
+    w_out = torch.empty_like(w)
+    b_out = torch.empty(n, dtype=torch.float32, device=w.device)
+    _lib.call("gcmi_fold_affine", _ptr(w), _ptr(_vec(b, "b", n)), _ptr(_vec(scale, "scale", n)),
+              _ptr(_vec(shift, "shift", n)), k, n, 1 if trans_w else 0, _ptr(w_out), _ptr(b_out), _stream())
+    return w_out, b_out
+
+
+def _i32vec(t: torch.Tensor, name: str, n: Optional[int] = None) -> torch.Tensor:
+    if not (torch.is_tensor(t) and t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+        raise _lib.GcmiError("%s must be a contiguous int32 CUDA tensor" % name)
+    if n is not None and t.numel() != n:
+        raise _lib.GcmiError("%s has %d entries, expected %d" % (name, t.numel(), n))
+    return t
+
+
+def weave_pair_to_atom(pair_feat: torch.Tensor, pair_ptr: torch.Tensor, w: torch.Tensor, b: torch.Tensor):
+    """sum over the pairs of every source atom of relu(pair_feat . w + b)."""
+    pf = _mat(pair_feat, "pair_feat")
+    w = _mat(w, "w", rows=pf.shape[1])
+    n_atoms = pair_ptr.numel() - 1
+    H = w.shape[1]
+    out = torch.empty((n_atoms, H), dtype=torch.float32, device=pf.device)
+    _lib.call("gcmi_weave_pair_to_atom", _ptr(pf), _ld(pf), pf.shape[1], _ptr(_i32vec(pair_ptr, "pair_ptr")),
+              n_atoms, _ptr(w), _ptr(_vec(b, "b", H)), H, _ptr(out), _ld(out), _stream())
+    return out
+
+
+def weave_pair_features(u: torch.Tensor, v: torch.Tensor, b_ap, pair_feat: torch.Tensor, w_pp, b_pp,
+                        atom_to_pair: torch.Tensor):
+    """[relu(U[i]+V[j]+b) + relu(U[j]+V[i]+b) | relu(pair_feat . w_pp + b_pp)] per ordered pair."""
+    u, v = _mat(u, "u"), _mat(v, "v", rows=u.shape[0], cols=u.shape[1])
+    if _ld(u) != _ld(v):
+        raise _lib.GcmiError("u and v must share their leading dimension")
+    pf = _mat(pair_feat, "pair_feat")
+    w_pp = _mat(w_pp, "w_pp", rows=pf.shape[1])
+    P, H, H2 = pf.shape[0], u.shape[1], w_pp.shape[1]
+    z = torch.empty((P, H + H2), dtype=torch.float32, device=pf.device)
+    _lib.call("gcmi_weave_pair_features", _ptr(u), _ptr(v), _ld(u), H, _ptr(_vec(b_ap, "b_ap", H)), _ptr(pf), _ld(pf),
+              pf.shape[1], _ptr(w_pp), _ptr(_vec(b_pp, "b_pp", H2)), H2,
+              _ptr(_i32vec(atom_to_pair, "atom_to_pair", 2 * P)), P, _ptr(z), _ld(z), _stream())
+    return z
+
+
+def weave_gather(x: torch.Tensor, mol_ptr: torch.Tensor, gaussian_expand: bool):
+    x = _mat(x, "x")
+    n_mols = mol_ptr.numel() - 1
+    out = torch.empty((n_mols, x.shape[1] * (11 if gaussian_expand else 1)), dtype=torch.float32, device=x.device)
+    _lib.call("gcmi_weave_gather", _ptr(x), _ld(x), x.shape[1], _ptr(_i32vec(mol_ptr, "mol_ptr")), n_mols,
+              1 if gaussian_expand else 0, _ptr(out), _ld(out), _stream())
+    return out
+
+
+def tanh_(x: torch.Tensor) -> torch.Tensor:
+    x = _mat(x, "x")
+    _lib.call("gcmi_tanh_", _ptr(x), _ld(x), x.shape[0], x.shape[1], _stream())
+    return x
+
+
 def timing_enable(kernel_id: int, on: bool = True):
     _lib.call("gcmi_timing_enable", kernel_id, 1 if on else 0)
 

@@ -254,6 +254,40 @@ int gcmi_seg_gemm_wgrad(int32_t n_seg, const int32_t* seg_begin, const int32_t* 
 int gcmi_relu_bwd(float* d_g, int64_t ldg, const float* d_y, int64_t ldy, int64_t n_rows,
                   int32_t n_feat, void* stream);
 
+/* ---------------------------------------------------------------- Weave (pair-feature convolution)
+ * The index-driven parts of WeaveLayer.forward (models/torch_models/layers.py:4327-4429) and
+ * WeaveGather.forward (:4547-4648); the dense products go through gcmi_seg_gemm.  All BatchNorm
+ * layers of this path run in eval mode in the reference (layers.py:4361, :4369, :4390, ...):
+ * gcmi_fold_affine folds them into the neighbouring weights,
+ *     W' = W * diag(scale),  b' = b * scale + shift      (W: k x n row-major, n x k if trans_w)
+ * with scale/shift from gcmi_bn_fold_eval.
+ *
+ * gcmi_weave_pair_to_atom (layers.py:4366-4387): PA = relu(Pf . W + b) summed over the pairs of
+ *   every source atom; pairs are listed source by source (pair_split ascending), d_pair_ptr
+ *   [n_atoms + 1] is the CSR of that listing.  out [n_atoms x n_hidden].
+ * gcmi_weave_pair_features (layers.py:4397-4424): per ordered pair p = (i, j)
+ *     z[p, 0:Hap]       = relu(U[i] + V[j] + b_ap) + relu(U[j] + V[i] + b_ap)
+ *     z[p, Hap:Hap+Hpp] = relu(Pf[p] . W_pp + b_pp)
+ *   where U = A . W_AP[:Fa], V = A . W_AP[Fa:] (n_atoms x Hap, computed per atom by the caller):
+ *   the reference's gathered P x 2Fa matmuls, re-associated.  d_atom_to_pair [n_pairs x 2] int32.
+ * gcmi_weave_gather (layers.py:4566-4648): per molecule (atoms [mol_ptr[m], mol_ptr[m+1])) the sum
+ *   of the atom rows, after the 11-bin Gaussian-histogram expansion when gaussian_expand != 0
+ *   (out [n_mols x 11*n_feat], column f*11 + bin) or of the raw rows (out [n_mols x n_feat]).
+ * gcmi_tanh_: in-place tanh (final_conv_activation_fn of the Weave model).                      */
+int gcmi_fold_affine(const float* d_w, const float* d_b, const float* d_scale, const float* d_shift, int32_t k,
+                     int32_t n, int32_t trans_w, float* d_w_out, float* d_b_out, void* stream);
+int gcmi_weave_pair_to_atom(const float* d_pair_feat, int64_t ldp, int32_t n_pair_feat, const int32_t* d_pair_ptr,
+                            int32_t n_atoms, const float* d_w, const float* d_b, int32_t n_hidden, float* d_out,
+                            int64_t ldo, void* stream);
+int gcmi_weave_pair_features(const float* d_u, const float* d_v, int64_t lduv, int32_t n_hidden_ap,
+                             const float* d_b_ap, const float* d_pair_feat, int64_t ldp, int32_t n_pair_feat,
+                             const float* d_w_pp, const float* d_b_pp, int32_t n_hidden_pp,
+                             const int32_t* d_atom_to_pair, int64_t n_pairs, float* d_z, int64_t ldz,
+                             void* stream);
+int gcmi_weave_gather(const float* d_x, int64_t ldx, int32_t n_feat, const int32_t* d_mol_ptr, int32_t n_mols,
+                      int32_t gaussian_expand, float* d_out, int64_t ldo, void* stream);
+int gcmi_tanh_(float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat, void* stream);
+
 /* ---------------------------------------------------------------- loss
  * SoftmaxCrossEntropy (models/losses.py:251-259) / L2Loss (:85-94) through
  * _StandardLoss (models/torch_models/torch_model.py:1275-1294):
