@@ -115,5 +115,54 @@ def main():
     print("wrote weave_layers.npz with", len(out), "arrays")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--model" not in sys.argv:
     main()
+
+
+def model_fixture():
+    """tests/golden/weave_model.npz: the reference WeaveModel (default seed-22 initialisation) on a
+    seeded set of WeaveMol objects: initial parameters, predictions, per-batch training losses of
+    ``fit_on_batch`` and the parameters afterwards, classification and regression."""
+    dc = import_reference()
+    import torch
+    from deepchem.feat.mol_graphs import WeaveMol
+    from deepchem.models.torch_models import WeaveModel
+    out = {}
+    mols = random_mols(11, n_mols=10, max_atoms=7)
+    rng = np.random.RandomState(4)
+    mols = [((n * 0.5).astype(np.float32), (p * 0.5).astype(np.float32), e) for n, p, e in mols]
+    out["n_mols"] = np.array(len(mols))
+    for i, (n, p, e) in enumerate(mols):
+        out["mol%d_nodes" % i], out["mol%d_pairs" % i], out["mol%d_edges" % i] = n, p, e
+    X = np.empty(len(mols), dtype=object)
+    for i, (n, p, e) in enumerate(mols):
+        X[i] = WeaveMol(n, p, e)
+    for mode in ("classification", "regression"):
+        y = (rng.rand(len(mols), 2) < 0.5).astype(np.float64) if mode == "classification" else rng.standard_normal((len(mols), 2))
+        w = (rng.rand(len(mols), 2) < 0.9).astype(np.float64)
+        out[mode + "_y"], out[mode + "_w"] = y, w
+        model = WeaveModel(2, fully_connected_layer_sizes=[40, 20], batch_size=4, mode=mode, learning_rate=1e-3,
+                           device=torch.device("cpu"))
+        ds = dc.data.NumpyDataset(X, y, w)
+        sd = {k: v.detach().cpu().numpy().copy() for k, v in model.model.state_dict().items()}
+        for k, v in sd.items():
+            out[mode + "_init_" + k] = v
+        for li, layer in enumerate(model.model.layers):
+            for name in ("W_AA", "W_PA", "W_A", "W_AP", "W_PP", "W_P"):
+                if hasattr(layer, name):
+                    out[mode + "_init_layers.%d.%s" % (li, name)] = getattr(layer, name).detach().numpy().copy()
+        out[mode + "_pred0"] = model.predict(ds)
+        losses = []
+        for epoch in range(3):
+            for s in range(0, len(mols), 4):
+                losses.append(model.fit_on_batch(X[s:s + 4], y[s:s + 4], w[s:s + 4]))
+        out[mode + "_losses"] = np.array(losses, np.float64)
+        out[mode + "_pred1"] = model.predict(ds)
+        for k, v in model.model.state_dict().items():
+            out[mode + "_trained_" + k] = v.detach().cpu().numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "weave_model.npz"), **out)
+    print("wrote weave_model.npz with", len(out), "arrays")
+
+
+if __name__ == "__main__" and "--model" in sys.argv:
+    model_fixture()
