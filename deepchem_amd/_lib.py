@@ -136,6 +136,11 @@ _SIGNATURES = {
                                  c_int64, _P, c_int64, _P],
     "gcmi_weave_gather": [_P, c_int64, c_int32, _P, c_int32, c_int32, _P, c_int64, _P],
     "gcmi_tanh_": [_P, c_int64, c_int64, c_int32, _P],
+    "gcmi_edge_network_sum": [_P, c_int64, c_int32, c_int32, _P, c_int64, _P, _P, c_int32, _P, c_int64, _P],
+    "gcmi_gru_gates": [_P, _P, _P, _P, c_int64, _P],
+    "gcmi_gru_out": [_P, _P, _P, _P, c_int64, _P],
+    "gcmi_set2set_attend": [_P, c_int64, c_int32, _P, c_int32, _P, c_int64, _P, c_int64, _P],
+    "gcmi_lstm_cell": [_P, c_int64, c_int32, c_int64, _P, c_int64, _P, c_int64, _P],
     "gcmi_model_forward": [_MD, _G, _P, _MIO, c_int32, _P],
     "gcmi_model_loss_backward": [_MD, _G, _P, _P, _MIO, _P, _P, c_int64, _I64P, _I64P, _P],
     "gcmi_diag_mfma_peak": [c_int32, c_int32, _P, _P],

@@ -1,0 +1,208 @@
+// Message-passing sub-layers: the index-driven / elementwise parts of EdgeNetwork
+// (models/torch_models/layers.py:4006-4088), GatedRecurrentUnit (:2884-2913) and SetGather
+// (set2set, :2976-3138); the dense products go through gcmi_seg_gemm.
+//
+// EdgeNetwork maps every pair's feature vector to a d x d matrix A_p = reshape(Pf[p].W + b) and
+// multiplies it with the hidden state of the pair's second atom: a P x d x d tensor (40 KB per
+// pair at d = 100) in the reference.  Re-associated here:
+//     (A_p . h_j)[r] = sum_k Pf[p,k] * G[j][k*d + r] + G[j][K*d + r],
+//     G[j][k*d + r]  = sum_c W[k][r*d + c] * h_j[c]      (k < K),   G[j][K*d + r] = sum_c b[r*d+c] h_j[c]
+// G is ONE GEMM per message-passing step over the ATOMS (N x d by d x (K+1)d, weights read in place:
+// W viewed as a (K*d) x d matrix is exactly the transposed-layout operand), and the per-pair work
+// drops from K*d*d + d*d to (K+1)*d multiply-adds with no pair-sized intermediate.
+// Bound: L2/HBM gathers of G rows; lanes run along r.
+#include <math.h>
+
+#include "common.h"
+
+namespace gcmi {
+
+constexpr int kMpBlock = 256;
+constexpr int kMaxPairFeat = 32;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// out[i, r] = sum over pairs p of destination i of (sum_k pf[p,k] G[src[p]][k*d + r] + G[src[p]][K*d + r])
+__global__ void __launch_bounds__(kMpBlock)
+edge_network_kernel(const float* __restrict__ g, int64_t ldg, int d, int K, const float* __restrict__ pf, int64_t ldp,
+                    const int32_t* __restrict__ dst_ptr, const int32_t* __restrict__ src, int n_dst,
+                    float* __restrict__ out, int64_t ldo) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * kMpBlock + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * kMpBlock) >> 6;
+  for (int i = wave; i < n_dst; i += n_waves) {
+    const int p0 = dst_ptr[i], p1 = dst_ptr[i + 1];
+    for (int r0 = 0; r0 < d; r0 += 64) {
+      const int r = r0 + lane;
+      float acc = 0.f;
+      if (r < d) {
+        for (int p = p0; p < p1; ++p) {
+          const float* grow = g + (int64_t)src[p] * ldg;
+          const float* prow = pf + (int64_t)p * ldp;  // broadcast loads
+          float m = grow[(int64_t)K * d + r];
+          for (int k = 0; k < K; ++k) m = fmaf(prow[k], grow[(int64_t)k * d + r], m);
+          acc += m;
+        }
+        out[(int64_t)i * ldo + r] = acc;
+      }
+    }
+  }
+}
+
+// z <- sigmoid(z), r <- sigmoid(r), hr = h * r
+__global__ void gru_gates_kernel(float* __restrict__ z, float* __restrict__ r, const float* __restrict__ h,
+                                 float* __restrict__ hr, int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const float zz = sigmoidf_(z[e]), rr = sigmoidf_(r[e]);
+    z[e] = zz;
+    r[e] = rr;
+    hr[e] = h[e] * rr;
+  }
+}
+
+// out = (1 - z) * tanh(hpre) + z * x
+__global__ void gru_out_kernel(const float* __restrict__ z, const float* __restrict__ hpre,
+                               const float* __restrict__ x, float* __restrict__ out, int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    out[e] = (1.f - z[e]) * tanhf(hpre[e]) + z[e] * x[e];
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// set2set attention of one step: per molecule m, e_a = <x_a, h_m>, a = softmax over its atoms,
+// q_star[m] = [h_m | sum_a a x_a].  One wave per molecule at a time, lanes along the features.
+__global__ void __launch_bounds__(kMpBlock)
+set2set_attend_kernel(const float* __restrict__ x, int64_t ldx, int n_feat, const int32_t* __restrict__ mol_ptr,
+                      int n_mols, const float* __restrict__ h, int64_t ldh, float* __restrict__ qstar,
+                      int64_t ldq) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * kMpBlock + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * kMpBlock) >> 6;
+  constexpr int kPer = 8;  // features per lane: n_feat <= 512
+  for (int m = wave; m < n_mols; m += n_waves) {
+    const int a0 = mol_ptr[m], a1 = mol_ptr[m + 1];
+    float hv[kPer], racc[kPer];
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      const int f = lane + 64 * q;
+      hv[q] = f < n_feat ? h[(int64_t)m * ldh + f] : 0.f;
+      racc[q] = 0.f;
+    }
+    float emax = -INFINITY;
+    for (int a = a0; a < a1; ++a) {
+      float part = 0.f;
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) {
+        const int f = lane + 64 * q;
+        if (f < n_feat) part = fmaf(x[(int64_t)a * ldx + f], hv[q], part);
+      }
+      emax = fmaxf(emax, wave_sum(part));
+    }
+    float denom = 0.f;
+    for (int a = a0; a < a1; ++a) {
+      float xv[kPer], part = 0.f;
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) {
+        const int f = lane + 64 * q;
+        xv[q] = f < n_feat ? x[(int64_t)a * ldx + f] : 0.f;
+        part = fmaf(xv[q], hv[q], part);
+      }
+      const float w = expf(wave_sum(part) - emax);
+      denom += w;
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) racc[q] = fmaf(w, xv[q], racc[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      const int f = lane + 64 * q;
+      if (f < n_feat) {
+        qstar[(int64_t)m * ldq + f] = hv[q];
+        qstar[(int64_t)m * ldq + n_feat + f] = a1 > a0 ? racc[q] / denom : 0.f;
+      }
+    }
+  }
+}
+
+// z = [i | f | o | g] pre-activations (B x 4H); c <- sig(f) c + sig(i) tanh(g); h = sig(o) tanh(c)
+__global__ void lstm_cell_kernel(const float* __restrict__ z, int64_t ldz, int n_hidden, int64_t n_rows,
+                                 float* __restrict__ c, int64_t ldc, float* __restrict__ h, int64_t ldh) {
+  const int64_t total = n_rows * n_hidden;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / n_hidden;
+    const int j = (int)(e - r * n_hidden);
+    const float* zr = z + r * ldz;
+    const float i = sigmoidf_(zr[j]), f = sigmoidf_(zr[n_hidden + j]), o = sigmoidf_(zr[2 * n_hidden + j]);
+    const float cn = f * c[r * ldc + j] + i * tanhf(zr[3 * n_hidden + j]);
+    c[r * ldc + j] = cn;
+    h[r * ldh + j] = o * tanhf(cn);
+  }
+}
+
+}  // namespace gcmi
+
+using namespace gcmi;
+
+extern "C" {
+
+int gcmi_edge_network_sum(const float* d_g, int64_t ldg, int32_t n_hidden, int32_t n_pair_feat,
+                          const float* d_pair_feat, int64_t ldp, const int32_t* d_dst_ptr, const int32_t* d_src,
+                          int32_t n_dst, float* d_out, int64_t ldo, void* stream) {
+  GCMI_CHECK_ARG(n_hidden > 0 && n_pair_feat > 0 && n_pair_feat <= kMaxPairFeat && n_dst >= 0 &&
+                     ldg >= (int64_t)(n_pair_feat + 1) * n_hidden && ldp >= n_pair_feat && ldo >= n_hidden,
+                 "edge_network_sum: bad shape");
+  if (n_dst == 0) return GCMI_OK;
+  GCMI_CHECK_ARG(d_g && d_pair_feat && d_dst_ptr && d_src && d_out, "edge_network_sum: NULL buffer");
+  hipLaunchKernelGGL(edge_network_kernel, dim3(grid_for((int64_t)n_dst * 64, kMpBlock)), dim3(kMpBlock), 0,
+                     (hipStream_t)stream, d_g, ldg, n_hidden, n_pair_feat, d_pair_feat, ldp, d_dst_ptr, d_src, n_dst,
+                     d_out, ldo);
+  GCMI_CHECK_LAUNCH("edge_network_sum");
+  return GCMI_OK;
+}
+
+int gcmi_gru_gates(float* d_z, float* d_r, const float* d_h, float* d_hr, int64_t n, void* stream) {
+  GCMI_CHECK_ARG(n >= 0, "gru_gates: bad size");
+  if (n == 0) return GCMI_OK;
+  GCMI_CHECK_ARG(d_z && d_r && d_h && d_hr, "gru_gates: NULL buffer");
+  hipLaunchKernelGGL(gru_gates_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, d_z, d_r, d_h, d_hr, n);
+  GCMI_CHECK_LAUNCH("gru_gates");
+  return GCMI_OK;
+}
+
+int gcmi_gru_out(const float* d_z, const float* d_hpre, const float* d_x, float* d_out, int64_t n, void* stream) {
+  GCMI_CHECK_ARG(n >= 0, "gru_out: bad size");
+  if (n == 0) return GCMI_OK;
+  GCMI_CHECK_ARG(d_z && d_hpre && d_x && d_out, "gru_out: NULL buffer");
+  hipLaunchKernelGGL(gru_out_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, d_z, d_hpre, d_x, d_out, n);
+  GCMI_CHECK_LAUNCH("gru_out");
+  return GCMI_OK;
+}
+
+int gcmi_set2set_attend(const float* d_x, int64_t ldx, int32_t n_feat, const int32_t* d_mol_ptr, int32_t n_mols,
+                        const float* d_h, int64_t ldh, float* d_qstar, int64_t ldq, void* stream) {
+  GCMI_CHECK_ARG(n_feat > 0 && n_feat <= 512 && n_mols >= 0 && ldx >= n_feat && ldh >= n_feat && ldq >= 2 * n_feat,
+                 "set2set_attend: bad shape (n_feat <= 512)");
+  if (n_mols == 0) return GCMI_OK;
+  GCMI_CHECK_ARG(d_x && d_mol_ptr && d_h && d_qstar, "set2set_attend: NULL buffer");
+  hipLaunchKernelGGL(set2set_attend_kernel, dim3(grid_for((int64_t)n_mols * 64, kMpBlock)), dim3(kMpBlock), 0,
+                     (hipStream_t)stream, d_x, ldx, n_feat, d_mol_ptr, n_mols, d_h, ldh, d_qstar, ldq);
+  GCMI_CHECK_LAUNCH("set2set_attend");
+  return GCMI_OK;
+}
+
+int gcmi_lstm_cell(const float* d_z, int64_t ldz, int32_t n_hidden, int64_t n_rows, float* d_c, int64_t ldc,
+                   float* d_h, int64_t ldh, void* stream) {
+  GCMI_CHECK_ARG(n_hidden > 0 && n_rows >= 0 && ldz >= 4 * n_hidden && ldc >= n_hidden && ldh >= n_hidden,
+                 "lstm_cell: bad shape");
+  if (n_rows == 0) return GCMI_OK;
+  GCMI_CHECK_ARG(d_z && d_c && d_h, "lstm_cell: NULL buffer");
+  hipLaunchKernelGGL(lstm_cell_kernel, dim3(grid_for(n_rows * n_hidden, 256)), dim3(256), 0, (hipStream_t)stream, d_z,
+                     ldz, n_hidden, n_rows, d_c, ldc, d_h, ldh);
+  GCMI_CHECK_LAUNCH("lstm_cell");
+  return GCMI_OK;
+}
+
+}  // extern "C"

@@ -171,3 +171,4 @@ class GraphGather(nn.Module):
 
 
 from deepchem_amd.models.torch_models.weave_layers import WeaveGather, WeaveLayer  # noqa: E402,F401
+from deepchem_amd.models.torch_models.mpnn_layers import EdgeNetwork, GatedRecurrentUnit, SetGather  # noqa: E402,F401

@@ -1,0 +1,136 @@
+"""Message-passing sub-layers with the reference's layer contract
+(deepchem/models/torch_models/layers.py: ``EdgeNetwork`` :4006-4088, ``GatedRecurrentUnit``
+:2884-2913, ``SetGather`` :2976-3138), computed by libgcmi.so.  Same constructors, attribute names
+(``W``, ``b``; ``Wz`` ... ``bh``; ``U``, ``b``) and input lists; inputs may be NumPy arrays or tensors.
+
+EdgeNetwork is re-associated (include/gcmi.h, message-passing section): one atom-level GEMM produces
+G = h.[W_k^T ..| B^T], the pair-level work is a (K+1)*d multiply-add gather instead of a d x d
+matrix per pair.
+"""
+from typing import List
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn import init as initializers
+
+from deepchem_amd import ops
+from deepchem_amd.models.torch_models.weave_layers import _csr_from_sorted, _dev_f32, _host_i64
+
+
+def _linear(x, w, b, x2=None, w2=None):
+    n = x.shape[0]
+    return ops.seg_gemm([0], [n], x, w.reshape(-1), [0], x2, None if w2 is None else w2.reshape(-1),
+                        None if w2 is None else [0], b, None if b is None else [0], w.shape[1], False, False, n,
+                        x.shape[1], 0 if x2 is None else x2.shape[1])
+
+
+class EdgeNetwork(nn.Module):
+    """Message function of MPNN: every pair's features select a d x d matrix that multiplies the hidden
+    state of the pair's second atom; messages are summed per first atom."""
+
+    def __init__(self, n_pair_features: int = 8, n_hidden: int = 100, init: str = 'xavier_uniform_', device=None,
+                 **kwargs):
+        super(EdgeNetwork, self).__init__(**kwargs)
+        self.n_pair_features = n_pair_features
+        self.n_hidden = n_hidden
+        self.init = init
+        self.device = torch.device("cuda:0") if device is None else torch.device(device)
+        init_func = getattr(initializers, self.init)
+        self.W = init_func(torch.empty([n_pair_features, n_hidden * n_hidden])).to(self.device)
+        self.b = torch.zeros((n_hidden * n_hidden,), device=self.device)
+        self.built = True
+
+    def __repr__(self) -> str:
+        return (f'{self.__class__.__name__}(n_pair_features:{self.n_pair_features},n_hidden:{self.n_hidden},'
+                f'init:{self.init})')
+
+    def forward(self, inputs: List) -> torch.Tensor:
+        """inputs = [pair_features, atom_features, atom_to_pair] -> (n_atoms_with_pairs, n_hidden)."""
+        pf = _dev_f32(inputs[0], self.device)
+        h = _dev_f32(inputs[1], self.device)
+        a2p = _host_i64(inputs[2]).reshape(-1, 2)
+        d, K = self.n_hidden, self.n_pair_features
+        if pf.shape[1] != K or h.shape[1] != d or a2p.shape[0] != pf.shape[0]:
+            raise ValueError("EdgeNetwork: shapes do not match (pairs %s, atoms %s, atom_to_pair %s)" %
+                             (tuple(pf.shape), tuple(h.shape), a2p.shape))
+        if a2p.size and (a2p.min() < 0 or a2p.max() >= h.shape[0]):
+            raise ValueError("atom_to_pair refers to atoms outside [0, %d)" % h.shape[0])
+        n_dst = int(a2p[:, 0].max()) + 1 if a2p.size else 0
+        dst_ptr = torch.from_numpy(_csr_from_sorted(a2p[:, 0], n_dst, "atom_to_pair[:, 0]")).to(self.device)
+        src = torch.from_numpy(a2p[:, 1].astype(np.int32)).to(self.device)
+        # G = h . [W_0^T | ... | W_{K-1}^T | B^T]: W (K, d*d) read in place as a (K*d, d) nn.Linear-layout matrix
+        W = self.W.detach().to(self.device, torch.float32).contiguous()
+        b = self.b.detach().to(self.device, torch.float32).contiguous()
+        n = h.shape[0]
+        G = torch.empty((n, (K + 1) * d), dtype=torch.float32, device=self.device)
+        G[:, :K * d] = ops.seg_gemm([0], [n], h, W.reshape(-1), [0], None, None, None, None, None, K * d, True, False, n, d, 0)
+        G[:, K * d:] = ops.seg_gemm([0], [n], h, b, [0], None, None, None, None, None, d, True, False, n, d, 0)
+        return ops.edge_network_sum(G, d, pf, dst_ptr, src)
+
+
+class GatedRecurrentUnit(nn.Module):
+    """Update function of MPNN (a GRU whose carry is mixed with the INPUT: ``... + z * x``, as the
+    reference writes it)."""
+
+    def __init__(self, n_hidden: int = 100, init: str = 'xavier_uniform_', device=None, **kwargs):
+        super(GatedRecurrentUnit, self).__init__(**kwargs)
+        self.n_hidden = n_hidden
+        self.init = init
+        self.device = torch.device("cuda:0") if device is None else torch.device(device)
+        init_fn = getattr(initializers, self.init)
+        for name in ("Wz", "Wr", "Wh", "Uz", "Ur", "Uh"):
+            setattr(self, name, init_fn(torch.empty(n_hidden, n_hidden)).to(self.device))
+        for name in ("bz", "br", "bh"):
+            setattr(self, name, torch.zeros((n_hidden,), device=self.device))
+
+    def _p(self, name):
+        return getattr(self, name).detach().to(self.device, torch.float32).contiguous()
+
+    def forward(self, inputs: List) -> torch.Tensor:
+        """inputs = [h_tm1, x] -> h."""
+        h = _dev_f32(inputs[0], self.device).contiguous()
+        x = _dev_f32(inputs[1], self.device).contiguous()
+        z = _linear(x, self._p("Wz"), self._p("bz"), h, self._p("Uz"))
+        r = _linear(x, self._p("Wr"), self._p("br"), h, self._p("Ur"))
+        hr = ops.gru_gates_(z, r, h)
+        hpre = _linear(x, self._p("Wh"), self._p("bh"), hr, self._p("Uh"))
+        return ops.gru_out(z, hpre, x)
+
+
+class SetGather(nn.Module):
+    """set2set readout (Vinyals et al. 2015): M rounds of per-molecule softmax attention over the atom
+    features followed by an LSTM step; returns q_star = [h, r] of the last round."""
+
+    def __init__(self, M: int, batch_size: int, n_hidden: int = 100, init='orthogonal', device=None, **kwargs):
+        super(SetGather, self).__init__(**kwargs)
+        self.M = M
+        self.batch_size = batch_size
+        self.n_hidden = n_hidden
+        self.init = init
+        self.device = torch.device("cuda:0") if device is None else torch.device(device)
+        self.U = nn.Parameter(torch.Tensor(2 * n_hidden, 4 * n_hidden).normal_(mean=0.0, std=0.1))
+        self.b = nn.Parameter(torch.cat((torch.zeros(n_hidden), torch.ones(n_hidden), torch.zeros(n_hidden),
+                                         torch.zeros(n_hidden))))
+        self.built = True
+
+    def __repr__(self) -> str:
+        return f'{self.__class__.__name__}(M={self.M}, batch_size={self.batch_size}, n_hidden={self.n_hidden}, init={self.init})'
+
+    def forward(self, inputs: List) -> torch.Tensor:
+        """inputs = [atom_features, atom_split] -> (batch_size, 2 * n_hidden)."""
+        x = _dev_f32(inputs[0], self.device)
+        split = _host_i64(inputs[1])
+        if x.shape[1] != self.n_hidden or split.shape[0] != x.shape[0]:
+            raise ValueError("SetGather: atom features must be (n_atoms, n_hidden) with one split id per atom")
+        mol_ptr = torch.from_numpy(_csr_from_sorted(split, self.batch_size, "atom_split")).to(self.device)
+        U = self.U.detach().to(self.device, torch.float32).contiguous()
+        b = self.b.detach().to(self.device, torch.float32).contiguous()
+        c = torch.zeros((self.batch_size, self.n_hidden), device=self.device)
+        h = torch.zeros((self.batch_size, self.n_hidden), device=self.device)
+        q_star = None
+        for _ in range(self.M):
+            q_star = ops.set2set_attend(x, mol_ptr, h)
+            z = _linear(q_star, U, b)
+            h = ops.lstm_cell_(z, c)
+        return q_star

@@ -368,6 +368,59 @@ def tanh_(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+# ------------------------------------------------------------------ message passing
+def edge_network_sum(g: torch.Tensor, n_hidden: int, pair_feat: torch.Tensor, dst_ptr: torch.Tensor,
+                     src: torch.Tensor) -> torch.Tensor:
+    g = _mat(g, "g")
+    pf = _mat(pair_feat, "pair_feat")
+    K = pf.shape[1]
+    if g.shape[1] != (K + 1) * n_hidden:
+        raise ValueError("g must have (n_pair_feat + 1) * n_hidden columns")
+    n_dst = dst_ptr.numel() - 1
+    out = torch.empty((n_dst, n_hidden), dtype=torch.float32, device=g.device)
+    _lib.call("gcmi_edge_network_sum", _ptr(g), _ld(g), n_hidden, K, _ptr(pf), _ld(pf),
+              _ptr(_i32vec(dst_ptr, "dst_ptr")), _ptr(_i32vec(src, "src", pf.shape[0])), n_dst, _ptr(out), _ld(out),
+              _stream())
+    return out
+
+
+def gru_gates_(z: torch.Tensor, r: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
+    for t, nm in ((z, "z"), (r, "r"), (h, "h")):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.shape == z.shape):
+            raise ValueError("%s must be a contiguous float32 CUDA tensor of the gate shape" % nm)
+    hr = torch.empty_like(h)
+    _lib.call("gcmi_gru_gates", _ptr(z), _ptr(r), _ptr(h), _ptr(hr), z.numel(), _stream())
+    return hr
+
+
+def gru_out(z: torch.Tensor, hpre: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    for t, nm in ((z, "z"), (hpre, "hpre"), (x, "x")):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.shape == z.shape):
+            raise ValueError("%s must be a contiguous float32 CUDA tensor of the gate shape" % nm)
+    out = torch.empty_like(x)
+    _lib.call("gcmi_gru_out", _ptr(z), _ptr(hpre), _ptr(x), _ptr(out), z.numel(), _stream())
+    return out
+
+
+def set2set_attend(x: torch.Tensor, mol_ptr: torch.Tensor, h: torch.Tensor) -> torch.Tensor:
+    x = _mat(x, "x")
+    n_mols = mol_ptr.numel() - 1
+    h = _mat(h, "h", rows=n_mols, cols=x.shape[1])
+    q = torch.empty((n_mols, 2 * x.shape[1]), dtype=torch.float32, device=x.device)
+    _lib.call("gcmi_set2set_attend", _ptr(x), _ld(x), x.shape[1], _ptr(_i32vec(mol_ptr, "mol_ptr")), n_mols, _ptr(h),
+              _ld(h), _ptr(q), _ld(q), _stream())
+    return q
+
+
+def lstm_cell_(z: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
+    z = _mat(z, "z")
+    H = z.shape[1] // 4
+    c = _mat(c, "c", rows=z.shape[0], cols=H)
+    h = torch.empty_like(c)
+    _lib.call("gcmi_lstm_cell", _ptr(z), _ld(z), H, z.shape[0], _ptr(c), _ld(c), _ptr(h), _ld(h), _stream())
+    return h
+
+
 def timing_enable(kernel_id: int, on: bool = True):
     _lib.call("gcmi_timing_enable", kernel_id, 1 if on else 0)
 

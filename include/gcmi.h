@@ -288,6 +288,27 @@ int gcmi_weave_gather(const float* d_x, int64_t ldx, int32_t n_feat, const int32
                       int32_t gaussian_expand, float* d_out, int64_t ldo, void* stream);
 int gcmi_tanh_(float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat, void* stream);
 
+/* ---------------------------------------------------------------- message passing (MPNN sub-layers)
+ * gcmi_edge_network_sum: EdgeNetwork.forward (models/torch_models/layers.py:4060-4088) after the
+ *   re-association  (reshape(Pf[p].W + b) . h_j)[r] = sum_k Pf[p,k] G[j][k*d+r] + G[j][K*d+r]  with
+ *   G = h . [W_0^T | ... | W_{K-1}^T | B^T]  (N x (K+1)d, one gcmi_seg_gemm over the atoms, W read in
+ *   place as a (K*d) x d matrix in transposed layout):  out[i] = sum over the pairs p whose first
+ *   atom is i (pairs sorted by it; d_dst_ptr [n_dst+1] is that CSR) of the message from d_src[p].
+ * gcmi_gru_gates / gcmi_gru_out: the elementwise parts of GatedRecurrentUnit.forward (:2903-2913):
+ *   z <- sigmoid(z), r <- sigmoid(r), hr = h*r;   out = (1-z) tanh(hpre) + z x   (contiguous, n floats).
+ * gcmi_set2set_attend: one attention step of SetGather.forward (:3047-3064): per molecule
+ *   e_a = <x_a, h_m>, a = softmax over its atoms, q_star[m] = [h_m | sum_a a_a x_a].
+ * gcmi_lstm_cell: SetGather._LSTMStep (:3066-3092) after z = q_star.U + b: gate order i, f, o, g.  */
+int gcmi_edge_network_sum(const float* d_g, int64_t ldg, int32_t n_hidden, int32_t n_pair_feat,
+                          const float* d_pair_feat, int64_t ldp, const int32_t* d_dst_ptr, const int32_t* d_src,
+                          int32_t n_dst, float* d_out, int64_t ldo, void* stream);
+int gcmi_gru_gates(float* d_z, float* d_r, const float* d_h, float* d_hr, int64_t n, void* stream);
+int gcmi_gru_out(const float* d_z, const float* d_hpre, const float* d_x, float* d_out, int64_t n, void* stream);
+int gcmi_set2set_attend(const float* d_x, int64_t ldx, int32_t n_feat, const int32_t* d_mol_ptr, int32_t n_mols,
+                        const float* d_h, int64_t ldh, float* d_qstar, int64_t ldq, void* stream);
+int gcmi_lstm_cell(const float* d_z, int64_t ldz, int32_t n_hidden, int64_t n_rows, float* d_c, int64_t ldc,
+                   float* d_h, int64_t ldh, void* stream);
+
 /* ---------------------------------------------------------------- loss
  * SoftmaxCrossEntropy (models/losses.py:251-259) / L2Loss (:85-94) through
  * _StandardLoss (models/torch_models/torch_model.py:1275-1294):
