@@ -22,13 +22,43 @@ constexpr int kReplicas = 32;  // accumulator replicas: same-address fp64 atomic
 // of 2F partial sums.  The kernels that consume the partial sums zero them again, so a scratch
 // that starts clean stays clean (the whole-model path zeroes it once per pass).
 
+// The gradient w.r.t. the readout input, recomputed instead of read (GraphGather backward fused
+// into the BatchNorm backward that consumes it): with g2[m] = [dsum | dmax] of molecule m (tanh
+// derivative already applied) and arg[m,f] = row of the first maximum,
+//   dy[r, f] = g2[mol(r)][f] + (arg[mol(r)][f] == r) * g2[mol(r)][F + f].
+struct ReadoutGrad {
+  const int32_t* membership;  // N
+  const float* g2;            // n_mols x ldg2 (>= 2F)
+  int64_t ldg2;
+  const int32_t* arg;         // n_mols x F
+};
+
+template <int V>
+__device__ __forceinline__ void readout_dy(const ReadoutGrad& rg, int64_t r, int c, int n_feat, float (&dy)[V]) {
+  const int m = rg.membership[r];
+  const float* grow = rg.g2 + (int64_t)m * rg.ldg2;
+  const int32_t* arow = rg.arg + (int64_t)m * n_feat;
+  if constexpr (V == 4) {
+    const float4 s4 = *reinterpret_cast<const float4*>(grow + c);
+    const float4 m4 = *reinterpret_cast<const float4*>(grow + n_feat + c);
+    const int4 a4 = *reinterpret_cast<const int4*>(arow + c);
+    dy[0] = s4.x + (a4.x == r ? m4.x : 0.f);
+    dy[1] = s4.y + (a4.y == r ? m4.y : 0.f);
+    dy[2] = s4.z + (a4.z == r ? m4.z : 0.f);
+    dy[3] = s4.w + (a4.w == r ? m4.w : 0.f);
+  } else {
+    dy[0] = grow[c] + (arow[c] == r ? grow[n_feat + c] : 0.f);
+  }
+}
+
 // sums[0:F] += sum_r a[r,:],  sums[F:2F] += sum_r a[r,:]*b[r,:]
 // MODE 0: b = a (sum of squares).  MODE 1: b = (x - mean)*invstd (x given), a = dy.
+// MODE 2: as MODE 1 with dy recomputed from the readout gradient (rg) instead of read from a.
 template <int V, int MODE>
 __global__ void __launch_bounds__(kBBlock)
 col_sums_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ x, int64_t ldx,
                 const float* __restrict__ mean, const float* __restrict__ invstd, int64_t n_rows,
-                int n_feat, int lpr, int lx, double* __restrict__ sums) {
+                int n_feat, int lpr, int lx, double* __restrict__ sums, ReadoutGrad rg) {
   __shared__ double red[2 * kBBlock * 4];
   const int ry = kBBlock / lx;  // row lanes
   const int ty = threadIdx.x / lx;
@@ -45,22 +75,25 @@ col_sums_kernel(const float* __restrict__ a, int64_t lda, const float* __restric
     for (int q = 0; q < V; ++q) {
       s1[q] = 0.0;
       s2[q] = 0.0;
-      mu[q] = MODE == 1 ? mean[c + q] : 0.f;
-      is[q] = MODE == 1 ? invstd[c + q] : 0.f;
+      mu[q] = MODE >= 1 ? mean[c + q] : 0.f;
+      is[q] = MODE >= 1 ? invstd[c + q] : 0.f;
     }
     if (active) {
       for (int64_t r = r_begin + ty; r < r_end; r += ry) {
         float av[V], xv[V];
+        if constexpr (MODE == 2) readout_dy<V>(rg, r, c, n_feat, av);
         if constexpr (V == 4) {
-          const float4 t4 = *reinterpret_cast<const float4*>(a + r * lda + c);
-          av[0] = t4.x; av[1] = t4.y; av[2] = t4.z; av[3] = t4.w;
-          if (MODE == 1) {
+          if (MODE != 2) {
+            const float4 t4 = *reinterpret_cast<const float4*>(a + r * lda + c);
+            av[0] = t4.x; av[1] = t4.y; av[2] = t4.z; av[3] = t4.w;
+          }
+          if (MODE >= 1) {
             const float4 u4 = *reinterpret_cast<const float4*>(x + r * ldx + c);
             xv[0] = u4.x; xv[1] = u4.y; xv[2] = u4.z; xv[3] = u4.w;
           }
         } else {
-          av[0] = a[r * lda + c];
-          if (MODE == 1) xv[0] = x[r * ldx + c];
+          if (MODE != 2) av[0] = a[r * lda + c];
+          if (MODE >= 1) xv[0] = x[r * ldx + c];
         }
 #pragma unroll
         for (int q = 0; q < V; ++q) {
@@ -201,11 +234,11 @@ __global__ void bn_bwd_params_kernel(double* __restrict__ sums, int64_t n_rows, 
 
 constexpr int kDxRows = 256;  // rows per workgroup
 
-template <int V, bool RELU>
+template <int V, bool RELU, bool RD>
 __global__ void __launch_bounds__(kBBlock)
 bn_bwd_dx_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
                  int64_t ldx, int64_t n_rows, int n_feat, int lpr, int lx,
-                 const float* __restrict__ coef, float* __restrict__ dx, int64_t lddx) {
+                 const float* __restrict__ coef, float* __restrict__ dx, int64_t lddx, ReadoutGrad rg) {
   const int ry = kBBlock / lx;
   const int ty = threadIdx.x / lx;
   const int tx = threadIdx.x - ty * lx;
@@ -223,14 +256,17 @@ bn_bwd_dx_kernel(const float* __restrict__ dy, int64_t lddy, const float* __rest
     }
     for (int64_t r = r_begin + ty; r < r_end; r += ry) {
       float xv[V], gv[V], o[V];
+      if constexpr (RD) readout_dy<V>(rg, r, c, n_feat, gv);
       if constexpr (V == 4) {
         const float4 a4 = *reinterpret_cast<const float4*>(x + r * ldx + c);
-        const float4 b4 = *reinterpret_cast<const float4*>(dy + r * lddy + c);
         xv[0] = a4.x; xv[1] = a4.y; xv[2] = a4.z; xv[3] = a4.w;
-        gv[0] = b4.x; gv[1] = b4.y; gv[2] = b4.z; gv[3] = b4.w;
+        if (!RD) {
+          const float4 b4 = *reinterpret_cast<const float4*>(dy + r * lddy + c);
+          gv[0] = b4.x; gv[1] = b4.y; gv[2] = b4.z; gv[3] = b4.w;
+        }
       } else {
         xv[0] = x[r * ldx + c];
-        gv[0] = dy[r * lddy + c];
+        if (!RD) gv[0] = dy[r * lddy + c];
       }
 #pragma unroll
       for (int q = 0; q < V; ++q) {
@@ -248,25 +284,33 @@ bn_bwd_dx_kernel(const float* __restrict__ dy, int64_t lddy, const float* __rest
 
 static int launch_col_sums(int mode, const float* a, int64_t lda, const float* x, int64_t ldx,
                            const float* mean, const float* invstd, int64_t n_rows, int n_feat,
-                           double* sums, bool acc_clean, hipStream_t st) {
+                           double* sums, bool acc_clean, hipStream_t st, const ReadoutGrad* rgp = nullptr) {
   if (!acc_clean &&
       hipMemsetAsync(sums, 0, sizeof(double) * 2 * n_feat * (1 + kReplicas), st) != hipSuccess) {
     set_error("bn: memset failed");
     return GCMI_ERR_LAUNCH;
   }
   if (n_rows == 0) return GCMI_OK;
-  int V = vec_width(a, lda, n_feat);
-  if (mode == 1 && vec_width(x, ldx, n_feat) != 4) V = 1;
+  ReadoutGrad rg{nullptr, nullptr, 0, nullptr};
+  int V;
+  if (rgp) {
+    rg = *rgp;
+    mode = 2;
+    V = (vec_width(x, ldx, n_feat) == 4 && aligned16(rg.g2) && rg.ldg2 % 4 == 0 && aligned16(rg.arg)) ? 4 : 1;
+  } else {
+    V = vec_width(a, lda, n_feat);
+    if (mode == 1 && vec_width(x, ldx, n_feat) != 4) V = 1;
+  }
   const int lpr = n_feat / V;
   const int lx = lpr < kBBlock ? lpr : kBBlock;
   const int blocks = (int)((n_rows + kRowsPerBlock - 1) / kRowsPerBlock);
 #define LAUNCH_CS(VV, MM)                                                                     \
   hipLaunchKernelGGL((col_sums_kernel<VV, MM>), dim3(blocks), dim3(kBBlock), 0, st, a, lda, x, \
-                     ldx, mean, invstd, n_rows, n_feat, lpr, lx, sums)
+                     ldx, mean, invstd, n_rows, n_feat, lpr, lx, sums, rg)
   if (V == 4) {
-    if (mode == 0) LAUNCH_CS(4, 0); else LAUNCH_CS(4, 1);
+    if (mode == 0) LAUNCH_CS(4, 0); else if (mode == 1) LAUNCH_CS(4, 1); else LAUNCH_CS(4, 2);
   } else {
-    if (mode == 0) LAUNCH_CS(1, 0); else LAUNCH_CS(1, 1);
+    if (mode == 0) LAUNCH_CS(1, 0); else if (mode == 1) LAUNCH_CS(1, 1); else LAUNCH_CS(1, 2);
   }
 #undef LAUNCH_CS
   GCMI_CHECK_LAUNCH("bn col_sums");
@@ -356,15 +400,40 @@ int gcmi_bn_bwd(const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx, 
 
 namespace gcmi {
 
+static int bn_bwd_any(const ReadoutGrad* rgp, const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx,
+                      int64_t n_rows, int32_t n_feat, const float* d_gamma, const float* d_mean,
+                      const float* d_invstd, float* d_dgamma, float* d_dbeta, float* d_dx, int64_t lddx,
+                      int32_t relu_mask, double* d_acc, bool acc_clean, void* stream);
+
 int bn_bwd_impl(const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx, int64_t n_rows,
                 int32_t n_feat, const float* d_gamma, const float* d_mean,
                 const float* d_invstd, float* d_dgamma, float* d_dbeta, float* d_dx,
                 int64_t lddx, int32_t relu_mask, double* d_acc, bool acc_clean, void* stream) {
-  GCMI_CHECK_ARG(n_feat > 0 && n_rows > 0 && lddy >= n_feat && ldx >= n_feat, "bn_bwd: bad shape");
-  GCMI_CHECK_ARG(d_dy && d_x && d_mean && d_invstd && d_acc, "bn_bwd: NULL buffer");
+  GCMI_CHECK_ARG(lddy >= n_feat && d_dy, "bn_bwd: bad dy");
+  return bn_bwd_any(nullptr, d_dy, lddy, d_x, ldx, n_rows, n_feat, d_gamma, d_mean, d_invstd, d_dgamma, d_dbeta,
+                    d_dx, lddx, relu_mask, d_acc, acc_clean, stream);
+}
+
+// BatchNorm backward whose incoming gradient is the GraphGather backward, recomputed on the fly
+int bn_bwd_readout_impl(const int32_t* d_membership, const float* d_g2, int64_t ldg2, const int32_t* d_arg,
+                        const float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat, const float* d_gamma,
+                        const float* d_mean, const float* d_invstd, float* d_dgamma, float* d_dbeta, float* d_dx,
+                        int64_t lddx, int32_t relu_mask, double* d_acc, bool acc_clean, void* stream) {
+  GCMI_CHECK_ARG(d_membership && d_g2 && d_arg && ldg2 >= 2 * (int64_t)n_feat, "bn_bwd_readout: bad readout gradient");
+  const ReadoutGrad rg{d_membership, d_g2, ldg2, d_arg};
+  return bn_bwd_any(&rg, nullptr, 0, d_x, ldx, n_rows, n_feat, d_gamma, d_mean, d_invstd, d_dgamma, d_dbeta, d_dx,
+                    lddx, relu_mask, d_acc, acc_clean, stream);
+}
+
+static int bn_bwd_any(const ReadoutGrad* rgp, const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx,
+                      int64_t n_rows, int32_t n_feat, const float* d_gamma, const float* d_mean,
+                      const float* d_invstd, float* d_dgamma, float* d_dbeta, float* d_dx, int64_t lddx,
+                      int32_t relu_mask, double* d_acc, bool acc_clean, void* stream) {
+  GCMI_CHECK_ARG(n_feat > 0 && n_rows > 0 && ldx >= n_feat, "bn_bwd: bad shape");
+  GCMI_CHECK_ARG(d_x && d_mean && d_invstd && d_acc, "bn_bwd: NULL buffer");
   GCMI_CHECK_ARG(d_dx == nullptr || lddx >= n_feat, "bn_bwd: bad lddx");
   hipStream_t st = (hipStream_t)stream;
-  int rc = launch_col_sums(1, d_dy, lddy, d_x, ldx, d_mean, d_invstd, n_rows, n_feat, d_acc, acc_clean, st);
+  int rc = launch_col_sums(1, d_dy, lddy, d_x, ldx, d_mean, d_invstd, n_rows, n_feat, d_acc, acc_clean, st, rgp);
   if (rc) return rc;
   // coefficient vectors (3F floats) live in the first 2F doubles of the scratch
   float* coef = reinterpret_cast<float*>(d_acc);
@@ -372,21 +441,25 @@ int bn_bwd_impl(const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx, 
                      n_feat, d_gamma, d_mean, d_invstd, d_dgamma, d_dbeta, coef);
   GCMI_CHECK_LAUNCH("bn_bwd_params");
   if (d_dx) {
-    const int V = (vec_width(d_dx, lddx, n_feat) == 4 && vec_width(d_dy, lddy, n_feat) == 4 &&
-                   vec_width(d_x, ldx, n_feat) == 4)
-                      ? 4
-                      : 1;
+    ReadoutGrad rg{nullptr, nullptr, 0, nullptr};
+    if (rgp) rg = *rgp;
+    const bool src_ok = rgp ? (aligned16(rg.g2) && rg.ldg2 % 4 == 0 && aligned16(rg.arg))
+                            : vec_width(d_dy, lddy, n_feat) == 4;
+    const int V = (vec_width(d_dx, lddx, n_feat) == 4 && src_ok && vec_width(d_x, ldx, n_feat) == 4) ? 4 : 1;
     const int lpr = n_feat / V;
     const int lx = lpr < kBBlock ? lpr : kBBlock;
     const int blocks = (int)((n_rows + kDxRows - 1) / kDxRows);
-#define LAUNCH_DX(VV, RR)                                                                     \
-  hipLaunchKernelGGL((bn_bwd_dx_kernel<VV, RR>), dim3(blocks), dim3(kBBlock), 0, st, d_dy, lddy, \
-                     d_x, ldx, n_rows, n_feat, lpr, lx, coef, d_dx, lddx)
+#define LAUNCH_DX(VV, RR, DD)                                                                     \
+  hipLaunchKernelGGL((bn_bwd_dx_kernel<VV, RR, DD>), dim3(blocks), dim3(kBBlock), 0, st, d_dy, lddy, \
+                     d_x, ldx, n_rows, n_feat, lpr, lx, coef, d_dx, lddx, rg)
+#define LAUNCH_DX_R(VV, RR) \
+  do { if (rgp) LAUNCH_DX(VV, RR, true); else LAUNCH_DX(VV, RR, false); } while (0)
     if (V == 4) {
-      if (relu_mask) LAUNCH_DX(4, true); else LAUNCH_DX(4, false);
+      if (relu_mask) LAUNCH_DX_R(4, true); else LAUNCH_DX_R(4, false);
     } else {
-      if (relu_mask) LAUNCH_DX(1, true); else LAUNCH_DX(1, false);
+      if (relu_mask) LAUNCH_DX_R(1, true); else LAUNCH_DX_R(1, false);
     }
+#undef LAUNCH_DX_R
 #undef LAUNCH_DX
     GCMI_CHECK_LAUNCH("bn_bwd_dx");
   }

@@ -89,6 +89,12 @@ int bn_bwd_impl(const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx, 
                 int32_t n_feat, const float* d_gamma, const float* d_mean, const float* d_invstd,
                 float* d_dgamma, float* d_dbeta, float* d_dx, int64_t lddx, int32_t relu_mask,
                 double* d_acc, bool acc_clean, void* stream);
+int bn_bwd_readout_impl(const int32_t* d_membership, const float* d_g2, int64_t ldg2, const int32_t* d_arg,
+                        const float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat, const float* d_gamma,
+                        const float* d_mean, const float* d_invstd, float* d_dgamma, float* d_dbeta, float* d_dx,
+                        int64_t lddx, int32_t relu_mask, double* d_acc, bool acc_clean, void* stream);
+int readout_grad_prep(float* d_g, int64_t ldg, const float* d_out, int64_t ldo, int64_t n_mols, int n_feat,
+                      hipStream_t st);
 int loss_impl(int32_t kind, const float* d_logits, const float* d_labels, const float* d_weights,
               int64_t n_rows, int32_t n_tasks, int32_t n_classes, float* d_loss, float* d_dlogits,
               float* d_probs, double* d_acc, bool acc_clean, void* stream);

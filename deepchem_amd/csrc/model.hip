@@ -306,14 +306,18 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
   // ---- readout (+ folded BatchNorm of the dense layer, + its ReLU mask)
   float* dyD = ws + w.tA;   // grad w.r.t. the (normalised) readout input
   float* dxD = ws + w.tB;   // grad w.r.t. the dense pre-activation
-  RUN(gcmi_readout_bwd(g, ws + w.dfp, 2 * D, io->d_fingerprint, 2 * D, D, 1,
-                       reinterpret_cast<const int32_t*>(ws + w.arg_r), dyD, D, stream));
   if (m->batch_norm) {
+    // GraphGather backward is recomputed inside the BatchNorm backward from the per-molecule
+    // gradient (tanh derivative applied in place): the N x D gradient is never written or re-read
+    RUN(readout_grad_prep(ws + w.dfp, 2 * D, io->d_fingerprint, 2 * D, B, D, st));
     const float* bnv = ws + w.bnv[L];
-    RUN(bn_bwd_impl(dyD, D, ws + w.dense, D, N, D, d_params + m->off_bn_gamma[L], bnv, bnv + D,
-                    d_grads + m->off_bn_gamma[L], d_grads + m->off_bn_beta[L], dxD, D, 1,
-                    reinterpret_cast<double*>(ws + w.acc), true, stream));
+    RUN(bn_bwd_readout_impl(g->d_membership, ws + w.dfp, 2 * D, reinterpret_cast<const int32_t*>(ws + w.arg_r),
+                            ws + w.dense, D, N, D, d_params + m->off_bn_gamma[L], bnv, bnv + D,
+                            d_grads + m->off_bn_gamma[L], d_grads + m->off_bn_beta[L], dxD, D, 1,
+                            reinterpret_cast<double*>(ws + w.acc), true, stream));
   } else {
+    RUN(gcmi_readout_bwd(g, ws + w.dfp, 2 * D, io->d_fingerprint, 2 * D, D, 1,
+                         reinterpret_cast<const int32_t*>(ws + w.arg_r), dyD, D, stream));
     RUN(gcmi_relu_bwd(dyD, D, ws + w.dense, D, N, D, stream));
     dxD = dyD;
   }

@@ -155,6 +155,28 @@ readout_bwd_kernel(int64_t slots, int lpr, int n_feat, const int32_t* __restrict
   }
 }
 
+// g[b, :] *= 1 - out[b, :]^2 over the 2F columns of every molecule (tanh derivative of the readout),
+// in place: the per-molecule gradient the fused BatchNorm backward gathers from
+__global__ void readout_grad_prep_kernel(float* __restrict__ g, int64_t ldg, const float* __restrict__ out,
+                                         int64_t ldo, int64_t n_mols, int n2) {
+  const int64_t total = n_mols * n2;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = e / n2;
+    const int c = (int)(e - b * n2);
+    const float o = out[b * ldo + c];
+    g[b * ldg + c] *= (1.f - o * o);
+  }
+}
+
+int readout_grad_prep(float* d_g, int64_t ldg, const float* d_out, int64_t ldo, int64_t n_mols, int n_feat,
+                      hipStream_t st) {
+  if (n_mols == 0) return GCMI_OK;
+  hipLaunchKernelGGL(readout_grad_prep_kernel, dim3(grid_for(n_mols * 2 * n_feat, 256)), dim3(256), 0, st, d_g, ldg,
+                     d_out, ldo, n_mols, 2 * n_feat);
+  GCMI_CHECK_LAUNCH("readout_grad_prep");
+  return GCMI_OK;
+}
+
 }  // namespace gcmi
 
 using namespace gcmi;
