@@ -71,6 +71,20 @@ int win_gather_max(const gcmi_graph* g, const float* d_x, int64_t ldx, int n_fea
 int win_gather_max_bwd(const gcmi_graph* g, const float* d_dout, int64_t lddo, int n_feat,
                        const uint8_t* d_arg, float* d_dx, int64_t lddx, hipStream_t st);
 
+// row slabs of the weight-gradient kernels (gemm.hip, gemm_split.hip)
+constexpr int kMaxSegW = 16;
+struct SlabTable {
+  int32_t n_seg;
+  int32_t slab_rows;
+  int32_t seg_begin[kMaxSegW];
+  int32_t seg_end[kMaxSegW];
+  int32_t slab_start[kMaxSegW + 1];
+  int64_t dw_off[kMaxSegW];
+  int64_t db_off[kMaxSegW];
+};
+int launch_wgrad3(const SlabTable& st, int slabs, const float* d_a, int64_t lda, int k, const float* d_g, int64_t ldg,
+                  int n, float* d_dw, float* d_dbias, int trans_w, hipStream_t sm);
+
 // gemm_split.hip: the segmented GEMM on the bf16 matrix cores with exactly split fp32 operands;
 // GCMI_ERR_UNSUPPORTED = shape not covered (fall back to gemm.hip)
 int launch_seg_gemm3(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_end, const float* d_a1,

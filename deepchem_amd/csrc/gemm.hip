@@ -392,16 +392,6 @@ seg_gemm2_kernel(SegTable st, const float* __restrict__ a1, int64_t lda1, int k1
 }
 
 // ------------------------------------------------------------------ wgrad
-struct SlabTable {
-  int32_t n_seg;
-  int32_t slab_rows;
-  int32_t seg_begin[kMaxSeg];
-  int32_t seg_end[kMaxSeg];
-  int32_t slab_start[kMaxSeg + 1];
-  int64_t dw_off[kMaxSeg];
-  int64_t db_off[kMaxSeg];
-};
-
 template <int KT, bool TRANS>
 __global__ void __launch_bounds__(kGBlock)
 wgrad_kernel(SlabTable st, const float* __restrict__ a, int64_t lda, int k, int kt0,
@@ -706,6 +696,13 @@ int gcmi_seg_gemm_wgrad(int32_t n_seg, const int32_t* seg_begin, const int32_t* 
   const int KT_total = (k + 31) / 32;
   dim3 grid((unsigned)slabs, (unsigned)((NT + ntw - 1) / ntw));
   TimedScope ts(GCMI_K_WGRAD, sm);
+  // GCMI_WGRAD_V3=0 keeps the exact-fp32 MFMA kernel below; default: the split-bf16 form
+  // (gemm_split.hip: fp32-accurate, 6 bf16 MFMAs per 16 rows instead of 8 fp32 ones)
+  static const bool wg3 = !(getenv("GCMI_WGRAD_V3") && atoi(getenv("GCMI_WGRAD_V3")) == 0);
+  if (wg3) {
+    const int rc = launch_wgrad3(st, (int)slabs, d_a, lda, k, d_g, ldg, n, d_dw, d_dbias, trans_w, sm);
+    if (rc != GCMI_ERR_UNSUPPORTED) return rc;
+  }
   for (int kt0 = 0; kt0 < KT_total; kt0 += 8) {
     const int KT = KT_total - kt0 < 8 ? KT_total - kt0 : 8;
 #define LAUNCH_WG(KK)                                                                            \

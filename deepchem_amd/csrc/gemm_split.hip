@@ -395,4 +395,178 @@ int launch_seg_gemm3(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg
   return GCMI_OK;
 }
 
+
+// ------------------------------------------------------------------ weight gradient, split-bf16
+// dW[s] += a[rows_s]^T . g[rows_s] with the same exact three-way operand split: the contraction
+// runs over ROWS, so a lane's MFMA fragment is 8 consecutive rows of one feature column (8 dword
+// loads, coalesced across the 32 columns of the tile), split and packed in registers.  Structure as
+// wgrad_kernel (gemm.hip): a workgroup = one row slab x `ntw` 32-column tiles of g, every wave one
+// g tile x all KT a tiles, row parts combined through LDS, one float atomic per dW element.
+template <int KT, bool TRANS>
+__global__ void __launch_bounds__(kS3Block)
+wgrad3_kernel(SlabTable st, const float* __restrict__ a, int64_t lda, int k, const float* __restrict__ g,
+              int64_t ldg, int n, int ntw, float* __restrict__ dw, float* __restrict__ dbias) {
+  const int b = blockIdx.x;
+  int s = 0;
+#pragma unroll
+  for (int q = 1; q < kMaxSegW; ++q) s += (q < st.n_seg && b >= st.slab_start[q]) ? 1 : 0;
+  const int seg_end = pick3(st.seg_end, s);
+  const int slab0 = pick3(st.seg_begin, s) + (b - pick3(st.slab_start, s)) * st.slab_rows;
+  const int wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int half = lane >> 5;
+  const int nt = blockIdx.y * ntw + (wave % ntw);
+  const int rp = wave / ntw;
+  const int parts = 4 / ntw;
+  const int part_rows = st.slab_rows / parts;  // a multiple of 16
+  const int r_begin = slab0 + rp * part_rows;
+  int r_end = r_begin + part_rows;
+  if (r_end > seg_end) r_end = seg_end;
+  const int ncol = nt * 32 + (lane & 31);
+  const bool n_ok = ncol < n;
+  f32x16 acc[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  float bsum = 0.f;
+  bool k_ok[KT];
+  int kcol[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    kcol[t] = t * 32 + (lane & 31);
+    k_ok[t] = kcol[t] < k;
+  }
+  // 16 rows per step: this lane's rows r + 8*half .. + 7; clamped unconditional loads, zeroed by selects
+  float av[2][KT][8], gv[2][8];
+  auto load_set = [&](int buf, int r) {
+    const int r8 = r + 8 * half;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int rr = r8 + u;
+      const int rc = rr < r_end ? rr : r_end - 1;
+      gv[buf][u] = g[(int64_t)rc * ldg + (n_ok ? ncol : 0)];
+#pragma unroll
+      for (int t = 0; t < KT; ++t) av[buf][t][u] = a[(int64_t)rc * lda + (k_ok[t] ? kcol[t] : 0)];
+    }
+  };
+  auto mma_set = [&](int buf, int r) {
+    const int r8 = r + 8 * half;
+    float gq[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      gq[u] = (n_ok && r8 + u < r_end) ? gv[buf][u] : 0.f;
+      bsum += gq[u];
+    }
+    const Frag3 fg = split_frag(gq);
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      float aq[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) aq[u] = (k_ok[t] && r8 + u < r_end) ? av[buf][t][u] : 0.f;
+      const Frag3 fa = split_frag(aq);
+      // TRANS (nn.Linear layout, dW stored n x k): operands swapped so the accumulator holds dW^T
+      // and its lane index is the contiguous index of the destination (see wgrad_kernel)
+      const Frag3& L = TRANS ? fg : fa;
+      const Frag3& R = TRANS ? fa : fg;
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[2]), as_bf16x8(R.p[0]), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[0]), as_bf16x8(R.p[2]), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[1]), as_bf16x8(R.p[1]), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[1]), as_bf16x8(R.p[0]), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[0]), as_bf16x8(R.p[1]), acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[0]), as_bf16x8(R.p[0]), acc[t], 0, 0, 0);
+    }
+  };
+  if (r_begin < r_end) {
+    load_set(0, r_begin);
+    int r = r_begin;
+    while (true) {
+      const int r1 = r + 16;
+      if (r1 < r_end) load_set(1, r1);
+      mma_set(0, r);
+      if (r1 >= r_end) break;
+      const int r2 = r1 + 16;
+      if (r2 < r_end) load_set(0, r2);
+      mma_set(1, r1);
+      if (r2 >= r_end) break;
+      r = r2;
+    }
+  }
+  if (parts > 1) {
+    extern __shared__ float red[];
+    float* racc = red + (size_t)(wave % ntw) * KT * 16 * 64;
+    float* rb = red + (size_t)ntw * KT * 16 * 64 + (wave % ntw) * 64;
+    for (int p = 1; p < parts; ++p) {
+      if (rp == p) {
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) racc[(t * 16 + reg) * 64 + lane] = acc[t][reg];
+        rb[lane] = bsum;
+      }
+      __syncthreads();
+      if (rp == 0) {
+#pragma unroll
+        for (int t = 0; t < KT; ++t)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) acc[t][reg] += racc[(t * 16 + reg) * 64 + lane];
+        bsum += rb[lane];
+      }
+      __syncthreads();
+    }
+    if (rp != 0) return;
+  }
+  if (slab0 >= seg_end) return;
+  const int64_t woff = pick3(st.dw_off, s);
+  if (woff >= 0) {
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int rix = (reg & 3) + 8 * (reg >> 2) + 4 * half;
+        if constexpr (TRANS) {
+          const int nc = nt * 32 + rix;
+          if (nc < n && k_ok[t]) atomicAdd(dw + woff + (int64_t)nc * k + kcol[t], acc[t][reg]);
+        } else {
+          const int kf = t * 32 + rix;
+          if (kf < k && n_ok) atomicAdd(dw + woff + (int64_t)kf * n + ncol, acc[t][reg]);
+        }
+      }
+    }
+  }
+  if (dbias != nullptr) {
+    const int64_t boff = pick3(st.db_off, s);
+    bsum += __shfl_xor(bsum, 32);
+    if (half == 0 && n_ok && boff >= 0) atomicAdd(dbias + boff + ncol, bsum);
+  }
+}
+
+int launch_wgrad3(const SlabTable& st, int slabs, const float* d_a, int64_t lda, int k, const float* d_g, int64_t ldg,
+                  int n, float* d_dw, float* d_dbias, int trans_w, hipStream_t sm) {
+  const int KT = (k + 31) / 32;
+  if (KT > 4 || st.slab_rows % 64) return GCMI_ERR_UNSUPPORTED;  // wider K: the fp32 kernel's k-passes
+  const int NT = (n + 31) / 32;
+  const int ntw = NT >= 3 ? 4 : NT;
+  dim3 grid((unsigned)slabs, (unsigned)((NT + ntw - 1) / ntw));
+#define LAUNCH_W3(KK)                                                                               \
+  do {                                                                                              \
+    const size_t lds = ntw == 4 ? 0 : (size_t)ntw * (KK * 16 * 64 + 64) * sizeof(float);            \
+    if (trans_w)                                                                                    \
+      hipLaunchKernelGGL((wgrad3_kernel<KK, true>), grid, dim3(kS3Block), lds, sm, st, d_a, lda, k, d_g, ldg, n, \
+                         ntw, d_dw, d_dbias);                                                       \
+    else                                                                                            \
+      hipLaunchKernelGGL((wgrad3_kernel<KK, false>), grid, dim3(kS3Block), lds, sm, st, d_a, lda, k, d_g, ldg, n, \
+                         ntw, d_dw, d_dbias);                                                       \
+  } while (0)
+  switch (KT) {
+    case 1: LAUNCH_W3(1); break;
+    case 2: LAUNCH_W3(2); break;
+    case 3: LAUNCH_W3(3); break;
+    default: LAUNCH_W3(4); break;
+  }
+#undef LAUNCH_W3
+  GCMI_CHECK_LAUNCH("seg_gemm_wgrad3");
+  return GCMI_OK;
+}
+
 }  // namespace gcmi
