@@ -19,6 +19,7 @@ def bn_acc_doubles(n_feat: int) -> int:
 K_GATHER_SUM, K_GATHER_MAX, K_READOUT, K_SEG_GEMM, K_WGRAD, K_GATHER_MAX_BWD = 0, 1, 2, 3, 4, 5
 
 
+GCMI_OPT_GEMM_EXACT = 1
 GCMI_WIN_META_INTS = 24
 GCMI_WIN_MAX_SLOTS = 4095
 
@@ -144,6 +145,8 @@ _SIGNATURES = {
     "gcmi_model_forward": [_MD, _G, _P, _MIO, c_int32, _P],
     "gcmi_model_loss_backward": [_MD, _G, _P, _P, _MIO, _P, _P, c_int64, _I64P, _I64P, _P],
     "gcmi_diag_mfma_peak": [c_int32, c_int32, _P, _P],
+    "gcmi_set_option": [c_int32, c_int32],
+    "gcmi_get_option": [c_int32, _I32P],
     "gcmi_timing_enable": [c_int32, c_int32],
     "gcmi_timing_read": [c_int32, _I64P, POINTER(c_double), c_int32],
 }

@@ -71,6 +71,8 @@ int win_gather_max(const gcmi_graph* g, const float* d_x, int64_t ldx, int n_fea
 int win_gather_max_bwd(const gcmi_graph* g, const float* d_dout, int64_t lddo, int n_feat,
                        const uint8_t* d_arg, float* d_dx, int64_t lddx, hipStream_t st);
 
+bool gemm_exact_mode();  // gcmi_set_option(GCMI_OPT_GEMM_EXACT)
+
 // row slabs of the weight-gradient kernels (gemm.hip, gemm_split.hip)
 constexpr int kMaxSegW = 16;
 struct SlabTable {
@@ -88,6 +90,12 @@ int launch_wgrad3(const SlabTable& st, int slabs, const float* d_a, int64_t lda,
 // gemm_split.hip: the segmented GEMM on the bf16 matrix cores with exactly split fp32 operands;
 // GCMI_ERR_UNSUPPORTED = shape not covered (fall back to gemm.hip)
 int launch_seg_gemm3(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_end, const float* d_a1,
+                     int64_t lda1, int32_t k1, const float* d_w1, const int64_t* w1_off, const float* d_a2,
+                     int64_t lda2, int32_t k2, const float* d_w2, const int64_t* w2_off, const float* d_bias,
+                     const int64_t* bias_off, int32_t n_out, int32_t trans_w, int32_t act, float* d_out,
+                     int64_t ldo, hipStream_t sm);
+
+int launch_seg_gemm4(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_end, const float* d_a1,
                      int64_t lda1, int32_t k1, const float* d_w1, const int64_t* w1_off, const float* d_a2,
                      int64_t lda2, int32_t k2, const float* d_w2, const int64_t* w2_off, const float* d_bias,
                      const int64_t* bias_off, int32_t n_out, int32_t trans_w, int32_t act, float* d_out,

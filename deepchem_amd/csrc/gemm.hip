@@ -18,6 +18,8 @@
 // the feature dimension, so both operands are loaded straight from global
 // memory (one dword per lane per row pair) and every wave keeps <= 8
 // accumulators (k <= 256 per pass).
+#include <atomic>
+
 #include "common.h"
 
 namespace gcmi {
@@ -548,11 +550,31 @@ relu_bwd_kernel(float* __restrict__ g, int64_t ldg, const float* __restrict__ y,
   }
 }
 
+// GCMI_OPT_GEMM_EXACT: 1 = every product on the exact-fp32 MFMA (a k-ordered fmaf chain: the same
+// summation order as the reference's CPU matmuls, so discrete decisions downstream -- arg-max of
+// the pools, ReLU boundaries -- fall the same way and whole training trajectories track the
+// reference to ~1e-5); 0 (default) = the faster split-bf16 kernels, equally accurate per product
+// but with their own rounding.
+static std::atomic<int> g_gemm_exact{getenv("GCMI_GEMM_EXACT") && atoi(getenv("GCMI_GEMM_EXACT")) == 1 ? 1 : 0};
+bool gemm_exact_mode() { return g_gemm_exact.load(std::memory_order_relaxed) != 0; }
+
 }  // namespace gcmi
 
 using namespace gcmi;
 
 extern "C" {
+
+int gcmi_set_option(int32_t option, int32_t value) {
+  GCMI_CHECK_ARG(option == GCMI_OPT_GEMM_EXACT, "set_option: unknown option %d", option);
+  g_gemm_exact.store(value != 0 ? 1 : 0, std::memory_order_relaxed);
+  return GCMI_OK;
+}
+
+int gcmi_get_option(int32_t option, int32_t* value) {
+  GCMI_CHECK_ARG(option == GCMI_OPT_GEMM_EXACT && value, "get_option: unknown option %d", option);
+  *value = g_gemm_exact.load(std::memory_order_relaxed);
+  return GCMI_OK;
+}
 
 int gcmi_seg_gemm(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_end,
                   const float* d_a1, int64_t lda1, int32_t k1, const float* d_w1,
@@ -606,7 +628,15 @@ int gcmi_seg_gemm(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_en
   // (tools/kbench.py) and equal to them inside the model, where both are bound by their operand
   // streams from HBM; the exact-fp32 chain stays the default.
   static const bool v3 = getenv("GCMI_GEMM_V3") && atoi(getenv("GCMI_GEMM_V3")) == 1;
-  if (v3 && vec4) {
+  const bool exact = gemm_exact_mode();
+  // GCMI_GEMM_V4=0 disables the LDS-staged split-bf16 kernel (default path)
+  static const bool v4 = !(getenv("GCMI_GEMM_V4") && atoi(getenv("GCMI_GEMM_V4")) == 0);
+  if (v4 && !v3 && !exact) {
+    const int rc = launch_seg_gemm4(n_seg, seg_begin, seg_end, d_a1, lda1, k1, d_w1, w1_off, d_a2, lda2, k2,
+                                    d_w2, w2_off, d_bias, bias_off, n_out, trans_w, act, d_out, ldo, sm);
+    if (rc != GCMI_ERR_UNSUPPORTED) return rc;
+  }
+  if (v3 && vec4 && !exact) {
     const int rc = launch_seg_gemm3(n_seg, seg_begin, seg_end, d_a1, lda1, k1, d_w1, w1_off, d_a2, lda2, k2,
                                     d_w2, w2_off, d_bias, bias_off, n_out, trans_w, act, d_out, ldo, sm);
     if (rc != GCMI_ERR_UNSUPPORTED) return rc;
@@ -699,7 +729,7 @@ int gcmi_seg_gemm_wgrad(int32_t n_seg, const int32_t* seg_begin, const int32_t* 
   // GCMI_WGRAD_V3=0 keeps the exact-fp32 MFMA kernel below; default: the split-bf16 form
   // (gemm_split.hip: fp32-accurate, 6 bf16 MFMAs per 16 rows instead of 8 fp32 ones)
   static const bool wg3 = !(getenv("GCMI_WGRAD_V3") && atoi(getenv("GCMI_WGRAD_V3")) == 0);
-  if (wg3) {
+  if (wg3 && !gemm_exact_mode()) {
     const int rc = launch_wgrad3(st, (int)slabs, d_a, lda, k, d_g, ldg, n, d_dw, d_dbias, trans_w, sm);
     if (rc != GCMI_ERR_UNSUPPORTED) return rc;
   }

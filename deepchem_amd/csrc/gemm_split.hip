@@ -3,10 +3,10 @@
 // The exact-fp32 MFMA (v_mfma_f32_32x32x2_f32, gemm.hip) peaks at ~157 TFLOP/s, which for the
 // shapes of this model (K = 64..152, 64..128 output columns) is the same time as streaming the
 // operands from HBM: the kernel would have to sit at both ceilings at once.  Here every fp32
-// operand is split EXACTLY into three bf16 pieces (x = x1 + x2 + x3: each piece takes the top 8
-// significant bits of what is left, 3 x 8 = the 24 bits of an fp32 significand) and the product
-// is assembled from the six piece products that matter,
-//     a.b ~= a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1        (dropped terms <= 3 * 2^-24 |a||b|,
+// operand is split into three bf16 pieces by round-to-nearest (x = x1 + x2 + x3 + r, |r| <= 2^-24 |x|,
+// residuals signed and unbiased) and the product is assembled from the six piece products that
+// matter,
+//     a.b ~= a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1        (dropped terms <= 2^-23 |a||b|,
 //                                                            the size of an fp32 rounding)
 // on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 6 bf16 MFMAs do the work of 8 fp32-MFMA
 // k-steps in 3/8 of the matrix-pipe time, so the kernel is bound by HBM alone.
@@ -49,18 +49,30 @@ __device__ __forceinline__ T pick3(const T* a, int s) {
   return v;
 }
 
-// x = p1 + p2 + p3 exactly, each piece a bf16 (the top 16 bits of an fp32 word)
-__device__ __forceinline__ void split3(float x, unsigned& p1, unsigned& p2, unsigned& p3) {
-  p1 = __float_as_uint(x) & 0xFFFF0000u;
-  const float r1 = x - __uint_as_float(p1);
-  p2 = __float_as_uint(r1) & 0xFFFF0000u;
-  const float r2 = r1 - __uint_as_float(p2);
-  p3 = __float_as_uint(r2) & 0xFFFF0000u;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Round-to-nearest three-way split, two values at a time (v_cvt_pk_bf16_f32 packs the pair):
+// x = p1 + p2 + p3 + r3 with |p2| <= 2^-8 |x|, |p3| <= 2^-16 |x|, |r3| <= 2^-24 |x| and signed,
+// unbiased residuals.  The six products kept below drop p2*q3 + p3*q2 + p3*q3 <= 2^-23 |x||y|.
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3) {
+  f32x2 v = {x0, x1};
+  p1 = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  const f32x2 f1 = {__uint_as_float(p1 << 16), __uint_as_float(p1 & 0xFFFF0000u)};
+  const f32x2 r1 = v - f1;  // exact
+  p2 = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2));
+  const f32x2 f2 = {__uint_as_float(p2 << 16), __uint_as_float(p2 & 0xFFFF0000u)};
+  const f32x2 r2 = r1 - f2;  // exact
+  p3 = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
 }
 
-// two pieces (high halves of two fp32 words) -> one dword holding [lo, hi] bf16
-__device__ __forceinline__ unsigned pack_hi(unsigned lo_word, unsigned hi_word) {
-  return (lo_word >> 16) | hi_word;
+// one value: the three bf16 pieces in the low halves of p1..p3
+__device__ __forceinline__ void split3(float x, unsigned& p1, unsigned& p2, unsigned& p3) {
+  unsigned q1, q2, q3;
+  split3_pair(x, 0.f, q1, q2, q3);
+  p1 = q1 << 16;  // callers take the piece from the HIGH half
+  p2 = q2 << 16;
+  p3 = q3 << 16;
 }
 
 struct Frag3 {
@@ -69,15 +81,15 @@ struct Frag3 {
 
 __device__ __forceinline__ Frag3 split_frag(const float (&v)[8]) {
   Frag3 f;
-  unsigned a[3][8];
+  unsigned q[3][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) split3(v[i], a[0][i], a[1][i], a[2][i]);
+  for (int i = 0; i < 4; ++i) split3_pair(v[2 * i], v[2 * i + 1], q[0][i], q[1][i], q[2][i]);
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
-    f.p[s].x = pack_hi(a[s][0], a[s][1]);
-    f.p[s].y = pack_hi(a[s][2], a[s][3]);
-    f.p[s].z = pack_hi(a[s][4], a[s][5]);
-    f.p[s].w = pack_hi(a[s][6], a[s][7]);
+    f.p[s].x = q[s][0];
+    f.p[s].y = q[s][1];
+    f.p[s].z = q[s][2];
+    f.p[s].w = q[s][3];
   }
   return f;
 }
@@ -395,6 +407,252 @@ int launch_seg_gemm3(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg
   return GCMI_OK;
 }
 
+
+// ------------------------------------------------------------------ forward / dgrad, LDS-staged
+// Same product as seg_gemm3_kernel, different operand path: A K-chunks of 32 columns are fetched
+// with coalesced 16-byte loads (8 lanes = one 128-byte row piece) into registers one chunk ahead
+// and staged through LDS as fp32; the matching weight chunk is split into its three bf16 images
+// when it is written to LDS.  Inside the model the operands stream from HBM, where this access
+// shape moves ~1.5x the bytes per second of the per-lane fragment loads of seg_gemm3_kernel.
+constexpr int kS4KC = 32;          // K chunk
+constexpr int kS4AStride = kS4KC + 4;   // floats per staged A row: 16-byte aligned, 2-way b128 reads
+constexpr int kS4WStride = kS4KC + 8;   // bf16 per staged W column: conflict-free b128 reads
+
+// AVEC: the A rows are 16-byte addressable (else four scalar loads per quad: same values, same
+// arithmetic, so the result does not depend on how the caller laid its rows out)
+template <bool TRANS, int NT, bool AVEC>
+__global__ void __launch_bounds__(kS3Block) __attribute__((amdgpu_waves_per_eu(NT <= 2 ? 3 : 2)))
+seg_gemm4_kernel(SegTable3 st, const float* __restrict__ a1, int64_t lda1, int k1, const float* __restrict__ w1,
+                 const float* __restrict__ a2, int64_t lda2, int k2, const float* __restrict__ w2,
+                 const float* __restrict__ bias, int n_out, int act, float* __restrict__ out, int64_t ldo) {
+  constexpr int NB = NT * 32;
+  constexpr int APASS = 4;                       // 128 rows / (256 threads / 8 lanes per row piece)
+  constexpr int BPASS = (kS4KC * NB) / kS3Block;  // weight elements per thread per chunk
+  __shared__ __attribute__((aligned(16))) float As[kS3Rows][kS4AStride];
+  __shared__ __attribute__((aligned(16))) unsigned short Ws[3][NB][kS4WStride];
+  __shared__ __attribute__((aligned(16))) float bias_lds[NB];
+  const int b = blockIdx.x;
+  int s = 0;
+#pragma unroll
+  for (int k = 1; k < kS3MaxSeg; ++k) s += (k < st.n_seg && b >= st.tile_start[k]) ? 1 : 0;
+  const int row0 = pick3(st.seg_begin, s) + (b - pick3(st.tile_start, s)) * kS3Rows;
+  const int seg_end = pick3(st.seg_end, s);
+  const int rows_valid = (seg_end - row0 < kS3Rows) ? seg_end - row0 : kS3Rows;
+  const int col0 = blockIdx.y * NB;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int half = lane >> 5;
+  const int64_t woff1 = pick3(st.w1_off, s), woff2 = pick3(st.w2_off, s);
+  const int64_t boff = pick3(st.bias_off, s);
+  const bool on1 = a1 != nullptr && w1 != nullptr && woff1 >= 0;
+  const bool on2 = a2 != nullptr && w2 != nullptr && woff2 >= 0;
+  const int n1 = on1 ? (k1 + kS4KC - 1) / kS4KC : 0;
+  const int n2 = on2 ? (k2 + kS4KC - 1) / kS4KC : 0;
+  const int nchunks = n1 + n2;
+  for (int j = tid; j < NB; j += kS3Block)
+    bias_lds[j] = (bias != nullptr && boff >= 0 && col0 + j < n_out) ? bias[boff + col0 + j] : 0.f;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  // prefetch registers: unconditional loads from clamped addresses, masked when stored to LDS
+  float4 ra[APASS];
+  float rb[BPASS];
+  int pend_k0 = 0, pend_K = 0;
+  auto gload = [&](int c) {
+    const bool first = c < n1;
+    const float* a = first ? a1 : a2;
+    const int64_t lda = first ? lda1 : lda2;
+    const int K = first ? k1 : k2;
+    const float* w = first ? w1 + woff1 : w2 + woff2;
+    const int k0 = (first ? c : c - n1) * kS4KC;
+    pend_k0 = k0;
+    pend_K = K;
+    const int kcol = k0 + (tid & 7) * 4;
+    const int kc = kcol + 4 <= lda ? kcol : 0;
+#pragma unroll
+    for (int pass = 0; pass < APASS; ++pass) {
+      const int r = (tid >> 3) + pass * 32;
+      const int rc = r < rows_valid ? r : rows_valid - 1;
+      const float* p = a + (int64_t)(row0 + rc) * lda;
+      if constexpr (AVEC) {
+        ra[pass] = *reinterpret_cast<const float4*>(p + kc);
+      } else {  // clamped scalar loads; columns >= K are zeroed when the quad goes to LDS
+        ra[pass].x = p[kcol + 0 < K ? kcol + 0 : 0];
+        ra[pass].y = p[kcol + 1 < K ? kcol + 1 : 0];
+        ra[pass].z = p[kcol + 2 < K ? kcol + 2 : 0];
+        ra[pass].w = p[kcol + 3 < K ? kcol + 3 : 0];
+      }
+    }
+    if constexpr (!TRANS) {  // w is K x n_out
+      const int j = col0 + tid % NB;
+      const int jc = j < n_out ? j : n_out - 1;
+#pragma unroll
+      for (int pass = 0; pass < BPASS; ++pass) {
+        const int kk = k0 + tid / NB + pass * (kS3Block / NB);
+        rb[pass] = w[(int64_t)(kk < K ? kk : K - 1) * n_out + jc];
+      }
+    } else {  // w is n_out x K
+      const int kk = k0 + (tid % kS4KC);
+      const int kkc = kk < K ? kk : K - 1;
+#pragma unroll
+      for (int pass = 0; pass < BPASS; ++pass) {
+        const int j = col0 + tid / kS4KC + pass * (kS3Block / kS4KC);
+        rb[pass] = w[(int64_t)(j < n_out ? j : n_out - 1) * K + kkc];
+      }
+    }
+  };
+  auto sstore = [&]() {
+    const int kq = (tid & 7) * 4;
+    const int tail = pend_K - (pend_k0 + kq);
+#pragma unroll
+    for (int pass = 0; pass < APASS; ++pass) {
+      const int r = (tid >> 3) + pass * 32;
+      const bool ok = r < rows_valid;
+      float4 v = ra[pass];
+      v.x = (ok && tail > 0) ? v.x : 0.f;
+      v.y = (ok && tail > 1) ? v.y : 0.f;
+      v.z = (ok && tail > 2) ? v.z : 0.f;
+      v.w = (ok && tail > 3) ? v.w : 0.f;
+      *reinterpret_cast<float4*>(&As[r][kq]) = v;
+    }
+#pragma unroll
+    for (int pass = 0; pass < BPASS; ++pass) {
+      int kk, j;
+      if constexpr (!TRANS) {
+        j = tid % NB;
+        kk = tid / NB + pass * (kS3Block / NB);
+      } else {
+        kk = tid % kS4KC;
+        j = tid / kS4KC + pass * (kS3Block / kS4KC);
+      }
+      const float v = (pend_k0 + kk < pend_K && col0 + j < n_out) ? rb[pass] : 0.f;
+      unsigned p1, p2, p3;
+      split3(v, p1, p2, p3);
+      Ws[0][j][kk] = (unsigned short)(p1 >> 16);
+      Ws[1][j][kk] = (unsigned short)(p2 >> 16);
+      Ws[2][j][kk] = (unsigned short)(p3 >> 16);
+    }
+  };
+
+  if (nchunks > 0) {
+    gload(0);
+    sstore();
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+      if (c + 1 < nchunks) gload(c + 1);  // in flight while the matrix pipe works on chunk c
+#pragma unroll
+      for (int step = 0; step < kS4KC / 16; ++step) {
+        const int kk0 = step * 16 + 8 * half;
+        const float* arow = &As[wave * 32 + (lane & 31)][kk0];
+        const float4 lo = *reinterpret_cast<const float4*>(arow);
+        const float4 hi = *reinterpret_cast<const float4*>(arow + 4);
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const Frag3 fa = split_frag(v);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int j = t * 32 + (lane & 31);
+          const u32x4 b1 = *reinterpret_cast<const u32x4*>(&Ws[0][j][kk0]);
+          const u32x4 b2 = *reinterpret_cast<const u32x4*>(&Ws[1][j][kk0]);
+          const u32x4 b3 = *reinterpret_cast<const u32x4*>(&Ws[2][j][kk0]);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b3), as_bf16x8(fa.p[0]), acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b1), as_bf16x8(fa.p[2]), acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b2), as_bf16x8(fa.p[1]), acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b2), as_bf16x8(fa.p[0]), acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b1), as_bf16x8(fa.p[1]), acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b1), as_bf16x8(fa.p[0]), acc[t], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+      if (c + 1 < nchunks) {
+        sstore();
+        __syncthreads();
+      }
+    }
+  } else {
+    __syncthreads();
+  }
+
+  // ---- epilogue (n_out % 4 == 0, 16-byte addressable output rows: checked by the launcher)
+  const int r = wave * 32 + (lane & 31);
+  if (r < rows_valid) {
+    float* orow = out + (int64_t)(row0 + r) * ldo + col0;
+    const float4* bias4 = reinterpret_cast<const float4*>(bias_lds);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int cl = t * 32 + 8 * rg + 4 * half;
+        if (col0 + cl < n_out) {
+          const float4 bq = bias4[cl >> 2];
+          float4 v = make_float4(acc[t][4 * rg] + bq.x, acc[t][4 * rg + 1] + bq.y, acc[t][4 * rg + 2] + bq.z,
+                                 acc[t][4 * rg + 3] + bq.w);
+          if (act == 1) {
+            v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+            v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+          }
+          if (act == 2) {
+            const float4 o = *reinterpret_cast<const float4*>(orow + cl);
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+          }
+          *reinterpret_cast<float4*>(orow + cl) = v;
+        }
+      }
+    }
+  }
+}
+
+int launch_seg_gemm4(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_end, const float* d_a1,
+                     int64_t lda1, int32_t k1, const float* d_w1, const int64_t* w1_off, const float* d_a2,
+                     int64_t lda2, int32_t k2, const float* d_w2, const int64_t* w2_off, const float* d_bias,
+                     const int64_t* bias_off, int32_t n_out, int32_t trans_w, int32_t act, float* d_out,
+                     int64_t ldo, hipStream_t sm) {
+  if (n_seg > kS3MaxSeg) return GCMI_ERR_UNSUPPORTED;
+  const bool avec = !((d_a1 && (!aligned16(d_a1) || lda1 % 4)) || (d_a2 && (!aligned16(d_a2) || lda2 % 4)));
+  if (n_out % 4 || ldo % 4 || !aligned16(d_out)) return GCMI_ERR_UNSUPPORTED;
+  const int nt = n_out <= 32 ? 1 : (n_out <= 64 ? 2 : 4);
+  SegTable3 st;
+  memset(&st, 0, sizeof(st));
+  st.n_seg = n_seg;
+  int64_t tiles = 0;
+  for (int s = 0; s < kS3MaxSeg; ++s) {
+    st.tile_start[s] = (int32_t)tiles;
+    if (s < n_seg) {
+      st.seg_begin[s] = seg_begin[s];
+      st.seg_end[s] = seg_end[s];
+      st.w1_off[s] = (d_a1 && w1_off) ? w1_off[s] : -1;
+      st.w2_off[s] = (d_a2 && w2_off) ? w2_off[s] : -1;
+      st.bias_off[s] = (d_bias && bias_off) ? bias_off[s] : -1;
+      tiles += (seg_end[s] - seg_begin[s] + kS3Rows - 1) / kS3Rows;
+    } else {
+      st.w1_off[s] = st.w2_off[s] = st.bias_off[s] = -1;
+    }
+  }
+  st.tile_start[kS3MaxSeg] = (int32_t)tiles;
+  if (tiles == 0) return GCMI_OK;
+  dim3 grid((unsigned)tiles, (unsigned)((n_out + nt * 32 - 1) / (nt * 32)));
+#define LAUNCH_S4(TT, NN)                                                                                      \
+  do {                                                                                                         \
+    if (avec)                                                                                                  \
+      hipLaunchKernelGGL((seg_gemm4_kernel<TT, NN, true>), grid, dim3(kS3Block), 0, sm, st, d_a1, lda1, k1, d_w1,   \
+                         d_a2, lda2, k2, d_w2, d_bias, n_out, act, d_out, ldo);                                \
+    else                                                                                                       \
+      hipLaunchKernelGGL((seg_gemm4_kernel<TT, NN, false>), grid, dim3(kS3Block), 0, sm, st, d_a1, lda1, k1, d_w1,  \
+                         d_a2, lda2, k2, d_w2, d_bias, n_out, act, d_out, ldo);                                \
+  } while (0)
+  if (trans_w) {
+    if (nt == 1) LAUNCH_S4(true, 1); else if (nt == 2) LAUNCH_S4(true, 2); else LAUNCH_S4(true, 4);
+  } else {
+    if (nt == 1) LAUNCH_S4(false, 1); else if (nt == 2) LAUNCH_S4(false, 2); else LAUNCH_S4(false, 4);
+  }
+#undef LAUNCH_S4
+  GCMI_CHECK_LAUNCH("seg_gemm4");
+  return GCMI_OK;
+}
 
 // ------------------------------------------------------------------ weight gradient, split-bf16
 // dW[s] += a[rows_s]^T . g[rows_s] with the same exact three-way operand split: the contraction

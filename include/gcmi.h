@@ -103,6 +103,13 @@ typedef struct gcmi_graph {
 } gcmi_graph;
 
 int gcmi_version(void);
+/* Process-wide options.  GCMI_OPT_GEMM_EXACT: 1 = all matrix products on the exact-fp32 MFMA (the
+ * reference's summation order: training trajectories track the reference to ~1e-5); 0 (default) =
+ * the split-bf16 kernels (fp32-accurate per product, ~1.25x faster, own rounding).  Also settable
+ * by the environment variable GCMI_GEMM_EXACT=1 before the library is loaded.                   */
+enum { GCMI_OPT_GEMM_EXACT = 1 };
+int gcmi_set_option(int32_t option, int32_t value);
+int gcmi_get_option(int32_t option, int32_t* value);
 const char* gcmi_last_error(void);
 
 /* ---------------------------------------------------------------- host side

@@ -184,9 +184,28 @@ def test_first_batch_outputs_loss_grads(name):
                 assert int(v) == int(tr.state[k])
 
 
+@pytest.fixture
+def gemm_mode(request):
+    import deepchem_amd
+    deepchem_amd.set_gemm_mode(request.param)
+    yield request.param
+    deepchem_amd.set_gemm_mode("fast")
+
+
 @pytest.mark.parametrize("name", MODEL_FIXTURES)
 @pytest.mark.parametrize("gm", ["reference", "full"])
-def test_fit_trajectory_predict_embedding(name, gm):
+@pytest.mark.parametrize("gemm_mode", ["exact", "fast"], indirect=True)
+def test_fit_trajectory_predict_embedding(name, gm, gemm_mode):
+    """Two epochs of fit() against the reference's trajectory.
+
+    ``exact`` GEMM mode sums every product in the reference's order (k-ordered fp32 chain), so even
+    the discrete decisions of training (arg-max of GraphPool / GraphGather, ReLU boundaries) fall the
+    same way: tight tolerances.  ``fast`` mode (default; split-bf16 products, equally accurate per
+    product) has its own rounding: per-step losses still agree to 5e-3, but a flipped arg-max moves
+    the trajectory discontinuously (tools/trajectory_sensitivity.py: a 1e-7 input perturbation jumps
+    between the same two trajectories) and Adam moves a parameter by ~lr per step whatever the
+    gradient's scale, so parameters are only bounded by n_steps * lr."""
+    exact = gemm_mode == "exact"
     g = load_golden("model_%s.npz" % name)
     model, cfg, state = build_model(g, gm)
     ds, _ = dataset_from(g)
@@ -206,17 +225,21 @@ def test_fit_trajectory_predict_embedding(name, gm):
         full = "%s_fit_state__%s" % (gm, k)
         if full in g.files:
             e = g[full]
-            assert np.abs(v - e).max() <= 5e-3 * max(np.abs(e).max(), 1e-3), k
+            bound = 5e-3 * max(np.abs(e).max(), 1e-3) if exact else max(len(exp) * 1e-3, 5e-3 * np.abs(e).max())
+            assert np.abs(v - e).max() <= bound, k
+            assert np.median(np.abs(v - e)) <= 2e-4 * max(np.abs(e).max(), 1e-3), k
         else:
             from oracle.gen_golden import sample
             e = g["%s_fit_statesample__%s" % (gm, k)]
-            assert np.abs(sample(v) - e).max() <= 5e-3 * max(np.abs(e).max(), 1e-3), k
+            bound = 5e-3 * max(np.abs(e).max(), 1e-3) if exact else max(len(exp) * 1e-3, 5e-3 * np.abs(e).max())
+            assert np.abs(sample(v) - e).max() <= bound, k
     pred = model.predict(ds)
     assert pred.shape == g["%s_predict" % gm].shape  # ragged last batch trimmed
-    assert np.abs(pred - g["%s_predict" % gm]).max() < 1e-2
+    assert np.abs(pred - g["%s_predict" % gm]).max() < (1e-2 if exact else 6e-2)
+    assert np.abs(pred - g["%s_predict" % gm]).mean() < 2e-3
     emb = model.predict_embedding(ds)
     assert emb.shape == g["%s_embedding" % gm].shape  # untrimmed
-    assert np.abs(emb - g["%s_embedding" % gm]).max() < 1e-2
+    assert np.abs(emb - g["%s_embedding" % gm]).max() < (1e-2 if exact else 6e-2)
 
 
 def test_predict_uncertainty_api():
