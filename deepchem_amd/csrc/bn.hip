@@ -79,29 +79,43 @@ col_sums_kernel(const float* __restrict__ a, int64_t lda, const float* __restric
       is[q] = MODE >= 1 ? invstd[c + q] : 0.f;
     }
     if (active) {
-      for (int64_t r = r_begin + ty; r < r_end; r += ry) {
-        float av[V], xv[V];
-        if constexpr (MODE == 2) readout_dy<V>(rg, r, c, n_feat, av);
-        if constexpr (V == 4) {
-          if (MODE != 2) {
-            const float4 t4 = *reinterpret_cast<const float4*>(a + r * lda + c);
-            av[0] = t4.x; av[1] = t4.y; av[2] = t4.z; av[3] = t4.w;
+      // four rows per round: the loads are issued together (one row per round leaves a single
+      // 16-byte load in flight per lane and the loop runs at memory latency)
+      constexpr int R = 4;
+      for (int64_t r0 = r_begin + ty; r0 < r_end; r0 += (int64_t)R * ry) {
+        float av[R][V], xv[R][V];
+        bool ok[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+          const int64_t r = r0 + (int64_t)u * ry;
+          ok[u] = r < r_end;
+          const int64_t rc = ok[u] ? r : r0;
+          if constexpr (MODE == 2) readout_dy<V>(rg, rc, c, n_feat, av[u]);
+          if constexpr (V == 4) {
+            if (MODE != 2) {
+              const float4 t4 = *reinterpret_cast<const float4*>(a + rc * lda + c);
+              av[u][0] = t4.x; av[u][1] = t4.y; av[u][2] = t4.z; av[u][3] = t4.w;
+            }
+            if (MODE >= 1) {
+              const float4 u4 = *reinterpret_cast<const float4*>(x + rc * ldx + c);
+              xv[u][0] = u4.x; xv[u][1] = u4.y; xv[u][2] = u4.z; xv[u][3] = u4.w;
+            }
+          } else {
+            if (MODE != 2) av[u][0] = a[rc * lda + c];
+            if (MODE >= 1) xv[u][0] = x[rc * ldx + c];
           }
-          if (MODE >= 1) {
-            const float4 u4 = *reinterpret_cast<const float4*>(x + r * ldx + c);
-            xv[0] = u4.x; xv[1] = u4.y; xv[2] = u4.z; xv[3] = u4.w;
-          }
-        } else {
-          if (MODE != 2) av[0] = a[r * lda + c];
-          if (MODE >= 1) xv[0] = x[r * ldx + c];
         }
 #pragma unroll
-        for (int q = 0; q < V; ++q) {
-          s1[q] += (double)av[q];
-          if (MODE == 0)
-            s2[q] += (double)av[q] * (double)av[q];
-          else
-            s2[q] += (double)av[q] * (double)((xv[q] - mu[q]) * is[q]);
+        for (int u = 0; u < R; ++u) {
+          if (!ok[u]) continue;
+#pragma unroll
+          for (int q = 0; q < V; ++q) {
+            s1[q] += (double)av[u][q];
+            if (MODE == 0)
+              s2[q] += (double)av[u][q] * (double)av[u][q];
+            else
+              s2[q] += (double)av[u][q] * (double)((xv[u][q] - mu[q]) * is[q]);
+          }
         }
       }
     }

@@ -582,6 +582,18 @@ seg_gemm4_kernel(SegTable3 st, const float* __restrict__ a1, int64_t lda1, int k
   if (r < rows_valid) {
     float* orow = out + (int64_t)(row0 + r) * ldo + col0;
     const float4* bias4 = reinterpret_cast<const float4*>(bias_lds);
+    // accumulate mode: all pieces of the old output row are requested before the first is used
+    // (a load-add-store chain per piece would pay the memory latency sixteen times)
+    float4 old[NT][4];
+    if (act == 2) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int cl = t * 32 + 8 * rg + 4 * half;
+          old[t][rg] = *reinterpret_cast<const float4*>(orow + (col0 + cl < n_out ? cl : 0));
+        }
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -596,8 +608,7 @@ seg_gemm4_kernel(SegTable3 st, const float* __restrict__ a1, int64_t lda1, int k
             v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
           }
           if (act == 2) {
-            const float4 o = *reinterpret_cast<const float4*>(orow + cl);
-            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            v.x += old[t][rg].x; v.y += old[t][rg].y; v.z += old[t][rg].z; v.w += old[t][rg].w;
           }
           *reinterpret_cast<float4*>(orow + cl) = v;
         }

@@ -75,19 +75,29 @@ readout_fwd_kernel(int n_mols, int n_deg, const int32_t* __restrict__ runs,
     }
     for (int d = 0; d < n_deg; ++d) {
       const int r0 = rb[2 * d], r1 = rb[2 * d + 1];
-      for (int r = r0; r < r1; ++r) {
-        float v[V];
-        if constexpr (V == 4) {
-          const float4 tv = *reinterpret_cast<const float4*>(x + (int64_t)r * ldx + c);
-          v[0] = tv.x; v[1] = tv.y; v[2] = tv.z; v[3] = tv.w;
-        } else {
-          v[0] = x[(int64_t)r * ldx + c];
+      // four rows of the run per round, loads issued together, consumed in row order
+      for (int rr = r0; rr < r1; rr += 4) {
+        float v[4][V];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int r = rr + u < r1 ? rr + u : rr;
+          if constexpr (V == 4) {
+            const float4 tv = *reinterpret_cast<const float4*>(x + (int64_t)r * ldx + c);
+            v[u][0] = tv.x; v[u][1] = tv.y; v[u][2] = tv.z; v[u][3] = tv.w;
+          } else {
+            v[u][0] = x[(int64_t)r * ldx + c];
+          }
         }
 #pragma unroll
-        for (int q = 0; q < V; ++q) {
-          const float a = BN ? fmaf(v[q], sc[q], sh[q]) : v[q];
-          sum[q] += a;
-          if (a > mx[q]) { mx[q] = a; am[q] = r; }
+        for (int u = 0; u < 4; ++u) {
+          const int r = rr + u;
+          if (r >= r1) break;
+#pragma unroll
+          for (int q = 0; q < V; ++q) {
+            const float a = BN ? fmaf(v[u][q], sc[q], sh[q]) : v[u][q];
+            sum[q] += a;
+            if (a > mx[q]) { mx[q] = a; am[q] = r; }
+          }
         }
       }
     }
