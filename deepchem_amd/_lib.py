@@ -132,7 +132,7 @@ _SIGNATURES = {
     "gcmi_softmax": [_P, c_int64, c_int32, _P, _P],
     "gcmi_adam_step": [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float, c_int64, _P],
     "gcmi_fold_affine": [_P, _P, _P, _P, c_int32, c_int32, c_int32, _P, _P, _P],
-    "gcmi_weave_pair_to_atom": [_P, c_int64, c_int32, _P, c_int32, _P, _P, c_int32, _P, c_int64, _P],
+    "gcmi_weave_pair_to_atom": [_P, c_int64, c_int32, _P, c_int64, c_int32, _P, _P, c_int32, _P, c_int64, _P],
     "gcmi_weave_pair_features": [_P, _P, c_int64, c_int32, _P, _P, c_int64, c_int32, _P, _P, c_int32, _P,
                                  c_int64, _P, c_int64, _P],
     "gcmi_weave_gather": [_P, c_int64, c_int32, _P, c_int32, c_int32, _P, c_int64, _P],

@@ -36,12 +36,21 @@ edge_network_kernel(const float* __restrict__ g, int64_t ldg, int d, int K, cons
       const int r = r0 + lane;
       float acc = 0.f;
       if (r < d) {
-        for (int p = p0; p < p1; ++p) {
-          const float* grow = g + (int64_t)src[p] * ldg;
-          const float* prow = pf + (int64_t)p * ldp;  // broadcast loads
-          float m = grow[(int64_t)K * d + r];
-          for (int k = 0; k < K; ++k) m = fmaf(prow[k], grow[(int64_t)k * d + r], m);
-          acc += m;
+        // two pairs per round, their K+1 gathered row pieces requested together
+        for (int p = p0; p < p1; p += 2) {
+          const bool two = p + 1 < p1;
+          const float* g0 = g + (int64_t)src[p] * ldg;
+          const float* g1 = g + (int64_t)src[two ? p + 1 : p] * ldg;
+          const float* f0 = pf + (int64_t)p * ldp;  // broadcast loads
+          const float* f1 = pf + (int64_t)(two ? p + 1 : p) * ldp;
+          float m0 = g0[(int64_t)K * d + r], m1 = g1[(int64_t)K * d + r];
+#pragma unroll 7
+          for (int k = 0; k < K; ++k) {
+            m0 = fmaf(f0[k], g0[(int64_t)k * d + r], m0);
+            m1 = fmaf(f1[k], g1[(int64_t)k * d + r], m1);
+          }
+          acc += m0;
+          if (two) acc += m1;
         }
         out[(int64_t)i * ldo + r] = acc;
       }

@@ -8,7 +8,8 @@
 // pair-sized intermediate is written that the reference's op-by-op graph materialises:
 //
 //   weave_pair_to_atom   relu(affine(Pf.W_PA))  summed over the pairs of every source atom
-//                        (the P x H activation is never written; K = Fp = 14 runs on the VALUs)
+//                        (the P x H activation is never written; K = Fp = 14 runs on the VALUs,
+//                        pair rows staged in LDS, one float atomic per column and atom)
 //   weave_pair_features  Z[p] = [ relu(U[i]+V[j]+b) + relu(U[j]+V[i]+b) | relu(affine(Pf[p].W_PP)) ]
 //                        with U = A.W_AP[:Fa], V = A.W_AP[Fa:] computed per ATOM: the reference's
 //                        two P x 2Fa gathered matmuls become two N x Fa ones plus row gathers
@@ -43,35 +44,55 @@ __global__ void fold_affine_kernel(const float* __restrict__ w, const float* __r
   }
 }
 
-// out[a, h] = sum over pairs p of atom a of relu(Pf[p,:] . W[:,h] + b[h]); one wave per atom at a
-// time, lane = output column h (H <= 64 per pass), W column in registers.
+// out[a, h] += relu(Pf[p,:] . W[:,h] + b[h]) for every pair p of source atom a (out pre-zeroed).
+// A workgroup takes kP2aPairs consecutive pairs: their feature rows and source atoms are staged in
+// LDS with coalesced loads; every wave then walks a quarter of them with lane = output column, the
+// pair row read by LDS broadcast, and flushes its running sum with one float atomic per column
+// whenever the source atom changes (pairs are sorted by source atom: ~one flush per atom).
+constexpr int kP2aPairs = 256;
+
 template <int FP>
 __global__ void __launch_bounds__(kWvBlock)
-pair_to_atom_kernel(const float* __restrict__ pf, int64_t ldp, int fp, const int32_t* __restrict__ pair_ptr,
-                    int n_atoms, const float* __restrict__ w, const float* __restrict__ b, int H,
+pair_to_atom_kernel(const float* __restrict__ pf, int64_t ldp, int fp, const int32_t* __restrict__ pair_src,
+                    int64_t n_pairs, const float* __restrict__ w, const float* __restrict__ b, int H,
                     float* __restrict__ out, int64_t ldo) {
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * kWvBlock + threadIdx.x) >> 6;
-  const int n_waves = (gridDim.x * kWvBlock) >> 6;
+  __shared__ float feat[kP2aPairs][FP];
+  __shared__ int src[kP2aPairs];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int64_t p0 = (int64_t)blockIdx.x * kP2aPairs;
+  const int np = (int)((n_pairs - p0 < kP2aPairs) ? n_pairs - p0 : kP2aPairs);
+  for (int e = tid; e < np * FP; e += kWvBlock) {  // rows are contiguous when ldp == fp
+    const int r = e / FP, k = e - r * FP;
+    feat[r][k] = k < fp ? pf[(p0 + r) * ldp + k] : 0.f;
+  }
+  for (int r = tid; r < np; r += kWvBlock) src[r] = pair_src[p0 + r];
+  __syncthreads();
+  const int q0 = wave * (kP2aPairs / 4);
+  const int q1 = (q0 + kP2aPairs / 4 < np) ? q0 + kP2aPairs / 4 : np;
   for (int h0 = 0; h0 < H; h0 += 64) {
     const int h = h0 + lane;
+    const bool h_ok = h < H;
     float wc[FP];
 #pragma unroll
-    for (int k = 0; k < FP; ++k) wc[k] = (h < H && k < fp) ? w[(int64_t)k * H + h] : 0.f;
-    const float bh = (h < H && b) ? b[h] : 0.f;
-    for (int a = wave; a < n_atoms; a += n_waves) {
-      const int p0 = pair_ptr[a], p1 = pair_ptr[a + 1];
-      float acc = 0.f;
-      for (int p = p0; p < p1; ++p) {
-        const float* row = pf + (int64_t)p * ldp;  // same address in every lane: one broadcast load
-        float v = bh;
-#pragma unroll
-        for (int k = 0; k < FP; ++k)
-          if (k < fp) v = fmaf(row[k], wc[k], v);
-        acc += v > 0.f ? v : 0.f;
+    for (int k = 0; k < FP; ++k) wc[k] = (h_ok && k < fp) ? w[(int64_t)k * H + h] : 0.f;
+    const float bh = (h_ok && b) ? b[h] : 0.f;
+    float acc = 0.f;
+    int cur = q0 < q1 ? src[q0] : -1;
+    for (int q = q0; q < q1; ++q) {
+      const int a = src[q];
+      if (a != cur) {  // wave-uniform
+        if (h_ok) atomicAdd(out + (int64_t)cur * ldo + h, acc);
+        acc = 0.f;
+        cur = a;
       }
-      if (h < H) out[(int64_t)a * ldo + h] = acc;
+      float v = bh;
+#pragma unroll
+      for (int k = 0; k < FP; ++k) v = fmaf(feat[q][k], wc[k], v);  // k >= fp: wc = 0, feat unread garbage * 0
+      acc += v > 0.f ? v : 0.f;
     }
+    if (cur >= 0 && h_ok) atomicAdd(out + (int64_t)cur * ldo + h, acc);
   }
 }
 
@@ -87,31 +108,51 @@ pair_features_kernel(const float* __restrict__ u, const float* __restrict__ v, i
   const int lane = threadIdx.x & 63;
   const int64_t wave = ((int64_t)blockIdx.x * kWvBlock + threadIdx.x) >> 6;
   const int64_t n_waves = ((int64_t)gridDim.x * kWvBlock) >> 6;
-  const int W = H + H2;
-  for (int c0 = 0; c0 < W; c0 += 64) {
+  constexpr int R = 4;  // pairs per round: their loads are issued together
+  // ---- atom -> pair columns [0, H): four gathered rows per pair
+  for (int c0 = 0; c0 < H; c0 += 64) {
     const int c = c0 + lane;
-    const bool is_ap = c < H;
-    const int h2 = c - H;
+    const bool ok = c < H;
+    const int cu = ok ? c : 0;
+    const float bias = (ok && b_ap) ? b_ap[c] : 0.f;
+    for (int64_t p0 = wave * R; p0 < n_pairs; p0 += n_waves * R) {
+      float uij[R], vij[R], uji[R], vji[R];
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        const int64_t p = p0 + q < n_pairs ? p0 + q : p0;
+        const int i = atom_to_pair[2 * p], j = atom_to_pair[2 * p + 1];
+        uij[q] = u[(int64_t)i * lduv + cu]; vij[q] = v[(int64_t)j * lduv + cu];
+        uji[q] = u[(int64_t)j * lduv + cu]; vji[q] = v[(int64_t)i * lduv + cu];
+      }
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        const float ij = uij[q] + vij[q] + bias, ji = uji[q] + vji[q] + bias;
+        if (ok && p0 + q < n_pairs) z[(p0 + q) * ldz + c] = (ij > 0.f ? ij : 0.f) + (ji > 0.f ? ji : 0.f);
+      }
+    }
+  }
+  // ---- pair -> pair columns [H, H + H2): K = fp product on the VALUs, the pair row by broadcast loads
+  for (int c0 = 0; c0 < H2; c0 += 64) {
+    const int h2 = c0 + lane;
+    const bool ok = h2 < H2;
     float wc[FP];
 #pragma unroll
-    for (int k = 0; k < FP; ++k) wc[k] = (!is_ap && c < W && k < fp) ? w_pp[(int64_t)k * H2 + h2] : 0.f;
-    const float bias = c >= W ? 0.f : (is_ap ? (b_ap ? b_ap[c] : 0.f) : (b_pp ? b_pp[h2] : 0.f));
-    for (int64_t p = wave; p < n_pairs; p += n_waves) {
-      float o;
-      if (is_ap) {
-        const int i = atom_to_pair[2 * p], j = atom_to_pair[2 * p + 1];
-        const float ij = u[(int64_t)i * lduv + c] + v[(int64_t)j * lduv + c] + bias;
-        const float ji = u[(int64_t)j * lduv + c] + v[(int64_t)i * lduv + c] + bias;
-        o = (ij > 0.f ? ij : 0.f) + (ji > 0.f ? ji : 0.f);
-      } else {
+    for (int k = 0; k < FP; ++k) wc[k] = (ok && k < fp) ? w_pp[(int64_t)k * H2 + h2] : 0.f;
+    const float bias = (ok && b_pp) ? b_pp[h2] : 0.f;
+    for (int64_t p0 = wave * R; p0 < n_pairs; p0 += n_waves * R) {
+      float t[R];
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        const int64_t p = p0 + q < n_pairs ? p0 + q : p0;
         const float* row = pf + p * ldp;
-        float t = bias;
+        t[q] = bias;
 #pragma unroll
         for (int k = 0; k < FP; ++k)
-          if (k < fp) t = fmaf(row[k], wc[k], t);
-        o = t > 0.f ? t : 0.f;
+          if (k < fp) t[q] = fmaf(row[k], wc[k], t[q]);
       }
-      if (c < W) z[p * ldz + c] = o;
+#pragma unroll
+      for (int q = 0; q < R; ++q)
+        if (ok && p0 + q < n_pairs) z[(p0 + q) * ldz + H + h2] = t[q] > 0.f ? t[q] : 0.f;
     }
   }
 }
@@ -123,48 +164,56 @@ __constant__ float kGaussMu[11] = {-1.645f, -1.080f, -0.739f, -0.468f, -0.228f, 
 __constant__ float kGaussSigma[11] = {0.283f, 0.170f, 0.134f, 0.118f, 0.114f, 0.114f,
                                       0.114f, 0.118f, 0.134f, 0.170f, 0.283f};
 
-// one wave per molecule at a time, lane = feature column; the 11 bin sums stay in registers
+// one wave per (molecule, 64-column chunk), lane = feature column; the 11 bin sums stay in registers.
+// Normal(mu, sigma).log_prob(x).exp() / (its value at mu) == exp(-(x-mu)^2 / (2 sigma^2)): the
+// normalisation constants of the reference cancel (difference ~1 ulp).
 __global__ void __launch_bounds__(kWvBlock)
 weave_gather_kernel(const float* __restrict__ x, int64_t ldx, int n_feat, const int32_t* __restrict__ mol_ptr,
                     int n_mols, int expand, float* __restrict__ out, int64_t ldo) {
   const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * kWvBlock + threadIdx.x) >> 6;
-  const int n_waves = (gridDim.x * kWvBlock) >> 6;
-  for (int m = wave; m < n_mols; m += n_waves) {
+  const int64_t wave = ((int64_t)blockIdx.x * kWvBlock + threadIdx.x) >> 6;
+  const int64_t n_waves = ((int64_t)gridDim.x * kWvBlock) >> 6;
+  const int chunks = (n_feat + 63) / 64;
+  float inv2var[11];
+#pragma unroll
+  for (int k = 0; k < 11; ++k) inv2var[k] = 1.f / (2.f * kGaussSigma[k] * kGaussSigma[k]);
+  for (int64_t job = wave; job < (int64_t)n_mols * chunks; job += n_waves) {
+    const int m = (int)(job / chunks);
+    const int f = (int)(job - (int64_t)m * chunks) * 64 + lane;
     const int a0 = mol_ptr[m], a1 = mol_ptr[m + 1];
-    for (int f0 = 0; f0 < n_feat; f0 += 64) {
-      const int f = f0 + lane;
-      float acc[11];
+    float acc[11];
 #pragma unroll
-      for (int k = 0; k < 11; ++k) acc[k] = 0.f;
-      if (f < n_feat) {
-        for (int a = a0; a < a1; ++a) {
-          const float xv = x[(int64_t)a * ldx + f];
-          if (expand) {
-            float g[11], tot = 0.f;
-#pragma unroll
-            for (int k = 0; k < 11; ++k) {
-              // Normal(mu, sigma).log_prob(x).exp() / (its value at mu), as the reference computes it
-              const float var = kGaussSigma[k] * kGaussSigma[k];
-              const float logs = logf(kGaussSigma[k]);
-              const float d = xv - kGaussMu[k];
-              const float lp = -(d * d) / (2.f * var) - logs - 0.91893853320467274178f;
-              const float lp0 = -logs - 0.91893853320467274178f;
-              g[k] = expf(lp) / expf(lp0);
-              tot += g[k];
-            }
-#pragma unroll
-            for (int k = 0; k < 11; ++k) acc[k] += g[k] / tot;
-          } else {
-            acc[0] += xv;
-          }
-        }
+    for (int k = 0; k < 11; ++k) acc[k] = 0.f;
+    if (f < n_feat) {
+      for (int a = a0; a < a1; a += 2) {
+        const bool two = a + 1 < a1;
+        const float x0 = x[(int64_t)a * ldx + f];
+        const float x1 = x[(int64_t)(two ? a + 1 : a) * ldx + f];
         if (expand) {
+          float g0[11], g1[11], t0 = 0.f, t1 = 0.f;
 #pragma unroll
-          for (int k = 0; k < 11; ++k) out[(int64_t)m * ldo + (int64_t)f * 11 + k] = acc[k];
+          for (int k = 0; k < 11; ++k) {
+            const float d0 = x0 - kGaussMu[k], d1 = x1 - kGaussMu[k];
+            g0[k] = expf(-(d0 * d0) * inv2var[k]);
+            g1[k] = expf(-(d1 * d1) * inv2var[k]);
+            t0 += g0[k];
+            t1 += g1[k];
+          }
+#pragma unroll
+          for (int k = 0; k < 11; ++k) {
+            acc[k] += g0[k] / t0;
+            if (two) acc[k] += g1[k] / t1;
+          }
         } else {
-          out[(int64_t)m * ldo + f] = acc[0];
+          acc[0] += x0;
+          if (two) acc[0] += x1;
         }
+      }
+      if (expand) {
+#pragma unroll
+        for (int k = 0; k < 11; ++k) out[(int64_t)m * ldo + (int64_t)f * 11 + k] = acc[k];
+      } else {
+        out[(int64_t)m * ldo + f] = acc[0];
       }
     }
   }
@@ -195,22 +244,30 @@ int gcmi_fold_affine(const float* d_w, const float* d_b, const float* d_scale, c
   return GCMI_OK;
 }
 
-int gcmi_weave_pair_to_atom(const float* d_pair_feat, int64_t ldp, int32_t n_pair_feat, const int32_t* d_pair_ptr,
-                            int32_t n_atoms, const float* d_w, const float* d_b, int32_t n_hidden, float* d_out,
-                            int64_t ldo, void* stream) {
-  GCMI_CHECK_ARG(n_atoms >= 0 && n_pair_feat > 0 && n_pair_feat <= kMaxFp && n_hidden > 0 && ldp >= n_pair_feat &&
-                     ldo >= n_hidden,
+int gcmi_weave_pair_to_atom(const float* d_pair_feat, int64_t ldp, int32_t n_pair_feat, const int32_t* d_pair_src,
+                            int64_t n_pairs, int32_t n_atoms, const float* d_w, const float* d_b, int32_t n_hidden,
+                            float* d_out, int64_t ldo, void* stream) {
+  GCMI_CHECK_ARG(n_atoms >= 0 && n_pairs >= 0 && n_pair_feat > 0 && n_pair_feat <= kMaxFp && n_hidden > 0 &&
+                     ldp >= n_pair_feat && ldo >= n_hidden,
                  "weave_pair_to_atom: bad shape (pair features <= %d)", kMaxFp);
   if (n_atoms == 0) return GCMI_OK;
-  GCMI_CHECK_ARG(d_pair_ptr && d_w && d_out, "weave_pair_to_atom: NULL buffer");
-  const int grid = grid_for((int64_t)n_atoms * 64, kWvBlock);
+  GCMI_CHECK_ARG(d_w && d_out && (n_pairs == 0 || (d_pair_src && d_pair_feat)), "weave_pair_to_atom: NULL buffer");
   hipStream_t st = (hipStream_t)stream;
+  if (hipMemset2DAsync(d_out, sizeof(float) * (size_t)ldo, 0, sizeof(float) * (size_t)n_hidden, (size_t)n_atoms, st) !=
+      hipSuccess) {
+    (void)hipGetLastError();
+    set_error("weave_pair_to_atom: memset failed");
+    return GCMI_ERR_LAUNCH;
+  }
+  if (n_pairs == 0) return GCMI_OK;
+  const int64_t blocks = (n_pairs + kP2aPairs - 1) / kP2aPairs;
+  GCMI_CHECK_ARG(blocks < (1LL << 31), "weave_pair_to_atom: too many pairs");
   if (n_pair_feat <= 16)
-    hipLaunchKernelGGL(pair_to_atom_kernel<16>, dim3(grid), dim3(kWvBlock), 0, st, d_pair_feat, ldp, n_pair_feat,
-                       d_pair_ptr, n_atoms, d_w, d_b, n_hidden, d_out, ldo);
+    hipLaunchKernelGGL(pair_to_atom_kernel<16>, dim3((unsigned)blocks), dim3(kWvBlock), 0, st, d_pair_feat, ldp,
+                       n_pair_feat, d_pair_src, n_pairs, d_w, d_b, n_hidden, d_out, ldo);
   else
-    hipLaunchKernelGGL(pair_to_atom_kernel<kMaxFp>, dim3(grid), dim3(kWvBlock), 0, st, d_pair_feat, ldp,
-                       n_pair_feat, d_pair_ptr, n_atoms, d_w, d_b, n_hidden, d_out, ldo);
+    hipLaunchKernelGGL(pair_to_atom_kernel<kMaxFp>, dim3((unsigned)blocks), dim3(kWvBlock), 0, st, d_pair_feat, ldp,
+                       n_pair_feat, d_pair_src, n_pairs, d_w, d_b, n_hidden, d_out, ldo);
   GCMI_CHECK_LAUNCH("weave_pair_to_atom");
   return GCMI_OK;
 }
@@ -246,7 +303,8 @@ int gcmi_weave_gather(const float* d_x, int64_t ldx, int32_t n_feat, const int32
                  "weave_gather: bad shape");
   if (n_mols == 0) return GCMI_OK;
   GCMI_CHECK_ARG(d_x && d_mol_ptr && d_out, "weave_gather: NULL buffer");
-  hipLaunchKernelGGL(weave_gather_kernel, dim3(grid_for((int64_t)n_mols * 64, kWvBlock)), dim3(kWvBlock), 0,
+  hipLaunchKernelGGL(weave_gather_kernel, dim3(grid_for((int64_t)n_mols * ((n_feat + 63) / 64) * 64, kWvBlock)),
+                     dim3(kWvBlock), 0,
                      (hipStream_t)stream, d_x, ldx, n_feat, d_mol_ptr, n_mols, gaussian_expand, d_out, ldo);
   GCMI_CHECK_LAUNCH("weave_gather");
   return GCMI_OK;

@@ -45,20 +45,31 @@ class EdgeNetwork(nn.Module):
         return (f'{self.__class__.__name__}(n_pair_features:{self.n_pair_features},n_hidden:{self.n_hidden},'
                 f'init:{self.init})')
 
+    def _plan(self, atom_to_pair, n_pairs: int, n_atoms: int):
+        """(CSR over the pairs by first atom, second atoms) on the device; the T message-passing rounds
+        of a model pass the same index array, so the last plan is kept."""
+        cached = getattr(self, "_last_plan", None)
+        if cached is not None and cached[0] is atom_to_pair and cached[1] == (n_pairs, n_atoms):
+            return cached[2], cached[3]
+        a2p = _host_i64(atom_to_pair).reshape(-1, 2)
+        if a2p.shape[0] != n_pairs:
+            raise ValueError("atom_to_pair does not match the %d pairs" % n_pairs)
+        if a2p.size and (a2p.min() < 0 or a2p.max() >= n_atoms):
+            raise ValueError("atom_to_pair refers to atoms outside [0, %d)" % n_atoms)
+        n_dst = int(a2p[:, 0].max()) + 1 if a2p.size else 0
+        dst_ptr = torch.from_numpy(_csr_from_sorted(a2p[:, 0], n_dst, "atom_to_pair[:, 0]")).to(self.device)
+        src = torch.from_numpy(a2p[:, 1].astype(np.int32)).to(self.device)
+        self._last_plan = (atom_to_pair, (n_pairs, n_atoms), dst_ptr, src)
+        return dst_ptr, src
+
     def forward(self, inputs: List) -> torch.Tensor:
         """inputs = [pair_features, atom_features, atom_to_pair] -> (n_atoms_with_pairs, n_hidden)."""
         pf = _dev_f32(inputs[0], self.device)
         h = _dev_f32(inputs[1], self.device)
-        a2p = _host_i64(inputs[2]).reshape(-1, 2)
         d, K = self.n_hidden, self.n_pair_features
-        if pf.shape[1] != K or h.shape[1] != d or a2p.shape[0] != pf.shape[0]:
-            raise ValueError("EdgeNetwork: shapes do not match (pairs %s, atoms %s, atom_to_pair %s)" %
-                             (tuple(pf.shape), tuple(h.shape), a2p.shape))
-        if a2p.size and (a2p.min() < 0 or a2p.max() >= h.shape[0]):
-            raise ValueError("atom_to_pair refers to atoms outside [0, %d)" % h.shape[0])
-        n_dst = int(a2p[:, 0].max()) + 1 if a2p.size else 0
-        dst_ptr = torch.from_numpy(_csr_from_sorted(a2p[:, 0], n_dst, "atom_to_pair[:, 0]")).to(self.device)
-        src = torch.from_numpy(a2p[:, 1].astype(np.int32)).to(self.device)
+        if pf.shape[1] != K or h.shape[1] != d:
+            raise ValueError("EdgeNetwork: shapes do not match (pairs %s, atoms %s)" % (tuple(pf.shape), tuple(h.shape)))
+        dst_ptr, src = self._plan(inputs[2], pf.shape[0], h.shape[0])
         # G = h . [W_0^T | ... | W_{K-1}^T | B^T]: W (K, d*d) read in place as a (K*d, d) nn.Linear-layout matrix
         W = self.W.detach().to(self.device, torch.float32).contiguous()
         b = self.b.detach().to(self.device, torch.float32).contiguous()

@@ -45,6 +45,40 @@ def _csr_from_sorted(ids: np.ndarray, n: int, what: str) -> np.ndarray:
     return ptr.astype(np.int32)
 
 
+class _PairPlan:
+    """Device copies of the pair index arrays of one batch (validated once)."""
+
+    def __init__(self, pair_split, atom_to_pair, n_atoms: int, device):
+        ps = _host_i64(pair_split)
+        a2p = _host_i64(atom_to_pair).reshape(-1, 2)
+        n_pairs = ps.shape[0]
+        if a2p.shape[0] != n_pairs:
+            raise ValueError("pair_split / atom_to_pair do not match (%d vs %d pairs)" % (n_pairs, a2p.shape[0]))
+        if n_pairs and (a2p.min() < 0 or a2p.max() >= n_atoms):
+            raise ValueError("atom_to_pair refers to atoms outside [0, %d)" % n_atoms)
+        if n_pairs and (np.any(np.diff(ps) < 0) or ps[0] < 0 or ps[-1] >= n_atoms):
+            raise ValueError("pair_split must be ascending and inside [0, %d)" % n_atoms)
+        if n_atoms and np.bincount(ps, minlength=n_atoms).min() == 0:
+            raise ValueError("every atom needs at least one pair (its self pair)")  # reference: shape error at the concat
+        self.n_pairs, self.n_atoms = n_pairs, n_atoms
+        self.pair_src = torch.from_numpy(ps.astype(np.int32)).to(device)
+        self.a2p = torch.from_numpy(a2p.astype(np.int32)).to(device).contiguous().view(-1)
+
+
+_plan_cache = []  # [(pair_split object, atom_to_pair object, n_atoms, plan)], newest first
+
+
+def _pair_plan(pair_split, atom_to_pair, n_atoms: int, device) -> _PairPlan:
+    """The stacked layers of a model receive the same index arrays: build their device form once."""
+    for ps, ap, n, plan in _plan_cache:
+        if ps is pair_split and ap is atom_to_pair and n == n_atoms and plan.pair_src.device == device:
+            return plan
+    plan = _PairPlan(pair_split, atom_to_pair, n_atoms, device)
+    _plan_cache.insert(0, (pair_split, atom_to_pair, n_atoms, plan))
+    del _plan_cache[2:]
+    return plan
+
+
 def _require_relu(activation: str, what: str):
     if activation != 'relu':
         raise GcmiError("%s: only activation='relu' has a kernel (got %r)" % (what, activation))
@@ -123,21 +157,15 @@ class WeaveLayer(nn.Module):
         """inputs = [atom_features, pair_features, pair_split, atom_to_pair] -> [A, P]."""
         A = _dev_f32(inputs[0], self.device)
         Pf = _dev_f32(inputs[1], self.device)
-        pair_split = _host_i64(inputs[2])
-        a2p_host = _host_i64(inputs[3]).reshape(-1, 2)
         n_atoms, n_pairs = A.shape[0], Pf.shape[0]
-        if pair_split.shape[0] != n_pairs or a2p_host.shape[0] != n_pairs:
+        plan = _pair_plan(inputs[2], inputs[3], n_atoms, self.device)
+        if plan.n_pairs != n_pairs:
             raise ValueError("pair_split / atom_to_pair do not match the %d pairs" % n_pairs)
-        if n_pairs and (a2p_host.min() < 0 or a2p_host.max() >= n_atoms):
-            raise ValueError("atom_to_pair refers to atoms outside [0, %d)" % n_atoms)
-        pair_ptr = torch.from_numpy(_csr_from_sorted(pair_split, n_atoms, "pair_split")).to(self.device)
-        if n_pairs and int((pair_ptr[1:] - pair_ptr[:-1]).min()) == 0:
-            raise ValueError("every atom needs at least one pair (its self pair)")  # reference: shape error at the concat
 
         w, b = self._folded(self.W_AA, self.b_AA, self.AA_bn)
         AA = self._linear(A, w, b, True)
         w, b = self._folded(self.W_PA, self.b_PA, self.PA_bn)
-        PA = ops.weave_pair_to_atom(Pf, pair_ptr, w, b)
+        PA = ops.weave_pair_to_atom(Pf, plan.pair_src, n_atoms, w, b)
         w, b = self._folded(self.W_A, self.b_A, self.A_bn)
         A_out = self._linear(AA, w[:self.n_hidden_AA].contiguous(), b, True, PA, w[self.n_hidden_AA:].contiguous())
         if not self.update_pair:
@@ -147,8 +175,7 @@ class WeaveLayer(nn.Module):
         U = self._linear(A, w[:Fa].contiguous(), None, False)
         V = self._linear(A, w[Fa:].contiguous(), None, False)
         w_pp, b_pp = self._folded(self.W_PP, self.b_PP, self.PP_bn)
-        a2p = torch.from_numpy(a2p_host.astype(np.int32)).to(self.device).contiguous().view(-1)
-        Z = ops.weave_pair_features(U, V, b_ap, Pf, w_pp, b_pp, a2p)
+        Z = ops.weave_pair_features(U, V, b_ap, Pf, w_pp, b_pp, plan.a2p)
         w, b = self._folded(self.W_P, self.b_P, self.P_bn)
         P_out = self._linear(Z, w, b, True)
         return [A_out, P_out]

@@ -325,15 +325,14 @@ def _i32vec(t: torch.Tensor, name: str, n: Optional[int] = None) -> torch.Tensor
     return t
 
 
-def weave_pair_to_atom(pair_feat: torch.Tensor, pair_ptr: torch.Tensor, w: torch.Tensor, b: torch.Tensor):
-    """sum over the pairs of every source atom of relu(pair_feat . w + b)."""
+def weave_pair_to_atom(pair_feat: torch.Tensor, pair_src: torch.Tensor, n_atoms: int, w: torch.Tensor, b: torch.Tensor):
+    """sum over the pairs of every source atom (pair_src ascending) of relu(pair_feat . w + b)."""
     pf = _mat(pair_feat, "pair_feat")
     w = _mat(w, "w", rows=pf.shape[1])
-    n_atoms = pair_ptr.numel() - 1
     H = w.shape[1]
     out = torch.empty((n_atoms, H), dtype=torch.float32, device=pf.device)
-    _lib.call("gcmi_weave_pair_to_atom", _ptr(pf), _ld(pf), pf.shape[1], _ptr(_i32vec(pair_ptr, "pair_ptr")),
-              n_atoms, _ptr(w), _ptr(_vec(b, "b", H)), H, _ptr(out), _ld(out), _stream())
+    _lib.call("gcmi_weave_pair_to_atom", _ptr(pf), _ld(pf), pf.shape[1], _ptr(_i32vec(pair_src, "pair_src", pf.shape[0])),
+              pf.shape[0], n_atoms, _ptr(w), _ptr(_vec(b, "b", H)), H, _ptr(out), _ld(out), _stream())
     return out
 
 

@@ -270,8 +270,8 @@ int gcmi_relu_bwd(float* d_g, int64_t ldg, const float* d_y, int64_t ldy, int64_
  * with scale/shift from gcmi_bn_fold_eval.
  *
  * gcmi_weave_pair_to_atom (layers.py:4366-4387): PA = relu(Pf . W + b) summed over the pairs of
- *   every source atom; pairs are listed source by source (pair_split ascending), d_pair_ptr
- *   [n_atoms + 1] is the CSR of that listing.  out [n_atoms x n_hidden].
+ *   every source atom; d_pair_src [n_pairs] int32 = pair_split (ascending: pairs are listed source
+ *   by source).  out [n_atoms x n_hidden] (zeroed here, float atomics, one per column and atom).
  * gcmi_weave_pair_features (layers.py:4397-4424): per ordered pair p = (i, j)
  *     z[p, 0:Hap]       = relu(U[i] + V[j] + b_ap) + relu(U[j] + V[i] + b_ap)
  *     z[p, Hap:Hap+Hpp] = relu(Pf[p] . W_pp + b_pp)
@@ -283,9 +283,9 @@ int gcmi_relu_bwd(float* d_g, int64_t ldg, const float* d_y, int64_t ldy, int64_
  * gcmi_tanh_: in-place tanh (final_conv_activation_fn of the Weave model).                      */
 int gcmi_fold_affine(const float* d_w, const float* d_b, const float* d_scale, const float* d_shift, int32_t k,
                      int32_t n, int32_t trans_w, float* d_w_out, float* d_b_out, void* stream);
-int gcmi_weave_pair_to_atom(const float* d_pair_feat, int64_t ldp, int32_t n_pair_feat, const int32_t* d_pair_ptr,
-                            int32_t n_atoms, const float* d_w, const float* d_b, int32_t n_hidden, float* d_out,
-                            int64_t ldo, void* stream);
+int gcmi_weave_pair_to_atom(const float* d_pair_feat, int64_t ldp, int32_t n_pair_feat, const int32_t* d_pair_src,
+                            int64_t n_pairs, int32_t n_atoms, const float* d_w, const float* d_b, int32_t n_hidden,
+                            float* d_out, int64_t ldo, void* stream);
 int gcmi_weave_pair_features(const float* d_u, const float* d_v, int64_t lduv, int32_t n_hidden_ap,
                              const float* d_b_ap, const float* d_pair_feat, int64_t ldp, int32_t n_pair_feat,
                              const float* d_w_pp, const float* d_b_pp, int32_t n_hidden_pp,
