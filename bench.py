@@ -179,11 +179,18 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU implementation)")
     import torch.distributed as dist
-    if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    device = torch.device("cuda", local_rank if world > 1 else 0)
+    # one rank per GPU over RCCL.  GCMI_BENCH_BACKEND=gloo is a rehearsal switch for boxes with fewer
+    # GPUs than ranks (ranks then share devices round-robin; the numbers mean nothing, the code path
+    # -- parameter broadcast, flat-bucket all-reduce, barriers, max over ranks -- is the real one)
+    backend = os.environ.get("GCMI_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if world > 1 else 0
+    device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from deepchem_amd import ops
     from deepchem_amd._lib import (K_GATHER_MAX, K_GATHER_MAX_BWD, K_GATHER_SUM, K_READOUT, K_SEG_GEMM,
