@@ -147,11 +147,13 @@ _SIGNATURES = {
     "gcmi_diag_mfma_peak": [c_int32, c_int32, _P, _P],
     "gcmi_set_option": [c_int32, c_int32],
     "gcmi_get_option": [c_int32, _I32P],
+    "gcmi_smiles_sizes": [_P, c_int64, _I32P, _I32P, ctypes.c_int],
+    "gcmi_smiles_featurize": [_P, c_int64, _I64P, _I64P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int],
     "gcmi_timing_enable": [c_int32, c_int32],
     "gcmi_timing_read": [c_int32, _I64P, POINTER(c_double), c_int32],
 }
 
-EXPORTS = ["gcmi_version", "gcmi_last_error", "gcmi_model_workspace_floats"] + sorted(_SIGNATURES)
+EXPORTS = ["gcmi_version", "gcmi_last_error", "gcmi_model_workspace_floats", "gcmi_smiles_check"] + sorted(_SIGNATURES)
 
 _lib = None
 
@@ -186,6 +188,8 @@ def load():
     lib.gcmi_last_error.restype = c_char_p
     lib.gcmi_model_workspace_floats.restype = c_int64
     lib.gcmi_model_workspace_floats.argtypes = [_MD, c_int64, c_int64]
+    lib.gcmi_smiles_check.restype = c_char_p
+    lib.gcmi_smiles_check.argtypes = [c_char_p]
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = argtypes

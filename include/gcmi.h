@@ -316,6 +316,34 @@ int gcmi_set2set_attend(const float* d_x, int64_t ldx, int32_t n_feat, const int
 int gcmi_lstm_cell(const float* d_z, int64_t ldz, int32_t n_hidden, int64_t n_rows, float* d_c, int64_t ldc,
                    float* d_h, int64_t ldh, void* stream);
 
+/* ---------------------------------------------------------------- SMILES featurization (host)
+ * What the reference computes in Python per rdkit Mol, for SMILES input:
+ *   atom_features feat/graph_features.py:282-391 (75 columns), bond_features :394-459 (6), pair_features +
+ *   find_distance :532-695 (14, all pairs), ConvMolFeaturizer._featurize :845-914, WeaveFeaturizer._featurize
+ *   :1037-1078; a molecule that cannot be read is skipped like MolecularFeaturizer.featurize does
+ *   (feat/base_classes.py:254-330).  Atoms keep their order of appearance in the SMILES.
+ * Two passes so that the caller owns all memory:
+ *   gcmi_smiles_sizes      n_atoms[i] / n_bonds[i] of every molecule; n_atoms[i] = -1 when it cannot be read.
+ *   gcmi_smiles_featurize  atom_off/bond_off (n+1 prefix sums of those sizes, 0 for rejected molecules) and,
+ *                          when pair_features is given, pair_off (prefix sums of n_atoms^2).  Every output may
+ *                          be NULL:  atom_features [A][75], adj_degree [A], adj_idx [2B] (neighbours LOCAL to
+ *                          the molecule, per atom in bond order: together with adj_degree the CSR the collation
+ *                          entry points read), bond_atoms [B][2], bond_features [B][6], pair_features
+ *                          [sum n^2][14] (row a1*n+a2), atom_props [A][8] = atomic number, degree, implicit H,
+ *                          explicit H, charge, radical electrons, hybridisation (0 unspecified, 1 S, 2 SP,
+ *                          3 SP2, 4 SP3, 5 SP3D, 6 SP3D2), aromatic.
+ *   gcmi_smiles_check      NULL when the SMILES can be read, else a static reason string.
+ * n_threads worker threads; results do not depend on it.                                                   */
+#define GCMI_ATOM_FEATURES 75
+#define GCMI_BOND_FEATURES 6
+#define GCMI_PAIR_FEATURES 14
+int gcmi_smiles_sizes(const char* const* smiles, int64_t n, int32_t* n_atoms, int32_t* n_bonds, int n_threads);
+int gcmi_smiles_featurize(const char* const* smiles, int64_t n, const int64_t* atom_off, const int64_t* bond_off,
+                          const int64_t* pair_off, float* atom_features, int32_t* adj_degree, int32_t* adj_idx,
+                          int32_t* bond_atoms, float* bond_features, float* pair_features, int32_t* atom_props,
+                          int n_threads);
+const char* gcmi_smiles_check(const char* smiles);
+
 /* ---------------------------------------------------------------- loss
  * SoftmaxCrossEntropy (models/losses.py:251-259) / L2Loss (:85-94) through
  * _StandardLoss (models/torch_models/torch_model.py:1275-1294):

@@ -1,0 +1,194 @@
+"""Native SMILES featurizer (csrc/featurize.cpp through deepchem_amd.feat) against its oracle
+(oracle/smiles_oracle.py) and the reference's known answers.  Host code only: no GPU needed."""
+import os
+
+import numpy as np
+import pytest
+
+import deepchem_amd as dc
+from deepchem_amd.feat import graph_features as gf
+from oracle import smiles_oracle as so
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+HAND_PICKED = [
+    "C", "CCC", "C[N+](C)(C)C", "c1ccccc1", "C1=CC=CC=C1", "CC(=O)O", "CC#N", "c1ccncc1", "c1cc[nH]c1", "Cn1cccc1",
+    "c1ccsc1", "c1ccoc1", "O=c1cccc[nH]1", "c1ccc2ccccc2c1", "c1ccccc1c1ccccc1", "c1ccccc1-c1ccccc1", "C1CC2CCC1C2",
+    "[Na+].[Cl-]", "CC(=O)Nc1ccccc1", "[O-][N+](=O)c1ccccc1", "CN(=O)=O", "c1ccc2cccc2cc1", "C12C3C4C1C5C2C3C45",
+    "[H]C([H])([H])O", "OS(=O)(=O)O", "[CH3]", "Clc1ccccc1", "Oc1ccccc1", "C=CC=C", "C1CC2CCC1CC2", "C1CC2CC1C2",
+    "C1C2CC3CC1CC(C2)C3", "C1CC1C1CC1", "C1CCC2(CC1)CCCC2", "[cH-]1cccc1", "c1cc[nH+]cc1", "C1=CCC=C1",
+    "C1=CC=CC=CC=C1", "OCl(=O)(=O)=O", "CN=N#N", "C=P(=O)(C)C", "Nc1cc(nc(N)n1=O)N2CCCCC2", "F/C=C/F", "F\\C=C\\F",
+    "N[C@@H](C)C(=O)O", "[13CH4]", "[2H]O[2H]", "[H][H]", "[H+]", "C%10CCCC%10", "[Fe+2]", "[Zn]", "[U]", "[Se]=C",
+    "c1cc[se]c1", "O=C1C=CC(=O)C=C1", "c1ccc2c(c1)[nH]c1ccccc12", "c1ccc2c(c1)Cc1ccccc1-2", "C1=CC2=CC=CC2=C1",
+    "CC(C)(C)c1ccc(O)cc1", "OC1CC1", "CCCCCCCCC", "B(O)O", "[B-](F)(F)(F)F", "[NH4+]", "[O-2]", "S=C=S", "C=C=C",
+    "[Si](C)(C)(C)C", "P(=O)(O)(O)O", "CS(=O)C", "CS(=O)(=O)C", "c1ccc2c(c1)ccc1ccccc12", "c1cc2ccc3cccc4ccc(c1)c2c34",
+    "O=C(O)c1ccccc1OC(C)=O", "CN1C=NC2=C1C(=O)N(C(=O)N2C)C", "Cn1cnc2c1c(=O)n(C)c(=O)n2C", "[n+]1(C)ccccc1",
+    "C[n+]1ccccc1", "c1ccc[o+]c1", "c1ncc[nH]1", "c1cnc[nH]1", "c1nnn[nH]1", "C1=COC=C1", "c1ccc2[nH]ccc2c1",
+    "II", "IC(I)I", "I(=O)(=O)c1ccccc1", "[Li]CCCC", "[Mg](Cl)Cl", "[Al](C)(C)C", "C[Sn](C)(C)C", "[Hg](C)C",
+]
+
+UNREADABLE = ["c1cccc1", "C(C)(C)(C)(C)C", "C1CC", "C(", "c1ccccc1)", "", "[Xx]", "cC", "C%1CC%1", "C=", "=C",
+              "C..C(", "[C", "C11", "CC(C)(C)(C)(C)(C)(C)(C)(C)(C)(C)C", "X", "[CH2:x]", "c1ccccc1c"]
+
+
+def _check_against_oracle(smiles):
+    r = gf.read_smiles(smiles, bonds=True, pairs=True, props=True, n_threads=3)
+    n_valid = 0
+    for i, s in enumerate(smiles):
+        try:
+            nodes, pairs, edges = so.weave_mol_arrays(s)
+        except so.SmilesError:
+            assert not r["valid"][i], (s, "oracle rejects, native accepts")
+            assert r["n_atoms"][i] == 0 and r["n_bonds"][i] == 0
+            continue
+        assert r["valid"][i], (s, gf.why_unreadable(s))
+        n_valid += 1
+        a0, a1 = r["atom_off"][i], r["atom_off"][i + 1]
+        np.testing.assert_array_equal(r["atom_features"][a0:a1], nodes.astype(np.float32), err_msg=s)
+        np.testing.assert_array_equal(r["pair_features"][r["pair_off"][i]:r["pair_off"][i + 1]],
+                                      pairs.astype(np.float32), err_msg=s)
+        mol = so.mol_from_smiles(s)
+        b0, b1 = r["bond_off"][i], r["bond_off"][i + 1]
+        assert b1 - b0 == len(mol.bonds)
+        for k, b in enumerate(mol.bonds):
+            assert tuple(r["bond_atoms"][b0 + k]) == (b.a, b.b)
+            np.testing.assert_array_equal(r["bond_features"][b0 + k], so.bond_features(b).astype(np.float32))
+        # adjacency: neighbours of every atom in bond order
+        _, adj = so.conv_mol_arrays(s)
+        deg = r["adj_degree"][a0:a1]
+        assert deg.tolist() == [len(x) for x in adj]
+        flat = r["adj_idx"][2 * b0:2 * b1]
+        assert flat.tolist() == [x for nb in adj for x in nb]
+        hyb = ["UNSPECIFIED", "S", "SP", "SP2", "SP3", "SP3D", "SP3D2"]
+        for k, a in enumerate(mol.atoms):
+            p = r["atom_props"][a0 + k]
+            assert (p[0], p[1], p[2], p[3], p[4], p[5], hyb[p[6]], bool(p[7])) == \
+                (a.z, mol.degree(k), a.implicit_h, a.explicit_h, a.charge, a.radicals, a.hybridization, a.aromatic), s
+    return n_valid
+
+
+def test_hand_picked_molecules_equal_the_oracle():
+    assert _check_against_oracle(HAND_PICKED) == len(HAND_PICKED)
+
+
+def test_unreadable_molecules_are_rejected_by_both():
+    assert _check_against_oracle(UNREADABLE) == 0
+    for s in UNREADABLE:
+        assert gf.why_unreadable(s)
+    assert gf.why_unreadable("CCO") is None
+
+
+def test_dataset_sample_equals_the_oracle():
+    with open(os.path.join(HERE, "golden", "smiles_sample.txt")) as f:
+        smiles = [l.strip() for l in f if l.strip() and not l.startswith("#")]
+    assert len(smiles) == 400
+    assert _check_against_oracle(smiles) == 400
+
+
+def test_thread_count_does_not_change_results():
+    with open(os.path.join(HERE, "golden", "smiles_sample.txt")) as f:
+        smiles = [l.strip() for l in f if l.strip() and not l.startswith("#")] + UNREADABLE
+    a = gf.read_smiles(smiles, bonds=True, pairs=True, props=True, n_threads=1)
+    b = gf.read_smiles(smiles, bonds=True, pairs=True, props=True, n_threads=7)
+    assert a.keys() == b.keys()
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k])
+
+
+def test_convmol_featurizer_reference_known_answers():
+    """feat/tests/test_graph_features.py:14-104."""
+    f = dc.feat.ConvMolFeaturizer()
+    mol = f.featurize(["C[N+](C)(C)C"])[0]
+    assert mol.get_num_atoms() == 5
+    lists = mol.get_deg_adjacency_lists()
+    assert np.array_equal(lists[0], np.zeros([0, 0], dtype=np.int32))
+    assert np.array_equal(lists[1], np.array([[4], [4], [4], [4]], dtype=np.int32))
+    assert np.array_equal(lists[2], np.zeros([0, 2], dtype=np.int32))
+    assert np.array_equal(lists[3], np.zeros([0, 3], dtype=np.int32))
+    assert np.array_equal(lists[4], np.array([[0, 1, 2, 3]], dtype=np.int32))
+    assert np.array_equal(lists[5], np.zeros([0, 5], dtype=np.int32))
+    assert np.array_equal(lists[6], np.zeros([0, 6], dtype=np.int32))
+    mol = f.featurize("C")[0]
+    assert mol.get_num_atoms() == 1
+    lists = mol.get_deg_adjacency_lists()
+    assert np.array_equal(lists[0], np.zeros([1, 0], dtype=np.int32))
+    for d in range(1, 7):
+        assert np.array_equal(lists[d], np.zeros([0, d], dtype=np.int32))
+    mol = f.featurize(["CCC"])[0]
+    assert mol.get_num_atoms() == 3
+    lists = mol.get_deg_adjacency_lists()
+    assert np.array_equal(lists[1], np.array([[2], [2]], dtype=np.int32))
+    assert np.array_equal(lists[2], np.array([[0, 1]], dtype=np.int32))
+    assert f.feature_length() == 75
+
+
+def test_convmol_featurizer_fragments_master_atom_and_failures():
+    """feat/tests/test_graph_features.py:106-127 (one fragment per atom) and base_classes.py:318-328."""
+    smiles = ['CC(CO)Cc1ccccc1', 'CC']
+    frags = dc.feat.ConvMolFeaturizer(per_atom_fragmentation=True).featurize(smiles)
+    assert len(frags) == 2
+    assert [len(x) for x in frags] == [11, 2]
+    assert all(m.get_num_atoms() == 10 for m in frags[0])
+    out = dc.feat.ConvMolFeaturizer().featurize(["CCO", "c1cccc1", "C"])
+    assert out[0].get_num_atoms() == 3 and out[2].get_num_atoms() == 1
+    assert isinstance(out[1], np.ndarray) and out[1].size == 0
+    m = dc.feat.ConvMolFeaturizer(master_atom=True).featurize(["CCO"])[0]
+    assert m.get_num_atoms() == 4
+    # the reference links every atom TO the master atom but gives the master atom no list of its own (:905-908)
+    assert sorted(len(x) for x in m.get_adjacency_list()) == [0, 2, 2, 3]
+    with pytest.raises(NotImplementedError):
+        dc.feat.ConvMolFeaturizer(use_chirality=True)
+
+
+def test_packed_output_feeds_the_collation_like_convmol_objects():
+    smiles = ["CCO", "c1ccccc1C(=O)O", "bad(", "C", "CC(C)N"]
+    f = dc.feat.ConvMolFeaturizer()
+    packed, keep = f.featurize_packed(smiles)
+    assert keep.tolist() == [0, 1, 3, 4]
+    objs = [m for m in f.featurize(smiles) if not isinstance(m, np.ndarray)]
+    assert packed.n_mols == 4
+    for k, m in enumerate(objs):
+        feats, adj = packed.molecule(k)
+        ref = dc.feat.ConvMol(feats, adj)
+        np.testing.assert_array_equal(ref.get_atom_features(), m.get_atom_features())
+        for x, y in zip(ref.get_deg_adjacency_lists(), m.get_deg_adjacency_lists()):
+            np.testing.assert_array_equal(x, y)
+    from deepchem_amd.feat.mol_graphs import collate_packed
+    multi_a = collate_packed(packed)
+    multi_b = dc.feat.ConvMol.agglomerate_mols(objs)
+    np.testing.assert_array_equal(multi_a.get_atom_features(), multi_b.get_atom_features())
+    np.testing.assert_array_equal(multi_a.membership, multi_b.membership)
+    for x, y in zip(multi_a.get_deg_adjacency_lists(), multi_b.get_deg_adjacency_lists()):
+        np.testing.assert_array_equal(x, y)
+
+
+def test_weave_featurizer_reference_known_answers():
+    """feat/tests/test_weave.py:47-124."""
+    f = dc.feat.WeaveFeaturizer()
+    mol = f.featurize(['C'])[0]
+    assert mol.get_num_atoms() == 1 and mol.get_num_features() == 75
+    assert mol.get_pair_features().shape == (1, 14)
+    mol = f.featurize(['CCC'])[0]
+    assert mol.get_num_atoms() == 3 and mol.get_num_features() == 75
+    assert mol.get_pair_features().shape == (9, 14)
+    assert mol.get_pair_edges().shape == (2, 9)
+    mol = f.featurize(['C[N+](C)(C)C'])[0]
+    assert mol.get_num_atoms() == 5
+    assert mol.get_pair_features().shape == (25, 14)
+    with pytest.raises(ValueError):
+        dc.feat.WeaveFeaturizer(max_pair_distance=0)
+    with pytest.raises(NotImplementedError):
+        dc.feat.WeaveFeaturizer(max_pair_distance=1)
+
+
+def test_csv_loader_with_the_native_featurizer(tmp_path):
+    """The MolNet recipe (molnet/load_function/delaney_datasets.py:14-40): CSVLoader + ConvMolFeaturizer."""
+    tasks = ["measured log solubility in mols per litre"]
+    loader = dc.data.CSVLoader(tasks=tasks, feature_field="smiles", featurizer=dc.feat.ConvMolFeaturizer())
+    ds = loader.create_dataset(os.path.join(HERE, "golden", "delaney_sample.csv"), data_dir=str(tmp_path),
+                               shard_size=100)
+    assert len(ds) == 256 and ds.get_number_shards() == 3
+    assert ds.y.shape == (256, 1) and np.all(ds.w == 1)
+    assert isinstance(ds.X[0], dc.feat.ConvMol)
+    assert ds.X[0].get_atom_features().shape[1] == 75
+    assert ds.ids[0] == "c1ccsc1" or isinstance(ds.ids[0], str)
