@@ -478,7 +478,8 @@ def test_real_smiles_end_to_end_regression(tmp_path):
     tr = dc.trans.NormalizationTransformer(transform_y=True, dataset=ds)
     ds = tr.transform(ds)
     torch.manual_seed(3)
-    model = GraphConvModel(1, batch_size=64, mode='regression', grad_mode="full", dropout=0.0,
+    model = GraphConvModel(1, number_input_features=[75, 64], batch_size=64, mode='regression', grad_mode="full",
+                           dropout=0.0,
                            device=torch.device(DEV))
     model.fit(ds, nb_epoch=80)
     pred = model.predict(ds).reshape(-1)
