@@ -16,7 +16,8 @@
 namespace gcmi {
 
 constexpr int kBBlock = 256;
-constexpr int kRowsPerBlock = 512;
+constexpr int kRowsPerBlock = 512;     // smallest share of rows a workgroup takes
+constexpr int kResidentBlocks = 2048;  // 256 CUs x 8 workgroups of 256 threads
 constexpr int kReplicas = 32;  // accumulator replicas: same-address fp64 atomics serialise
 // scratch layout (doubles): [0, 2F) backward coefficient vectors (3F floats), then kReplicas blocks
 // of 2F partial sums.  The kernels that consume the partial sums zero them again, so a scratch
@@ -58,16 +59,43 @@ template <int V, int MODE>
 __global__ void __launch_bounds__(kBBlock)
 col_sums_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ x, int64_t ldx,
                 const float* __restrict__ mean, const float* __restrict__ invstd, int64_t n_rows,
-                int n_feat, int lpr, int lx, double* __restrict__ sums, ReadoutGrad rg) {
+                int64_t rows_per_block, int n_feat, int lpr, int lx, double* __restrict__ sums, ReadoutGrad rg) {
   __shared__ double red[2 * kBBlock * 4];
   const int ry = kBBlock / lx;  // row lanes
   const int ty = threadIdx.x / lx;
   const int tx = threadIdx.x - ty * lx;
-  const int64_t r_begin = (int64_t)blockIdx.x * kRowsPerBlock;
-  const int64_t r_end = (r_begin + kRowsPerBlock < n_rows) ? r_begin + kRowsPerBlock : n_rows;
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r_end = (r_begin + rows_per_block < n_rows) ? r_begin + rows_per_block : n_rows;
+  // four rows per round, the next round's loads issued before this round is added up: one row per round
+  // leaves a single 16-byte load in flight per lane and the loop runs at memory latency
+  constexpr int R = 4;
+  struct Round {
+    float av[R][V], xv[R][V];
+  };
+  auto load_round = [&](int64_t r0, int c, Round& t) {
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const int64_t r = r0 + (int64_t)u * ry;
+      const int64_t rc = r < r_end ? r : r_end - 1;  // clamped: the load is unconditional, the add is not
+      if constexpr (MODE == 2) readout_dy<V>(rg, rc, c, n_feat, t.av[u]);
+      if constexpr (V == 4) {
+        if (MODE != 2) {
+          const float4 t4 = *reinterpret_cast<const float4*>(a + rc * lda + c);
+          t.av[u][0] = t4.x; t.av[u][1] = t4.y; t.av[u][2] = t4.z; t.av[u][3] = t4.w;
+        }
+        if (MODE >= 1) {
+          const float4 u4 = *reinterpret_cast<const float4*>(x + rc * ldx + c);
+          t.xv[u][0] = u4.x; t.xv[u][1] = u4.y; t.xv[u][2] = u4.z; t.xv[u][3] = u4.w;
+        }
+      } else {
+        if (MODE != 2) t.av[u][0] = a[rc * lda + c];
+        if (MODE >= 1) t.xv[u][0] = x[rc * ldx + c];
+      }
+    }
+  };
   for (int cc0 = 0; cc0 < lpr; cc0 += lx) {  // uniform trip count: barriers inside
     const int cc = cc0 + tx;
-    const bool active = cc < lpr && ty < ry;
+    const bool active = cc < lpr && ty < ry && r_begin < r_end;
     const int c = (cc < lpr ? cc : 0) * V;
     double s1[V], s2[V];
     float mu[V], is[V];
@@ -79,44 +107,28 @@ col_sums_kernel(const float* __restrict__ a, int64_t lda, const float* __restric
       is[q] = MODE >= 1 ? invstd[c + q] : 0.f;
     }
     if (active) {
-      // four rows per round: the loads are issued together (one row per round leaves a single
-      // 16-byte load in flight per lane and the loop runs at memory latency)
-      constexpr int R = 4;
-      for (int64_t r0 = r_begin + ty; r0 < r_end; r0 += (int64_t)R * ry) {
-        float av[R][V], xv[R][V];
-        bool ok[R];
+      // MODE 2 chains three dependent loads per row (membership -> gradient row -> arg-max row): holding a
+      // second round of those in flight costs more registers than it hides latency (291 us against 203)
+      constexpr bool PREFETCH = MODE != 2;
+      Round cur, nxt;
+      const int64_t step = (int64_t)R * ry;
+      if (PREFETCH) load_round(r_begin + ty, c, cur);
+      for (int64_t r0 = r_begin + ty; r0 < r_end; r0 += step) {
+        if (!PREFETCH) load_round(r0, c, cur);
+        if (PREFETCH && r0 + step < r_end) load_round(r0 + step, c, nxt);
 #pragma unroll
         for (int u = 0; u < R; ++u) {
-          const int64_t r = r0 + (int64_t)u * ry;
-          ok[u] = r < r_end;
-          const int64_t rc = ok[u] ? r : r0;
-          if constexpr (MODE == 2) readout_dy<V>(rg, rc, c, n_feat, av[u]);
-          if constexpr (V == 4) {
-            if (MODE != 2) {
-              const float4 t4 = *reinterpret_cast<const float4*>(a + rc * lda + c);
-              av[u][0] = t4.x; av[u][1] = t4.y; av[u][2] = t4.z; av[u][3] = t4.w;
-            }
-            if (MODE >= 1) {
-              const float4 u4 = *reinterpret_cast<const float4*>(x + rc * ldx + c);
-              xv[u][0] = u4.x; xv[u][1] = u4.y; xv[u][2] = u4.z; xv[u][3] = u4.w;
-            }
-          } else {
-            if (MODE != 2) av[u][0] = a[rc * lda + c];
-            if (MODE >= 1) xv[u][0] = x[rc * ldx + c];
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < R; ++u) {
-          if (!ok[u]) continue;
+          if (r0 + (int64_t)u * ry >= r_end) continue;
 #pragma unroll
           for (int q = 0; q < V; ++q) {
-            s1[q] += (double)av[u][q];
+            s1[q] += (double)cur.av[u][q];
             if (MODE == 0)
-              s2[q] += (double)av[u][q] * (double)av[u][q];
+              s2[q] += (double)cur.av[u][q] * (double)cur.av[u][q];
             else
-              s2[q] += (double)av[u][q] * (double)((xv[u][q] - mu[q]) * is[q]);
+              s2[q] += (double)cur.av[u][q] * (double)((cur.xv[u][q] - mu[q]) * is[q]);
           }
         }
+        if (PREFETCH) cur = nxt;
       }
     }
     // combine the row lanes of this column chunk
@@ -246,19 +258,19 @@ __global__ void bn_bwd_params_kernel(double* __restrict__ sums, int64_t n_rows, 
   }
 }
 
-constexpr int kDxRows = 256;  // rows per workgroup
+constexpr int kDxRows = 256;  // smallest share of rows a workgroup takes
 
 template <int V, bool RELU, bool RD>
 __global__ void __launch_bounds__(kBBlock)
 bn_bwd_dx_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
-                 int64_t ldx, int64_t n_rows, int n_feat, int lpr, int lx,
+                 int64_t ldx, int64_t n_rows, int64_t rows_per_block, int n_feat, int lpr, int lx,
                  const float* __restrict__ coef, float* __restrict__ dx, int64_t lddx, ReadoutGrad rg) {
   const int ry = kBBlock / lx;
   const int ty = threadIdx.x / lx;
   const int tx = threadIdx.x - ty * lx;
   if (ty >= ry) return;
-  const int64_t r_begin = (int64_t)blockIdx.x * kDxRows;
-  const int64_t r_end = (r_begin + kDxRows < n_rows) ? r_begin + kDxRows : n_rows;
+  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r_end = (r_begin + rows_per_block < n_rows) ? r_begin + rows_per_block : n_rows;
   for (int cc = tx; cc < lpr; cc += lx) {
     const int c = cc * V;
     float A[V], B[V], C[V];
@@ -268,29 +280,41 @@ bn_bwd_dx_kernel(const float* __restrict__ dy, int64_t lddy, const float* __rest
       B[q] = coef[n_feat + c + q];
       C[q] = coef[2 * n_feat + c + q];
     }
-    for (int64_t r = r_begin + ty; r < r_end; r += ry) {
-      float xv[V], gv[V], o[V];
-      if constexpr (RD) readout_dy<V>(rg, r, c, n_feat, gv);
-      if constexpr (V == 4) {
-        const float4 a4 = *reinterpret_cast<const float4*>(x + r * ldx + c);
-        xv[0] = a4.x; xv[1] = a4.y; xv[2] = a4.z; xv[3] = a4.w;
-        if (!RD) {
-          const float4 b4 = *reinterpret_cast<const float4*>(dy + r * lddy + c);
-          gv[0] = b4.x; gv[1] = b4.y; gv[2] = b4.z; gv[3] = b4.w;
+    constexpr int R = 4;  // rows per round, loads issued together
+    for (int64_t r0 = r_begin + ty; r0 < r_end; r0 += (int64_t)R * ry) {
+      float xv[R][V], gv[R][V];
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const int64_t r = r0 + (int64_t)u * ry;
+        const int64_t rc = r < r_end ? r : r_end - 1;
+        if constexpr (RD) readout_dy<V>(rg, rc, c, n_feat, gv[u]);
+        if constexpr (V == 4) {
+          const float4 a4 = *reinterpret_cast<const float4*>(x + rc * ldx + c);
+          xv[u][0] = a4.x; xv[u][1] = a4.y; xv[u][2] = a4.z; xv[u][3] = a4.w;
+          if (!RD) {
+            const float4 b4 = *reinterpret_cast<const float4*>(dy + rc * lddy + c);
+            gv[u][0] = b4.x; gv[u][1] = b4.y; gv[u][2] = b4.z; gv[u][3] = b4.w;
+          }
+        } else {
+          xv[u][0] = x[rc * ldx + c];
+          if (!RD) gv[u][0] = dy[rc * lddy + c];
         }
-      } else {
-        xv[0] = x[r * ldx + c];
-        if (!RD) gv[0] = dy[r * lddy + c];
       }
 #pragma unroll
-      for (int q = 0; q < V; ++q) {
-        const float v = fmaf(A[q], gv[q], fmaf(B[q], xv[q], C[q]));
-        o[q] = (RELU && !(xv[q] > 0.f)) ? 0.f : v;
-      }
-      if constexpr (V == 4) {
-        *reinterpret_cast<float4*>(dx + r * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
-      } else {
-        dx[r * lddx + c] = o[0];
+      for (int u = 0; u < R; ++u) {
+        const int64_t r = r0 + (int64_t)u * ry;
+        if (r >= r_end) continue;
+        float o[V];
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+          const float v = fmaf(A[q], gv[u][q], fmaf(B[q], xv[u][q], C[q]));
+          o[q] = (RELU && !(xv[u][q] > 0.f)) ? 0.f : v;
+        }
+        if constexpr (V == 4) {
+          *reinterpret_cast<float4*>(dx + r * lddx + c) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+          dx[r * lddx + c] = o[0];
+        }
       }
     }
   }
@@ -317,10 +341,16 @@ static int launch_col_sums(int mode, const float* a, int64_t lda, const float* x
   }
   const int lpr = n_feat / V;
   const int lx = lpr < kBBlock ? lpr : kBBlock;
-  const int blocks = (int)((n_rows + kRowsPerBlock - 1) / kRowsPerBlock);
+  // One resident wave of equal workgroups (256 CUs x 8): a fixed 512 rows per workgroup leaves a short second
+  // wave of workgroups behind the first and the launch takes two workgroup lifetimes.
+  const int64_t round_rows = 4 * (kBBlock / lx);
+  int64_t rpb = (n_rows + kResidentBlocks - 1) / kResidentBlocks;
+  if (rpb < kRowsPerBlock) rpb = kRowsPerBlock;
+  rpb = (rpb + round_rows - 1) / round_rows * round_rows;
+  const int blocks = (int)((n_rows + rpb - 1) / rpb);
 #define LAUNCH_CS(VV, MM)                                                                     \
   hipLaunchKernelGGL((col_sums_kernel<VV, MM>), dim3(blocks), dim3(kBBlock), 0, st, a, lda, x, \
-                     ldx, mean, invstd, n_rows, n_feat, lpr, lx, sums, rg)
+                     ldx, mean, invstd, n_rows, rpb, n_feat, lpr, lx, sums, rg)
   if (V == 4) {
     if (mode == 0) LAUNCH_CS(4, 0); else if (mode == 1) LAUNCH_CS(4, 1); else LAUNCH_CS(4, 2);
   } else {
@@ -462,10 +492,14 @@ static int bn_bwd_any(const ReadoutGrad* rgp, const float* d_dy, int64_t lddy, c
     const int V = (vec_width(d_dx, lddx, n_feat) == 4 && src_ok && vec_width(d_x, ldx, n_feat) == 4) ? 4 : 1;
     const int lpr = n_feat / V;
     const int lx = lpr < kBBlock ? lpr : kBBlock;
-    const int blocks = (int)((n_rows + kDxRows - 1) / kDxRows);
+    const int64_t round_rows = 4 * (kBBlock / lx);
+    int64_t rpb = (n_rows + kResidentBlocks - 1) / kResidentBlocks;  // one resident wave of equal workgroups
+    if (rpb < kDxRows) rpb = kDxRows;
+    rpb = (rpb + round_rows - 1) / round_rows * round_rows;
+    const int blocks = (int)((n_rows + rpb - 1) / rpb);
 #define LAUNCH_DX(VV, RR, DD)                                                                     \
   hipLaunchKernelGGL((bn_bwd_dx_kernel<VV, RR, DD>), dim3(blocks), dim3(kBBlock), 0, st, d_dy, lddy, \
-                     d_x, ldx, n_rows, n_feat, lpr, lx, coef, d_dx, lddx, rg)
+                     d_x, ldx, n_rows, rpb, n_feat, lpr, lx, coef, d_dx, lddx, rg)
 #define LAUNCH_DX_R(VV, RR) \
   do { if (rgp) LAUNCH_DX(VV, RR, true); else LAUNCH_DX(VV, RR, false); } while (0)
     if (V == 4) {

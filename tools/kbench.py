@@ -107,7 +107,7 @@ def main():
                 off1 = [0] * 11
             fn = lambda: ops.seg_gemm(sb, se, a1, w, off1, a2, w if k2 else None, off2 if k2 else None, bias, boff,
                                       n_out, trans, True, N, k1, k2)
-            rec("seg_gemm_" + label, timeit(fn, args.iters), None, 2.0 * N * (k1 + k2) * n_out)
+            rec("seg_gemm_" + label, timeit(fn, args.iters), 4.0 * N * (k1 + k2 + n_out), 2.0 * N * (k1 + k2) * n_out)
         fp = rnd(B, 256)
         wh = rnd(24 * 256)
         rec("seg_gemm_head_fwd", timeit(lambda: ops.seg_gemm([0], [B], fp, wh, [0], None, None, None, None, None, 24,
