@@ -193,8 +193,8 @@ def main():
             dist.init_process_group(backend)
 
     from deepchem_amd import ops
-    from deepchem_amd._lib import (K_GATHER_MAX, K_GATHER_MAX_BWD, K_GATHER_SUM, K_READOUT, K_SEG_GEMM,
-                                   K_WGRAD)
+    from deepchem_amd._lib import (K_BATCHNORM, K_GATHER_MAX, K_GATHER_MAX_BWD, K_GATHER_SUM, K_READOUT,
+                                   K_SEG_GEMM, K_WGRAD)
 
     model, dbatch, labels, weights = make_workload(args, rank, device, args.batch)
     if world > 1:
@@ -203,7 +203,7 @@ def main():
     run_steps(model, dbatch, labels, weights, max(args.warmup, 1))
 
     kernel_ids = {"gather_sum": K_GATHER_SUM, "gather_max": K_GATHER_MAX, "gather_max_bwd": K_GATHER_MAX_BWD,
-                  "readout": K_READOUT, "seg_gemm": K_SEG_GEMM, "wgrad": K_WGRAD}
+                  "readout": K_READOUT, "seg_gemm": K_SEG_GEMM, "wgrad": K_WGRAD, "batchnorm": K_BATCHNORM}
     # Inside the timed region only the roofline kernel is event-timed: every timed launch is
     # bracketed by two event records on the launch stream, which costs ~10 us of queue time each.
     # The other kernel families are measured in a second, untimed pass.
@@ -286,6 +286,31 @@ def main():
         },
         "kernel_ms_per_step": {k: round(v[1] / breakdown_steps, 4) for k, v in ktimes.items()},
     }
+    # Every event-timed kernel family against the same HBM peak (second, untimed pass): algorithmic bytes per
+    # step = operands read once + results written once (DESIGN.md section 7 lists the terms).
+    N, E, B = g.n_atoms, g.n_edges, args.batch
+    fam_bytes = {
+        "gather_sum": per_step,
+        "gather_max": 2 * (E * (4 * 64 + 4) + 2 * N * 4 * 64 + N * 64),
+        "gather_max_bwd": 2 * (E * (5 * 64 + 5) + 2 * N * 4 * 64 + N * 64) if args.grad_mode == "full" else
+        (E * (5 * 64 + 5) + 2 * N * 4 * 64 + N * 64),
+        "readout": N * (4 * 128 + 4) + B * 8 * 128,
+        # forward: GraphConv 0/1, dense, head; backward: head, dense, GraphConv 1 (self + neighbour terms)
+        "seg_gemm": 4 * (N * (75 + 75 + 64) + N * (64 + 64 + 64) + N * (64 + 128) + B * (256 + 24) +
+                         B * (24 + 256) + N * (128 + 64) +
+                         (N * (64 + 64) + N * (64 + 64 + 64) if args.grad_mode == "full" else 0)),
+        # dW = A^T dY per operand: head, dense, GraphConv 1 (S and X), GraphConv 0 (S and X)
+        "wgrad": 4 * (B * (256 + 24) + N * (64 + 128) + 2 * N * (64 + 64) + 2 * N * (75 + 64)),
+        # statistics: one read of the layer output (64, 64, 128 wide); backward: dy and y read for the
+        # sums, read again and dx written by the second pass (the 128-wide dy is recomputed, not read)
+        "batchnorm": 4 * N * (64 + 64 + 128) + 4 * N * (5 * 64 + 5 * 64 + 3 * 128),
+    }
+    out["roofline_by_kernel"] = {
+        k: {"ms": round(ktimes[k][1] / breakdown_steps, 4), "algorithmic_bytes": int(fam_bytes[k]),
+            "GBps": round(fam_bytes[k] / (ktimes[k][1] / breakdown_steps * 1e-3) / 1e9, 1) if ktimes[k][1] > 0 else 0.0,
+            "frac_of_hbm_peak": round(fam_bytes[k] / (ktimes[k][1] / breakdown_steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)
+            if ktimes[k][1] > 0 else 0.0}
+        for k in ktimes}
 
     if rank == 0 and args.small_batch and world == 1:
         m2, b2, l2, w2 = make_workload(args, 0, device, args.small_batch)

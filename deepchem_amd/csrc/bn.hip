@@ -369,6 +369,7 @@ int bn_stats_impl(const float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat,
                  (long long)n_rows);
   GCMI_CHECK_ARG(d_x && d_scale && d_shift && d_acc, "bn_stats: NULL buffer");
   hipStream_t st = (hipStream_t)stream;
+  TimedScope ts(GCMI_K_BATCHNORM, st);
   int rc = launch_col_sums(0, d_x, ldx, nullptr, 0, nullptr, nullptr, n_rows, n_feat, d_acc, acc_clean, st);
   if (rc) return rc;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((n_feat + 255) / 256), dim3(256), 0, st, d_acc, n_rows,
@@ -477,6 +478,7 @@ static int bn_bwd_any(const ReadoutGrad* rgp, const float* d_dy, int64_t lddy, c
   GCMI_CHECK_ARG(d_x && d_mean && d_invstd && d_acc, "bn_bwd: NULL buffer");
   GCMI_CHECK_ARG(d_dx == nullptr || lddx >= n_feat, "bn_bwd: bad lddx");
   hipStream_t st = (hipStream_t)stream;
+  TimedScope ts(GCMI_K_BATCHNORM, st);
   int rc = launch_col_sums(1, d_dy, lddy, d_x, ldx, d_mean, d_invstd, n_rows, n_feat, d_acc, acc_clean, st, rgp);
   if (rc) return rc;
   // coefficient vectors (3F floats) live in the first 2F doubles of the scratch
