@@ -138,6 +138,7 @@ _SIGNATURES = {
     "gcmi_weave_gather": [_P, c_int64, c_int32, _P, c_int32, c_int32, _P, c_int64, _P],
     "gcmi_tanh_": [_P, c_int64, c_int64, c_int32, _P],
     "gcmi_edge_network_sum": [_P, c_int64, c_int32, c_int32, _P, c_int64, _P, _P, c_int32, _P, c_int64, _P],
+    "gcmi_edge_network_moments": [_P, c_int64, c_int32, c_int32, _P, c_int64, _P, _P, c_int32, _P, c_int64, _P],
     "gcmi_gru_gates": [_P, _P, _P, _P, c_int64, _P],
     "gcmi_gru_out": [_P, _P, _P, _P, c_int64, _P],
     "gcmi_set2set_attend": [_P, c_int64, c_int32, _P, c_int32, _P, c_int64, _P, c_int64, _P],

@@ -58,6 +58,74 @@ edge_network_kernel(const float* __restrict__ g, int64_t ldg, int d, int K, cons
   }
 }
 
+// The same message with the products taken in the other order:
+//   m[i] = sum_p A(pf_p) h[src_p],  A(pf) = sum_k pf_k W_k + B
+//        = sum_k W_k (sum_p pf[p,k] h[src_p]) + B (sum_p h[src_p])
+// so the pair-level work is T[i, k*d + c] = sum_p pf[p,k] h[src_p, c] (k < K) and T[i, K*d + c] = sum_p h[src_p, c]:
+// one 4*d-byte row of h per pair instead of the (K+1)*4*d-byte row of G, (K+1)*d multiply-adds per pair as
+// before, and the weights meet the data in ONE atom-level product T . [W_0 | ... | W_{K-1} | B]^T afterwards.
+// One wave per destination atom, a lane owns columns lane and lane + 64, the (K+1) x 2 partial sums stay in
+// registers; the pair's feature row is loaded by the first K lanes and broadcast with readlane.
+template <int KMAX, int NC>
+__global__ void __launch_bounds__(kMpBlock)
+edge_moments_kernel(const float* __restrict__ h, int64_t ldh, int d, int K, const float* __restrict__ pf, int64_t ldp,
+                    const int32_t* __restrict__ dst_ptr, const int32_t* __restrict__ src, int n_dst,
+                    float* __restrict__ t, int64_t ldt) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * kMpBlock + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * kMpBlock) >> 6;
+  for (int i = wave; i < n_dst; i += n_waves) {
+    const int p0 = dst_ptr[i], p1 = dst_ptr[i + 1];
+    float acc[KMAX + 1][NC];
+#pragma unroll
+    for (int k = 0; k <= KMAX; ++k)
+#pragma unroll
+      for (int q = 0; q < NC; ++q) acc[k][q] = 0.f;
+    for (int p = p0; p < p1; p += 2) {  // two pairs per round: their rows are requested together
+      const bool two = p + 1 < p1;
+      const int pb = two ? p + 1 : p;
+      const float* ha = h + (int64_t)src[p] * ldh;
+      const float* hb = h + (int64_t)src[pb] * ldh;
+      float va[NC], vb[NC];
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        const int c = lane + 64 * q;
+        va[q] = c < d ? ha[c] : 0.f;
+        vb[q] = (two && c < d) ? hb[c] : 0.f;
+      }
+      const float fa = lane < K ? pf[(int64_t)p * ldp + lane] : 0.f;
+      const float fb = (two && lane < K) ? pf[(int64_t)pb * ldp + lane] : 0.f;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+          const float wa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fa), k));
+          const float wb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fb), k));
+#pragma unroll
+          for (int q = 0; q < NC; ++q) acc[k][q] = fmaf(wa, va[q], fmaf(wb, vb[q], acc[k][q]));
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NC; ++q) acc[KMAX][q] += va[q] + vb[q];
+    }
+    float* row = t + (int64_t)i * ldt;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      if (k < K) {
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+          const int c = lane + 64 * q;
+          if (c < d) row[(int64_t)k * d + c] = acc[k][q];
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+      const int c = lane + 64 * q;
+      if (c < d) row[(int64_t)K * d + c] = acc[KMAX][q];
+    }
+  }
+}
+
 // z <- sigmoid(z), r <- sigmoid(r), hr = h * r
 __global__ void gru_gates_kernel(float* __restrict__ z, float* __restrict__ r, const float* __restrict__ h,
                                  float* __restrict__ hr, int64_t n) {
@@ -169,6 +237,26 @@ int gcmi_edge_network_sum(const float* d_g, int64_t ldg, int32_t n_hidden, int32
                      (hipStream_t)stream, d_g, ldg, n_hidden, n_pair_feat, d_pair_feat, ldp, d_dst_ptr, d_src, n_dst,
                      d_out, ldo);
   GCMI_CHECK_LAUNCH("edge_network_sum");
+  return GCMI_OK;
+}
+
+int gcmi_edge_network_moments(const float* d_h, int64_t ldh, int32_t n_hidden, int32_t n_pair_feat,
+                              const float* d_pair_feat, int64_t ldp, const int32_t* d_dst_ptr, const int32_t* d_src,
+                              int32_t n_dst, float* d_t, int64_t ldt, void* stream) {
+  GCMI_CHECK_ARG(n_hidden > 0 && n_hidden <= 128 && n_pair_feat > 0 && n_pair_feat <= 16 && n_dst >= 0 &&
+                     ldh >= n_hidden && ldp >= n_pair_feat && ldt >= (int64_t)(n_pair_feat + 1) * n_hidden,
+                 "edge_network_moments: bad shape (n_hidden <= 128, n_pair_feat <= 16)");
+  if (n_dst == 0) return GCMI_OK;
+  GCMI_CHECK_ARG(d_h && d_pair_feat && d_dst_ptr && d_src && d_t, "edge_network_moments: NULL buffer");
+  const dim3 grid(grid_for((int64_t)n_dst * 64, kMpBlock));
+  hipStream_t st = (hipStream_t)stream;
+  if (n_hidden <= 64)
+    hipLaunchKernelGGL((edge_moments_kernel<16, 1>), grid, dim3(kMpBlock), 0, st, d_h, ldh, n_hidden, n_pair_feat,
+                       d_pair_feat, ldp, d_dst_ptr, d_src, n_dst, d_t, ldt);
+  else
+    hipLaunchKernelGGL((edge_moments_kernel<16, 2>), grid, dim3(kMpBlock), 0, st, d_h, ldh, n_hidden, n_pair_feat,
+                       d_pair_feat, ldp, d_dst_ptr, d_src, n_dst, d_t, ldt);
+  GCMI_CHECK_LAUNCH("edge_network_moments");
   return GCMI_OK;
 }
 

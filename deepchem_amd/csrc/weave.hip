@@ -157,6 +157,94 @@ pair_features_kernel(const float* __restrict__ u, const float* __restrict__ v, i
   }
 }
 
+// The same map with a lane per OUTPUT QUAD instead of a lane per column: a workgroup is `slots` pair
+// slots x Q = (H + H2) / 4 lanes, every lane owns four fixed columns (their biases and, for pair->pair
+// columns, their weight columns live in registers), gathers the four atom rows of its pair with 16-byte
+// loads and writes its quad with one 16-byte store -- whole 400-byte output rows per pair slot instead of
+// two half rows from 50 of 64 lanes, and a quarter of the load instructions.  Needs 16-byte addressable
+// U, V and Z rows and (H + H2) % 4 == 0; anything else takes the per-column kernel above.
+template <int FP>
+__global__ void __launch_bounds__(kWvBlock)
+pair_features_quad_kernel(const float* __restrict__ u, const float* __restrict__ v, int64_t lduv, int H,
+                          const float* __restrict__ b_ap, const float* __restrict__ pf, int64_t ldp, int fp,
+                          const float* __restrict__ w_pp, const float* __restrict__ b_pp, int H2,
+                          const int32_t* __restrict__ atom_to_pair, int64_t n_pairs, float* __restrict__ z,
+                          int64_t ldz, int Q, int slots) {
+  const int slot = threadIdx.x / Q;
+  if (slot >= slots) return;
+  const int q = threadIdx.x - slot * Q;
+  const int c0 = 4 * q;
+  const bool pure_ap = c0 + 3 < H, pure_pp = c0 >= H;
+  float bias[4], w[4][FP];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = c0 + e;
+    if (c < H) {
+      bias[e] = b_ap ? b_ap[c] : 0.f;
+#pragma unroll
+      for (int k = 0; k < FP; ++k) w[e][k] = 0.f;
+    } else {
+      const int h2 = c - H;
+      bias[e] = b_pp ? b_pp[h2] : 0.f;
+#pragma unroll
+      for (int k = 0; k < FP; ++k) w[e][k] = k < fp ? w_pp[(int64_t)k * H2 + h2] : 0.f;
+    }
+  }
+  constexpr int R = 2;  // pairs per round and slot: their loads are issued together
+  const int64_t stride = (int64_t)gridDim.x * slots;
+  for (int64_t p0 = (int64_t)blockIdx.x * slots + slot; p0 < n_pairs; p0 += stride * R) {
+    float uij[R][4], vij[R][4], uji[R][4], vji[R][4], pv[R][FP];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t pr = p0 + r * stride;
+      const int64_t p = pr < n_pairs ? pr : p0;
+      const int i = atom_to_pair[2 * p], j = atom_to_pair[2 * p + 1];
+      if (pure_ap) {
+        const float4 a = *reinterpret_cast<const float4*>(u + (int64_t)i * lduv + c0);
+        const float4 b = *reinterpret_cast<const float4*>(v + (int64_t)j * lduv + c0);
+        const float4 c = *reinterpret_cast<const float4*>(u + (int64_t)j * lduv + c0);
+        const float4 d = *reinterpret_cast<const float4*>(v + (int64_t)i * lduv + c0);
+        uij[r][0] = a.x; uij[r][1] = a.y; uij[r][2] = a.z; uij[r][3] = a.w;
+        vij[r][0] = b.x; vij[r][1] = b.y; vij[r][2] = b.z; vij[r][3] = b.w;
+        uji[r][0] = c.x; uji[r][1] = c.y; uji[r][2] = c.z; uji[r][3] = c.w;
+        vji[r][0] = d.x; vji[r][1] = d.y; vji[r][2] = d.z; vji[r][3] = d.w;
+      } else if (!pure_pp) {  // the quad that straddles the two column groups
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = c0 + e < H ? c0 + e : 0;
+          uij[r][e] = u[(int64_t)i * lduv + c]; vij[r][e] = v[(int64_t)j * lduv + c];
+          uji[r][e] = u[(int64_t)j * lduv + c]; vji[r][e] = v[(int64_t)i * lduv + c];
+        }
+      }
+      if (!pure_ap) {
+        const float* row = pf + p * ldp;
+#pragma unroll
+        for (int k = 0; k < FP; ++k) pv[r][k] = k < fp ? row[k] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int64_t pr = p0 + r * stride;
+      if (pr >= n_pairs) continue;
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (c0 + e < H) {
+          const float ij = uij[r][e] + vij[r][e] + bias[e], ji = uji[r][e] + vji[r][e] + bias[e];
+          o[e] = (ij > 0.f ? ij : 0.f) + (ji > 0.f ? ji : 0.f);
+        } else {
+          float t = bias[e];
+#pragma unroll
+          for (int k = 0; k < FP; ++k)
+            if (k < fp) t = fmaf(pv[r][k], w[e][k], t);
+          o[e] = t > 0.f ? t : 0.f;
+        }
+      }
+      *reinterpret_cast<float4*>(z + pr * ldz + c0) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
 // WeaveGather.gaussian_histogram (layers.py:4600-4648): 11 unit-height Gaussians
 // exp(-(x-mu)^2 / (2 sigma^2)), normalised over the bins; output column f*11 + bin.
 __constant__ float kGaussMu[11] = {-1.645f, -1.080f, -0.739f, -0.468f, -0.228f, 0.f,
@@ -283,8 +371,20 @@ int gcmi_weave_pair_features(const float* d_u, const float* d_v, int64_t lduv, i
   if (n_pairs == 0) return GCMI_OK;
   GCMI_CHECK_ARG(d_u && d_v && d_pair_feat && d_atom_to_pair && d_z && (n_hidden_pp == 0 || d_w_pp),
                  "weave_pair_features: NULL buffer");
-  const int grid = grid_for(n_pairs * 64, kWvBlock);
   hipStream_t st = (hipStream_t)stream;
+  const int HT = n_hidden_ap + n_hidden_pp;
+  if (HT % 4 == 0 && HT / 4 <= kWvBlock && n_pair_feat <= 16 && lduv % 4 == 0 && ldz % 4 == 0 && aligned16(d_u) &&
+      aligned16(d_v) && aligned16(d_z)) {
+    const int Q = HT / 4, slots = kWvBlock / Q;
+    const int64_t want = (n_pairs + 2 * slots - 1) / (2 * slots);
+    const int grid_q = (int)(want < 2048 ? want : 2048);  // 256 CUs x 8 resident workgroups
+    hipLaunchKernelGGL(pair_features_quad_kernel<16>, dim3(grid_q), dim3(kWvBlock), 0, st, d_u, d_v, lduv, n_hidden_ap,
+                       d_b_ap, d_pair_feat, ldp, n_pair_feat, d_w_pp, d_b_pp, n_hidden_pp, d_atom_to_pair, n_pairs,
+                       d_z, ldz, Q, slots);
+    GCMI_CHECK_LAUNCH("weave_pair_features");
+    return GCMI_OK;
+  }
+  const int grid = grid_for(n_pairs * 64, kWvBlock);
   if (n_pair_feat <= 16)
     hipLaunchKernelGGL(pair_features_kernel<16>, dim3(grid), dim3(kWvBlock), 0, st, d_u, d_v, lduv, n_hidden_ap,
                        d_b_ap, d_pair_feat, ldp, n_pair_feat, d_w_pp, d_b_pp, n_hidden_pp, d_atom_to_pair, n_pairs,

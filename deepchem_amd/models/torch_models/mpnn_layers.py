@@ -3,9 +3,9 @@
 :2884-2913, ``SetGather`` :2976-3138), computed by libgcmi.so.  Same constructors, attribute names
 (``W``, ``b``; ``Wz`` ... ``bh``; ``U``, ``b``) and input lists; inputs may be NumPy arrays or tensors.
 
-EdgeNetwork is re-associated (include/gcmi.h, message-passing section): one atom-level GEMM produces
-G = h.[W_k^T ..| B^T], the pair-level work is a (K+1)*d multiply-add gather instead of a d x d
-matrix per pair.
+EdgeNetwork is re-associated (include/gcmi.h, message-passing section): the pair-level work is a
+(K+1)*d multiply-add per pair on the d-float state of the pair's second atom (per-atom moments T), the
+weights are applied afterwards by ONE atom-level GEMM -- instead of a d x d matrix per pair.
 """
 from typing import List
 
@@ -70,10 +70,18 @@ class EdgeNetwork(nn.Module):
         if pf.shape[1] != K or h.shape[1] != d:
             raise ValueError("EdgeNetwork: shapes do not match (pairs %s, atoms %s)" % (tuple(pf.shape), tuple(h.shape)))
         dst_ptr, src = self._plan(inputs[2], pf.shape[0], h.shape[0])
-        # G = h . [W_0^T | ... | W_{K-1}^T | B^T]: W (K, d*d) read in place as a (K*d, d) nn.Linear-layout matrix
         W = self.W.detach().to(self.device, torch.float32).contiguous()
         b = self.b.detach().to(self.device, torch.float32).contiguous()
         n = h.shape[0]
+        if d <= 128 and K <= 16:
+            # weights last: T = per-atom moments of the neighbours' states (a d-float gather per pair), then ONE
+            # product with M[r, k*d + c] = W_k[r, c] (k < K), M[r, K*d + c] = B[r, c]  (nn.Linear layout)
+            T = ops.edge_network_moments(h, pf, dst_ptr, src)
+            M = torch.cat([W.reshape(K, d, d), b.reshape(1, d, d)]).permute(1, 0, 2).reshape(d, (K + 1) * d).contiguous()
+            nd = T.shape[0]
+            return ops.seg_gemm([0], [nd], T, M.reshape(-1), [0], None, None, None, None, None, d, True, False, nd,
+                                (K + 1) * d, 0)
+        # G = h . [W_0^T | ... | W_{K-1}^T | B^T]: W (K, d*d) read in place as a (K*d, d) nn.Linear-layout matrix
         G = torch.empty((n, (K + 1) * d), dtype=torch.float32, device=self.device)
         G[:, :K * d] = ops.seg_gemm([0], [n], h, W.reshape(-1), [0], None, None, None, None, None, K * d, True, False, n, d, 0)
         G[:, K * d:] = ops.seg_gemm([0], [n], h, b, [0], None, None, None, None, None, d, True, False, n, d, 0)

@@ -172,12 +172,32 @@ class WeaveLayer(nn.Module):
             return [A_out, Pf]
         Fa = self.n_atom_input_feat
         w, b_ap = self._folded(self.W_AP, self.b_AP, self.AP_bn)
-        U = self._linear(A, w[:Fa].contiguous(), None, False)
-        V = self._linear(A, w[Fa:].contiguous(), None, False)
+        # Z = [atom->pair block | pair->pair block], each padded to a multiple of four columns so that every
+        # row piece the kernels touch is 16-byte addressable (pad columns are exact zeros: zero weights, zero
+        # biases, relu(0) = 0).  U = A.W_AP[:Fa] and V = A.W_AP[Fa:] come from ONE atom-level product; the
+        # pair kernel does the four-row gather per pair, the pair->pair block is an ordinary product.
+        H, H2 = w.shape[1], self.n_hidden_PP
+        Hp, H2p = (H + 3) // 4 * 4, (H2 + 3) // 4 * 4
+        w_uv = torch.zeros((Fa, 2 * Hp), dtype=torch.float32, device=self.device)
+        w_uv[:, :H] = w[:Fa]
+        w_uv[:, Hp:Hp + H] = w[Fa:]
+        UV = self._linear(A, w_uv, None, False)
+        b_ap_p = torch.zeros(Hp, dtype=torch.float32, device=self.device)
+        b_ap_p[:H] = b_ap
+        Z = torch.empty((n_pairs, Hp + H2p), dtype=torch.float32, device=self.device)
+        ops.weave_pair_features(UV[:, :Hp], UV[:, Hp:], b_ap_p, Pf, None, None, plan.a2p, out=Z[:, :Hp])
         w_pp, b_pp = self._folded(self.W_PP, self.b_PP, self.PP_bn)
-        Z = ops.weave_pair_features(U, V, b_ap, Pf, w_pp, b_pp, plan.a2p)
+        w_pp_p = torch.zeros((w_pp.shape[0], H2p), dtype=torch.float32, device=self.device)
+        w_pp_p[:, :H2] = w_pp
+        b_pp_p = torch.zeros(H2p, dtype=torch.float32, device=self.device)
+        b_pp_p[:H2] = b_pp
+        ops.seg_gemm([0], [n_pairs], Pf, w_pp_p.reshape(-1), [0], None, None, None, b_pp_p, [0], H2p, False, True,
+                     n_pairs, Pf.shape[1], 0, out=Z[:, Hp:])
         w, b = self._folded(self.W_P, self.b_P, self.P_bn)
-        P_out = self._linear(Z, w, b, True)
+        w_p = torch.zeros((Hp + H2p, w.shape[1]), dtype=torch.float32, device=self.device)
+        w_p[:H] = w[:H]
+        w_p[Hp:Hp + H2] = w[H:]
+        P_out = self._linear(Z, w_p, b, True)
         return [A_out, P_out]
 
 

@@ -192,10 +192,12 @@ def _i64arr(vals):
 
 
 def seg_gemm(seg_begin, seg_end, a1, w1, w1_off, a2, w2, w2_off, bias, bias_off, n_out: int,
-             trans_w: bool, relu: bool, n_rows: int, k1: int = 0, k2: int = 0) -> torch.Tensor:
+             trans_w: bool, relu: bool, n_rows: int, k1: int = 0, k2: int = 0,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[n_rows, n_out]; rows not covered by any segment are left undefined.
     w1 / w2 / bias are flat float32 CUDA tensors holding the blocks at the
-    given offsets (in floats)."""
+    given offsets (in floats).  ``out``: write into this (n_rows, n_out) matrix (a column block of a
+    wider one is fine) instead of a fresh one."""
     n_seg = len(seg_begin)
     dev = (a1 if a1 is not None else a2).device
     for s in range(n_seg):
@@ -216,7 +218,10 @@ def seg_gemm(seg_begin, seg_end, a1, w1, w1_off, a2, w2, w2_off, bias, bias_off,
         for s in range(n_seg):
             if bias_off[s] >= 0 and bias_off[s] + n_out > bias.numel():
                 raise ValueError("bias block %d runs past the buffer" % s)
-    out = torch.empty((n_rows, n_out), dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.empty((n_rows, n_out), dtype=torch.float32, device=dev)
+    else:
+        _mat(out, "out", rows=n_rows, cols=n_out)
     _lib.call("gcmi_seg_gemm", n_seg, _i32arr(seg_begin), _i32arr(seg_end),
               _ptr(a1), _ld(a1) if a1 is not None else 0, k1, _ptr(w1),
               _i64arr(w1_off) if a1 is not None else None,
@@ -337,17 +342,23 @@ def weave_pair_to_atom(pair_feat: torch.Tensor, pair_src: torch.Tensor, n_atoms:
 
 
 def weave_pair_features(u: torch.Tensor, v: torch.Tensor, b_ap, pair_feat: torch.Tensor, w_pp, b_pp,
-                        atom_to_pair: torch.Tensor):
-    """[relu(U[i]+V[j]+b) + relu(U[j]+V[i]+b) | relu(pair_feat . w_pp + b_pp)] per ordered pair."""
+                        atom_to_pair: torch.Tensor, out: Optional[torch.Tensor] = None):
+    """[relu(U[i]+V[j]+b) + relu(U[j]+V[i]+b) | relu(pair_feat . w_pp + b_pp)] per ordered pair.
+    ``w_pp=None``: only the atom-pair block.  ``out``: write into this (P, H + H2) matrix (may be a column
+    block of a wider one)."""
     u, v = _mat(u, "u"), _mat(v, "v", rows=u.shape[0], cols=u.shape[1])
     if _ld(u) != _ld(v):
         raise _lib.GcmiError("u and v must share their leading dimension")
     pf = _mat(pair_feat, "pair_feat")
-    w_pp = _mat(w_pp, "w_pp", rows=pf.shape[1])
-    P, H, H2 = pf.shape[0], u.shape[1], w_pp.shape[1]
-    z = torch.empty((P, H + H2), dtype=torch.float32, device=pf.device)
+    if w_pp is not None:
+        w_pp = _mat(w_pp, "w_pp", rows=pf.shape[1])
+    P, H, H2 = pf.shape[0], u.shape[1], 0 if w_pp is None else w_pp.shape[1]
+    if out is None:
+        z = torch.empty((P, H + H2), dtype=torch.float32, device=pf.device)
+    else:
+        z = _mat(out, "out", rows=P, cols=H + H2)
     _lib.call("gcmi_weave_pair_features", _ptr(u), _ptr(v), _ld(u), H, _ptr(_vec(b_ap, "b_ap", H)), _ptr(pf), _ld(pf),
-              pf.shape[1], _ptr(w_pp), _ptr(_vec(b_pp, "b_pp", H2)), H2,
+              pf.shape[1], _ptr(w_pp), _ptr(_vec(b_pp, "b_pp", H2)) if H2 else None, H2,
               _ptr(_i32vec(atom_to_pair, "atom_to_pair", 2 * P)), P, _ptr(z), _ld(z), _stream())
     return z
 
@@ -381,6 +392,18 @@ def edge_network_sum(g: torch.Tensor, n_hidden: int, pair_feat: torch.Tensor, ds
               _ptr(_i32vec(dst_ptr, "dst_ptr")), _ptr(_i32vec(src, "src", pf.shape[0])), n_dst, _ptr(out), _ld(out),
               _stream())
     return out
+
+
+def edge_network_moments(h: torch.Tensor, pair_feat: torch.Tensor, dst_ptr: torch.Tensor, src: torch.Tensor):
+    """T[i] = [sum_p pf[p,0] h[src_p] | ... | sum_p pf[p,K-1] h[src_p] | sum_p h[src_p]] per destination atom."""
+    h = _mat(h, "h")
+    pf = _mat(pair_feat, "pair_feat")
+    d, K = h.shape[1], pf.shape[1]
+    n_dst = dst_ptr.numel() - 1
+    t = torch.empty((n_dst, (K + 1) * d), dtype=torch.float32, device=h.device)
+    _lib.call("gcmi_edge_network_moments", _ptr(h), _ld(h), d, K, _ptr(pf), _ld(pf), _ptr(_i32vec(dst_ptr, "dst_ptr")),
+              _ptr(_i32vec(src, "src", pf.shape[0])), n_dst, _ptr(t), _ld(t), _stream())
+    return t
 
 
 def gru_gates_(z: torch.Tensor, r: torch.Tensor, h: torch.Tensor) -> torch.Tensor:

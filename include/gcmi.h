@@ -309,6 +309,12 @@ int gcmi_tanh_(float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat, void* st
 int gcmi_edge_network_sum(const float* d_g, int64_t ldg, int32_t n_hidden, int32_t n_pair_feat,
                           const float* d_pair_feat, int64_t ldp, const int32_t* d_dst_ptr, const int32_t* d_src,
                           int32_t n_dst, float* d_out, int64_t ldo, void* stream);
+/* gcmi_edge_network_moments: the same message with the weights applied last,
+ *   T[i, k*d + c] = sum_p pf[p,k] h[src_p, c] (k < K),  T[i, K*d + c] = sum_p h[src_p, c]   (d <= 128, K <= 16),
+ *   message = T . [W_0 | ... | W_{K-1} | B]^T by one gcmi_seg_gemm: a 4d-byte gather per pair instead of 4(K+1)d. */
+int gcmi_edge_network_moments(const float* d_h, int64_t ldh, int32_t n_hidden, int32_t n_pair_feat,
+                              const float* d_pair_feat, int64_t ldp, const int32_t* d_dst_ptr, const int32_t* d_src,
+                              int32_t n_dst, float* d_t, int64_t ldt, void* stream);
 int gcmi_gru_gates(float* d_z, float* d_r, const float* d_h, float* d_hr, int64_t n, void* stream);
 int gcmi_gru_out(const float* d_z, const float* d_hpre, const float* d_x, float* d_out, int64_t n, void* stream);
 int gcmi_set2set_attend(const float* d_x, int64_t ldx, int32_t n_feat, const int32_t* d_mol_ptr, int32_t n_mols,

@@ -76,12 +76,19 @@ def main():
     w_pa, b_pa = layer.W_PA.contiguous(), layer.b_PA
     rec("weave_pair_to_atom", timeit(lambda: ops.weave_pair_to_atom(Pf, psrc, N, w_pa, b_pa), args.iters),
         P * 14 * 4 + N * H * 4)
-    U = torch.randn(N, H, device=dev)
-    V = torch.randn(N, H, device=dev)
+    UV = torch.randn(N, 104, device=dev)  # the layer's layout: both halves padded to 52 columns
     a2p_d = torch.from_numpy(a2p.astype(np.int32)).to(dev).contiguous().view(-1)
     w_pp, b_pp = layer.W_PP.contiguous(), layer.b_PP
-    rec("weave_pair_features", timeit(lambda: ops.weave_pair_features(U, V, layer.b_AP, Pf, w_pp, b_pp, a2p_d), args.iters),
-        P * (14 * 4 + 8 + 2 * H * 4) + P * 4 * H * 4)  # pair row + ids + output row + 4 gathered U/V rows (on-die)
+    Z = torch.empty(P, 104, device=dev)
+    b52 = torch.zeros(52, device=dev)
+    rec("weave_pair_features_atom_block",
+        timeit(lambda: ops.weave_pair_features(UV[:, :52], UV[:, 52:], b52, Pf, None, None, a2p_d, out=Z[:, :52]), args.iters),
+        P * (8 + 52 * 4) + P * 4 * 52 * 4)  # ids + output row + 4 gathered U/V rows (on-die)
+    w52 = torch.zeros(14, 52, device=dev)
+    w52[:, :50] = w_pp
+    rec("weave_pair_features_pair_block",
+        timeit(lambda: ops.seg_gemm([0], [P], Pf, w52.reshape(-1), [0], None, None, None, b52, [0], 52, False, True, P, 14,
+                                    0, out=Z[:, 52:]), args.iters), P * (14 * 4 + 52 * 4))
     x128 = torch.tanh(torch.randn(N, 128, device=dev))
     mptr = torch.from_numpy(np.concatenate([[0], np.cumsum(np.bincount(atom_split, minlength=args.mols))]).astype(np.int32)).to(dev)
     rec("weave_gather_gaussian", timeit(lambda: ops.weave_gather(x128, mptr, True), args.iters),
