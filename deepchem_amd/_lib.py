@@ -148,6 +148,7 @@ _SIGNATURES = {
     "gcmi_diag_mfma_peak": [c_int32, c_int32, _P, _P],
     "gcmi_set_option": [c_int32, c_int32],
     "gcmi_get_option": [c_int32, _I32P],
+    "gcmi_expand_atom_codes": [_P, c_int64, c_int64, _P, c_int64, _P],
     "gcmi_smiles_sizes": [_P, c_int64, _I32P, _I32P, ctypes.c_int],
     "gcmi_smiles_featurize": [_P, c_int64, _I64P, _I64P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_int],
     "gcmi_timing_enable": [c_int32, c_int32],

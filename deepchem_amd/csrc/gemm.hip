@@ -701,7 +701,11 @@ int gcmi_seg_gemm_wgrad(int32_t n_seg, const int32_t* seg_begin, const int32_t* 
   // slab size: about eight workgroups per CU (the row loop is latency-bound: it wants many
   // waves), but never so small that the atomic epilogue (k x n adds per workgroup into one
   // small block) outweighs the row loop
-  int64_t slab = (total_rows + 2047) / 2048;
+  // ... and sized so that ALL slabs are resident at once: the split-bf16 kernel holds 4 / 4 / 3 / 2 workgroups per
+  // CU for K <= 32 / 64 / 96 / 128 (registers); 1 880 slabs of 640 rows ran as 1.8 (2.4) rounds of workgroups.
+  const int kt = (k + 31) / 32;
+  const int64_t resident = 256 * (kt <= 2 ? 4 : (kt == 3 ? 3 : 2)) - n_seg;  // every segment may add a partial slab
+  int64_t slab = (total_rows + resident - 1) / resident;
   slab = ((slab + 63) / 64) * 64;
   if (slab < 256) slab = 256;
   if (slab > 4096) slab = 4096;

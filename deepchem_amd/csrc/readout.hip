@@ -281,3 +281,53 @@ int gcmi_readout_bwd(const gcmi_graph* g, const float* d_dout, int64_t lddo, con
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- atom codes -> feature rows
+// The 75 columns of atom_features (deepchem/feat/graph_features.py:282-391) are five one-hot blocks, two small
+// integers and a flag: eight bytes per atom (layout: deepchem_amd/feat/atom_codes.py).  Collation and the H2D copy
+// move the codes; this kernel writes the float rows the model reads (columns >= 75 up to ldo are zero).
+namespace gcmi {
+__global__ void __launch_bounds__(256)
+expand_codes_kernel(const uint8_t* __restrict__ codes, int64_t ldc, int64_t n_atoms, float* __restrict__ out,
+                    int64_t ldo, int quads) {
+  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= n_atoms * quads) return;
+  const int64_t r = slot / quads;
+  const int q = (int)(slot - r * quads);
+  const uint2 w = *reinterpret_cast<const uint2*>(codes + r * ldc);
+  const int sym = w.x & 255, deg = (w.x >> 8) & 255, imp = (w.x >> 16) & 255;
+  const int chg = (int)(int8_t)(w.x >> 24);
+  const int rad = w.y & 255, hyb = (w.y >> 8) & 255, aro = (w.y >> 16) & 255, toth = (w.y >> 24) & 255;
+  float v[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = 4 * q + e;
+    float x = 0.f;
+    if (c < 44) x = c == (sym < 43 ? sym : 43) ? 1.f : 0.f;
+    else if (c < 55) x = (c - 44) == (deg < 10 ? deg : 10) ? 1.f : 0.f;
+    else if (c < 62) x = (c - 55) == (imp < 6 ? imp : 6) ? 1.f : 0.f;
+    else if (c == 62) x = (float)chg;
+    else if (c == 63) x = (float)rad;
+    else if (c < 69) x = (c - 64) == (hyb < 4 ? hyb : 4) ? 1.f : 0.f;
+    else if (c == 69) x = (float)aro;
+    else if (c < 75) x = (c - 70) == (toth < 4 ? toth : 4) ? 1.f : 0.f;
+    v[e] = x;
+  }
+  *reinterpret_cast<float4*>(out + r * ldo + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
+}
+}  // namespace gcmi
+
+extern "C" int gcmi_expand_atom_codes(const uint8_t* d_codes, int64_t ldc, int64_t n_atoms, float* d_out, int64_t ldo,
+                                      void* stream) {
+  using namespace gcmi;
+  GCMI_CHECK_ARG(n_atoms >= 0 && ldc >= 8 && ldc % 8 == 0 && ldo >= 76 && ldo % 4 == 0,
+                 "expand_atom_codes: bad shape (8-byte aligned code rows, ldo >= 76 and a multiple of 4)");
+  if (n_atoms == 0) return GCMI_OK;
+  GCMI_CHECK_ARG(d_codes && d_out && aligned16(d_out) && (reinterpret_cast<uintptr_t>(d_codes) & 7u) == 0,
+                 "expand_atom_codes: NULL or misaligned buffer");
+  const int quads = (int)(ldo / 4);
+  hipLaunchKernelGGL(expand_codes_kernel, dim3(grid_for(n_atoms * quads, 256)), dim3(256), 0, (hipStream_t)stream,
+                     d_codes, ldc, n_atoms, d_out, ldo, quads);
+  GCMI_CHECK_LAUNCH("expand_atom_codes");
+  return GCMI_OK;
+}

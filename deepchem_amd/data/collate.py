@@ -130,13 +130,16 @@ def collate_host(packed: PackedMols, sel: Optional[np.ndarray], max_deg: int = 1
     _lib.call("gcmi_collate_sizes", packed.atom_ptr.ctypes.data, packed.adj_ptr.ctypes.data,
               sel.ctypes.data, n_sel, ctypes.byref(na), ctypes.byref(ne))
     n_atoms, n_edges = int(na.value), int(ne.value)
-    n_feat = packed.n_feat
-    ld = ((n_feat + pad_features_to - 1) // pad_features_to) * pad_features_to
+    # a set kept as 8-byte atom codes is collated as rows of two "floats" (8 bytes per atom in the arena) and expanded
+    # to feature rows on the device (collate_to_device)
+    coded = getattr(packed, "atom_codes", None) is not None
+    n_feat = 2 if coded else packed.n_feat
+    ld = 2 if coded else ((n_feat + pad_features_to - 1) // pad_features_to) * pad_features_to
     n_deg = max_deg + 1
 
     def up4(n):
         return (n + 3) // 4 * 4
-    off = {"mem": n_atoms * ld}
+    off = {"mem": up4(n_atoms * ld)}
     off["col"] = off["mem"] + up4(n_atoms)
     off["runs"] = off["col"] + up4(n_edges)
     off["win"] = off["runs"] + up4(n_sel * n_deg * 2)
@@ -151,7 +154,7 @@ def collate_host(packed: PackedMols, sel: Optional[np.ndarray], max_deg: int = 1
     else:
         arena = torch.empty(total, dtype=torch.float32, pin_memory=pin)
     base = arena.data_ptr()
-    feats = np.ascontiguousarray(packed.atom_features, np.float32)
+    feats = packed.atom_codes.view(np.float32) if coded else np.ascontiguousarray(packed.atom_features, np.float32)
     atom_ptr = np.ascontiguousarray(packed.atom_ptr, np.int64)
     adj_ptr = np.ascontiguousarray(packed.adj_ptr, np.int64)
     adj_idx = np.ascontiguousarray(packed.adj_idx, np.int32)
@@ -163,7 +166,9 @@ def collate_host(packed: PackedMols, sel: Optional[np.ndarray], max_deg: int = 1
               base + 4 * off["rev"], ctypes.byref(sym), int(win_cap), base + 4 * off["win"],
               base + 4 * off["loc"], ctypes.byref(g))
     counts = [g.deg_start[d + 1] - g.deg_start[d] for d in range(n_deg)]
-    return HostBatch(arena, off, n_atoms, n_edges, n_sel, n_feat, ld, n_deg, counts, bool(sym.value), g)
+    hb = HostBatch(arena, off, n_atoms, n_edges, n_sel, n_feat, ld, n_deg, counts, bool(sym.value), g)
+    hb.coded = coded
+    return hb
 
 
 def collate_to_device(packed: PackedMols, sel: Optional[np.ndarray], device: torch.device,
@@ -181,8 +186,14 @@ def collate_to_device(packed: PackedMols, sel: Optional[np.ndarray], device: tor
         graph.attach_rev_pos(hb.part("rev_pos", dev_arena))
     if hb.n_win > 0:
         graph.attach_windows(hb.plan, hb.part("win_meta", dev_arena), hb.part("win_edges", dev_arena))
-    return DeviceBatch(hb.part("features", dev_arena), graph, hb.n_sel if n_samples is None else n_samples,
-                       hb.n_feat)
+    feats = hb.part("features", dev_arena)
+    n_feat = hb.n_feat
+    if getattr(hb, "coded", False):
+        from deepchem_amd import ops
+        ld_out = ((75 + pad_features_to - 1) // pad_features_to) * pad_features_to
+        feats = ops.expand_atom_codes(feats.view(torch.uint8), max(76, (ld_out + 3) // 4 * 4))
+        n_feat = 75
+    return DeviceBatch(feats, graph, hb.n_sel if n_samples is None else n_samples, n_feat)
 
 
 def _is_symmetric(packed: PackedMols) -> bool:

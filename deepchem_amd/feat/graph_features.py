@@ -132,13 +132,16 @@ class ConvMolFeaturizer(_SmilesFeaturizer):
         """(PackedMols of the readable molecules, their positions in ``smiles``)."""
         if self.master_atom or self.per_atom_fragmentation:
             raise NotImplementedError("featurize_packed covers the plain featurization; use featurize()")
-        r = read_smiles(_as_list(smiles), n_threads=self.n_threads)
+        # the float rows are never built here: the property rows become 8-byte atom codes (feat/atom_codes.py),
+        # which is what the collation moves and the GPU expands
+        from deepchem_amd.feat.atom_codes import codes_from_props
+        r = read_smiles(_as_list(smiles), atoms=False, props=True, n_threads=self.n_threads)
         keep = np.nonzero(r["valid"])[0]
         atom_ptr = np.zeros(keep.shape[0] + 1, np.int64)
         np.cumsum(r["n_atoms"][keep], out=atom_ptr[1:])  # unreadable molecules own no rows, so offsets just close up
         adj_ptr = np.zeros(r["adj_degree"].shape[0] + 1, np.int64)
         np.cumsum(r["adj_degree"], out=adj_ptr[1:])
-        return PackedMols(r["atom_features"], atom_ptr, adj_ptr, r["adj_idx"]), keep
+        return PackedMols(None, atom_ptr, adj_ptr, r["adj_idx"], codes_from_props(r["atom_props"])), keep
 
     def featurize(self, datapoints, log_every_n: int = 1000, **kwargs) -> np.ndarray:
         smiles = _as_list(datapoints)

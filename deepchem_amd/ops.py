@@ -394,6 +394,19 @@ def edge_network_sum(g: torch.Tensor, n_hidden: int, pair_feat: torch.Tensor, ds
     return out
 
 
+def expand_atom_codes(codes: torch.Tensor, ld_out: int = 76) -> torch.Tensor:
+    """(N, >= 8) uint8 code rows (row stride a multiple of 8 bytes) -> (N, ld_out) float32 feature rows."""
+    if not torch.is_tensor(codes) or not codes.is_cuda or codes.dtype != torch.uint8 or codes.dim() != 2:
+        raise _lib.GcmiError("codes must be a 2-D uint8 CUDA tensor")
+    if codes.shape[1] < 8 or (codes.shape[1] > 1 and codes.stride(1) != 1):
+        raise ValueError("code rows are 8 contiguous bytes")
+    n = codes.shape[0]
+    out = torch.empty((n, ld_out), dtype=torch.float32, device=codes.device)
+    _lib.call("gcmi_expand_atom_codes", _ptr(codes), int(codes.stride(0)) if n > 1 else int(codes.shape[1]), n,
+              _ptr(out), ld_out, _stream())
+    return out
+
+
 def edge_network_moments(h: torch.Tensor, pair_feat: torch.Tensor, dst_ptr: torch.Tensor, src: torch.Tensor):
     """T[i] = [sum_p pf[p,0] h[src_p] | ... | sum_p pf[p,K-1] h[src_p] | sum_p h[src_p]] per destination atom."""
     h = _mat(h, "h")

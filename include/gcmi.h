@@ -322,6 +322,15 @@ int gcmi_set2set_attend(const float* d_x, int64_t ldx, int32_t n_feat, const int
 int gcmi_lstm_cell(const float* d_z, int64_t ldz, int32_t n_hidden, int64_t n_rows, float* d_c, int64_t ldc,
                    float* d_h, int64_t ldh, void* stream);
 
+/* ---------------------------------------------------------------- atom codes
+ * The 75-column rows of atom_features (feat/graph_features.py:282-391) are five one-hot blocks, two small integers
+ * and a flag.  Code row (8 bytes): symbol column, degree, implicit-valence column, formal charge (int8), radical
+ * electrons, hybridisation column, aromatic, total-H column.  Collation and the host-to-device copy move codes
+ * (gcmi_collate_plans with n_feat = 2 "floats"); this writes the float rows on the device:
+ * out[r, 0:75] as the reference lays them out, out[r, 75:ldo] = 0.                                            */
+int gcmi_expand_atom_codes(const uint8_t* d_codes, int64_t ldc_bytes, int64_t n_atoms, float* d_out, int64_t ldo,
+                           void* stream);
+
 /* ---------------------------------------------------------------- SMILES featurization (host)
  * What the reference computes in Python per rdkit Mol, for SMILES input:
  *   atom_features feat/graph_features.py:282-391 (75 columns), bond_features :394-459 (6), pair_features +

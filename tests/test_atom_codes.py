@@ -1,0 +1,125 @@
+"""Atom codes (deepchem_amd/feat/atom_codes.py): host round trips, PackedMols behaviour, collation of a coded set
+(CPU); device expansion and the training pipeline on codes against the float path (GPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import deepchem_amd as dc
+from deepchem_amd.feat import atom_codes as ac
+from deepchem_amd.feat import graph_features as gf
+from deepchem_amd.utils.synthetic import PackedMols, concat_packed
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _sample_smiles():
+    with open(os.path.join(HERE, "golden", "smiles_sample.txt")) as f:
+        return [l.strip() for l in f if l.strip() and not l.startswith("#")]
+
+
+def test_codes_round_trip_on_featurizer_output():
+    r = gf.read_smiles(_sample_smiles() + ["[U]", "[Fe+3]", "[CH3]", "[13CH4]", "[O-2]"], props=True)
+    codes = ac.codes_from_features(r["atom_features"])
+    assert codes is not None and codes.shape == (r["atom_features"].shape[0], 8) and codes.dtype == np.uint8
+    np.testing.assert_array_equal(codes, ac.codes_from_props(r["atom_props"]))
+    np.testing.assert_array_equal(ac.features_from_codes(codes), r["atom_features"])
+    assert ac.codes_from_features(r["atom_features"].astype(np.float64)) is not None  # the reference's dtype
+
+
+def test_rows_that_are_not_codes_stay_float():
+    r = gf.read_smiles(["CCO"])
+    f = r["atom_features"].copy()
+    assert ac.codes_from_features(f[:, :74]) is None
+    g = f.copy(); g[0, 3] = 0.5
+    assert ac.codes_from_features(g) is None
+    g = f.copy(); g[1, 0] = 1; g[1, 2] = 1          # two symbols set
+    assert ac.codes_from_features(g) is None
+    g = f.copy(); g[2, 44:55] = 0                   # empty degree block
+    assert ac.codes_from_features(g) is None
+    g = np.concatenate([f, f.mean(0, keepdims=True)])  # master-atom row
+    assert ac.codes_from_features(g) is None
+    assert ac.codes_from_features(np.random.RandomState(0).rand(4, 75)) is None
+
+
+def test_packed_set_on_codes_behaves_like_the_float_set():
+    smiles = ["CCO", "c1ccccc1C(=O)O", "bad(", "C", "CC(C)N", "[Na+].[Cl-]"]
+    coded, keep = dc.feat.ConvMolFeaturizer().featurize_packed(smiles)
+    assert coded.atom_codes is not None and coded._features is None and coded.n_feat == 75
+    r = gf.read_smiles(smiles)
+    np.testing.assert_array_equal(coded.atom_features, r["atom_features"])
+    flt = PackedMols(r["atom_features"], coded.atom_ptr, coded.adj_ptr, coded.adj_idx)
+    for m in range(coded.n_mols):
+        fa, aa = coded.molecule(m)
+        fb, ab = flt.molecule(m)
+        np.testing.assert_array_equal(fa, fb)
+        assert aa == ab
+    sel = np.array([3, 0, 0, 4])
+    np.testing.assert_array_equal(coded.select(sel).atom_features, flt.select(sel).atom_features)
+    both = concat_packed([coded, coded.select(sel)])
+    assert both.atom_codes is not None and both.n_atoms == coded.n_atoms + coded.select(sel).n_atoms
+    mixed = concat_packed([coded, flt])
+    assert mixed.atom_codes is None and mixed.atom_features.shape[0] == 2 * coded.n_atoms
+    from deepchem_amd.feat.mol_graphs import collate_packed
+    a, b = collate_packed(coded), collate_packed(flt)
+    np.testing.assert_array_equal(a.get_atom_features(), b.get_atom_features())
+
+
+def test_collation_moves_codes_not_floats():
+    from deepchem_amd.data.collate import collate_host
+    from deepchem_amd.data.packed_dataset import packed_from_convmols
+    smiles = _sample_smiles()[:64]
+    coded, _ = dc.feat.ConvMolFeaturizer().featurize_packed(smiles)
+    flt = PackedMols(coded.atom_features, coded.atom_ptr, coded.adj_ptr, coded.adj_idx)
+    hc = collate_host(coded, None, pin=False)
+    hf = collate_host(flt, None, pad_features_to=76, pin=False)
+    assert hc.coded and hc.ld == 2 and hf.ld == 76
+    assert hc.arena.numel() < hf.arena.numel() / 7  # what is left is index data
+    codes_sorted = hc.part("features").numpy().view(np.uint8).reshape(-1, 8)
+    np.testing.assert_array_equal(ac.features_from_codes(codes_sorted), hf.part("features").numpy()[:, :75])
+    for name in ("membership", "col_idx", "mol_runs"):
+        np.testing.assert_array_equal(hc.part(name).numpy(), hf.part(name).numpy())
+    # ConvMol objects of the featurizer are recognised when a dataset is packed
+    objs = dc.feat.ConvMolFeaturizer().featurize(smiles[:8])
+    assert packed_from_convmols(objs).atom_codes is not None
+
+
+@pytest.mark.gpu
+def test_device_expansion_equals_host_rows():
+    from deepchem_amd import ops
+    r = gf.read_smiles(_sample_smiles() + ["[U]", "[Fe+3]", "[CH3]"], props=True)
+    codes = ac.codes_from_props(r["atom_props"])
+    wide = np.zeros((codes.shape[0], 16), np.uint8)
+    wide[:, :8] = codes
+    for host in (codes, wide):
+        out = ops.expand_atom_codes(torch.from_numpy(host).to("cuda:0"), 76).cpu().numpy()
+        np.testing.assert_array_equal(out[:, :75], r["atom_features"])
+        assert not out[:, 75:].any()
+    out = ops.expand_atom_codes(torch.from_numpy(codes).to("cuda:0"), 80).cpu().numpy()
+    np.testing.assert_array_equal(out[:, :75], r["atom_features"])
+    assert not out[:, 75:].any()
+
+
+@pytest.mark.gpu
+def test_training_on_codes_equals_training_on_floats():
+    from deepchem_amd.models.torch_models import GraphConvModel
+    smiles = _sample_smiles()
+    coded, _ = dc.feat.ConvMolFeaturizer().featurize_packed(smiles)
+    flt = PackedMols(coded.atom_features, coded.atom_ptr, coded.adj_ptr, coded.adj_idx)
+    rng = np.random.RandomState(4)
+    y = rng.randn(coded.n_mols, 2)
+    w = np.ones_like(y)
+    first, after = [], []
+    for packed in (coded, flt):
+        torch.manual_seed(11)
+        np.random.seed(11)
+        model = GraphConvModel(2, number_input_features=[75, 64], batch_size=64, mode="regression", grad_mode="full",
+                               device=torch.device("cuda:0"))
+        ds = dc.data.PackedDataset(packed, y, w)
+        first.append(model.predict(ds))
+        model.fit(ds, nb_epoch=1, deterministic=True, checkpoint_interval=0)
+        after.append(model.predict(ds))
+    np.testing.assert_array_equal(first[0], first[1])  # the same rows reach the model
+    # the weight-gradient kernels add with float atomics: two float runs differ by ~1e-5 after an epoch as well
+    np.testing.assert_allclose(after[0], after[1], rtol=0, atol=2e-4)
