@@ -12,6 +12,7 @@
 // row bases (and closes the LDS windows), and a second parallel pass writes rows.
 // The result is identical for any thread count.
 #include <algorithm>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 
@@ -69,9 +70,11 @@ int gcmi_collate_plans(const float* atom_features, int64_t n_feat, const int64_t
   GCMI_CHECK_ARG(n_sel >= 0 && n_sel < (1LL << 31), "collate: bad n_sel");
   bool want_win = win_cap > 0 && out_win_meta && out_win_edges;
   const int n_deg = max_deg + 1;
+  // GCMI_COLLATE_THREADS: worker threads per call (default: up to 16, one per 256 molecules)
+  static const unsigned thread_cap = getenv("GCMI_COLLATE_THREADS") ? (unsigned)std::max(1, atoi(getenv("GCMI_COLLATE_THREADS"))) : 16u;
   const int n_threads = (int)std::min<int64_t>(
       std::max<int64_t>(1, n_sel / 256),
-      std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())));
+      std::min<unsigned>(thread_cap, std::max(1u, std::thread::hardware_concurrency())));
 
   // pass 1 (parallel): degree histogram of every molecule
   std::vector<int32_t> hist((size_t)n_sel * ND, 0);
