@@ -239,7 +239,10 @@ class DeviceBatchPipeline:
                 batch, y_t, w_t, ev = item
                 cur = torch.cuda.current_stream(dev)
                 cur.wait_event(ev)
-                for tns in (batch.graph._arena, y_t, w_t):
+                # everything the worker's stream allocated and this stream will read: the arena, the feature rows
+                # expanded from atom codes (their own allocation) and the gathered labels / weights -- without the
+                # mark the allocator may hand a block to the worker's next batch while the step still reads it
+                for tns in (batch.graph._arena, batch.atom_features, y_t, w_t):
                     if tns is not None:
                         tns.record_stream(cur)
                 yield batch, y_t, w_t

@@ -114,12 +114,14 @@ def test_training_on_codes_equals_training_on_floats():
     for packed in (coded, flt):
         torch.manual_seed(11)
         np.random.seed(11)
-        model = GraphConvModel(2, number_input_features=[75, 64], batch_size=64, mode="regression", grad_mode="full",
-                               device=torch.device("cuda:0"))
+        model = GraphConvModel(2, number_input_features=[75, 64], batch_size=coded.n_mols, mode="regression",
+                               grad_mode="full", device=torch.device("cuda:0"))
         ds = dc.data.PackedDataset(packed, y, w)
         first.append(model.predict(ds))
-        model.fit(ds, nb_epoch=1, deterministic=True, checkpoint_interval=0)
+        model.fit(ds, nb_epoch=2, deterministic=True, checkpoint_interval=0)  # two optimiser steps on the whole set
         after.append(model.predict(ds))
     np.testing.assert_array_equal(first[0], first[1])  # the same rows reach the model
-    # the weight-gradient kernels add with float atomics: two float runs differ by ~1e-5 after an epoch as well
-    np.testing.assert_allclose(after[0], after[1], rtol=0, atol=2e-4)
+    # the weight-gradient kernels add with float atomics, so two float runs are not bit-identical either; longer
+    # runs drift apart chaotically (arg-max flips), which is why this stops after two steps
+    np.testing.assert_allclose(after[0], after[1], rtol=0, atol=1e-4)
+    assert np.abs(after[0] - first[0]).max() > 1e-3  # and the steps did move the model
