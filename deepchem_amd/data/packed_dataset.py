@@ -166,7 +166,8 @@ class DeviceBatchPipeline:
     RESIDENT_LABEL_BYTES = 8 << 30
 
     def __init__(self, packed: PackedMols, y, w, index_batches, device: torch.device, label_fn=None,
-                 depth: int = 2):
+                 depth: int = 2, workers: int = 2):
+        self.workers = workers
         self.packed, self.y, self.w = packed, y, w
         self.index_batches = index_batches
         self.device = device
@@ -210,33 +211,76 @@ class DeviceBatchPipeline:
         return batch, y_t, w_t, ev
 
     def __iter__(self):
-        q: "queue.Queue" = queue.Queue(maxsize=self.depth)
-        stop = threading.Event()
+        """Batches in the order of ``index_batches``.  ``workers`` threads (own stream, own pinned ring) collate
+        ahead; a thread takes the next index batch under a lock, so results are handed out by sequence number."""
         dev = self.device
+        n_workers = max(1, self.workers)
+        window = self.depth + n_workers - 1  # batches taken but not yet consumed
+        cond = threading.Condition()
+        src_lock = threading.Lock()
+        source = iter(self.index_batches)
+        state = {"taken": 0, "consumed": 0, "exhausted": False, "alive": n_workers, "error": None}
+        results = {}
+        stop = threading.Event()
+
+        def take():
+            with src_lock:
+                if state["exhausted"]:
+                    return None
+                try:
+                    idx, n_real = next(source)
+                except StopIteration:
+                    state["exhausted"] = True
+                    return None
+                seq = state["taken"]
+                state["taken"] += 1
+                return seq, idx, n_real
 
         def work():
             try:
                 torch.cuda.set_device(dev)
                 stream = torch.cuda.Stream(device=dev)
-                ring = PinnedRing(self.depth + 2)
-                for idx, n_real in self.index_batches:
+                ring = PinnedRing(max(2, self.depth + 3 - n_workers))  # a worker holds at most this many arenas
+                while not stop.is_set():
+                    with cond:
+                        while not stop.is_set() and state["taken"] - state["consumed"] >= window:
+                            cond.wait(0.05)
                     if stop.is_set():
                         break
-                    q.put(self._make(idx, n_real, stream, ring))
-                q.put(None)
+                    job = take()
+                    if job is None:
+                        break
+                    seq, idx, n_real = job
+                    item = self._make(idx, n_real, stream, ring)
+                    with cond:
+                        results[seq] = item
+                        cond.notify_all()
             except BaseException as e:  # surface worker errors in the consumer
-                q.put(e)
+                with cond:
+                    state["error"] = e
+                    cond.notify_all()
+            finally:
+                with cond:
+                    state["alive"] -= 1
+                    cond.notify_all()
 
-        t = threading.Thread(target=work, daemon=True)
-        t.start()
+        threads = [threading.Thread(target=work, daemon=True) for _ in range(n_workers)]
+        for t in threads:
+            t.start()
         try:
+            seq = 0
             while True:
-                item = q.get()
-                if item is None:
-                    break
-                if isinstance(item, BaseException):
-                    raise item
-                batch, y_t, w_t, ev = item
+                with cond:
+                    while seq not in results and state["error"] is None and state["alive"] > 0:
+                        cond.wait(0.05)
+                    if state["error"] is not None:
+                        raise state["error"]
+                    if seq not in results:
+                        break  # every worker has finished and this batch was never produced: end of the stream
+                    batch, y_t, w_t, ev = results.pop(seq)
+                    state["consumed"] += 1
+                    cond.notify_all()
+                seq += 1
                 cur = torch.cuda.current_stream(dev)
                 cur.wait_event(ev)
                 # everything the worker's stream allocated and this stream will read: the arena, the feature rows
@@ -248,8 +292,8 @@ class DeviceBatchPipeline:
                 yield batch, y_t, w_t
         finally:
             stop.set()
-            while t.is_alive():
-                try:
-                    q.get_nowait()
-                except queue.Empty:
-                    t.join(timeout=0.05)
+            with cond:
+                cond.notify_all()
+            for t in threads:
+                t.join(timeout=5.0)
+
