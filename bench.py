@@ -343,6 +343,24 @@ def main():
             m3.fit(part, nb_epoch=2, checkpoint_interval=0)
             torch.cuda.synchronize()
             out["config"]["fit_molecules_per_s_batch_%d" % bsz] = round(2 * n_part / (time.perf_counter() - t1), 1)
+        # the same loop on a set whose rows are featurizer-shaped (one-hot blocks): kept, collated and copied as
+        # 8-byte atom codes and expanded on the GPU (deepchem_amd/feat/atom_codes.py)
+        from deepchem_amd.utils.synthetic import PackedMols
+        rng = np.random.RandomState(5)
+        big = packed.select(np.arange(4 * args.batch) % n_fit)
+        codes = np.stack([rng.randint(0, hi, big.n_atoms) for hi in (44, 11, 7, 1, 1, 5, 2, 5)], axis=1).astype(np.uint8)
+        coded = PackedMols(None, big.atom_ptr, big.adj_ptr, big.adj_idx, codes)
+        yb, wb = synthetic_labels(big.n_mols, args.tasks, "classification", seed=6)
+        m4 = dc.models.torch_models.GraphConvModel(args.tasks, number_input_features=[75, 64], batch_size=args.batch,
+                                                   grad_mode=args.grad_mode, device=device, log_frequency=10**9)
+        ds4 = dc.data.PackedDataset(coded, yb, wb)
+        m4.fit(ds4, nb_epoch=1, checkpoint_interval=0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        m4.fit(ds4, nb_epoch=2, checkpoint_interval=0)
+        torch.cuda.synchronize()
+        out["config"]["fit_molecules_per_s_batch_%d_atom_codes" % args.batch] = round(
+            2 * big.n_mols / (time.perf_counter() - t1), 1)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
