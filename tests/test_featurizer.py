@@ -192,3 +192,31 @@ def test_csv_loader_with_the_native_featurizer(tmp_path):
     assert isinstance(ds.X[0], dc.feat.ConvMol)
     assert ds.X[0].get_atom_features().shape[1] == 75
     assert ds.ids[0] == "c1ccsc1" or isinstance(ds.ids[0], str)
+
+
+def test_mutated_smiles_agree_with_the_oracle_and_never_crash():
+    """Seeded fuzz: edits of real SMILES (most of them malformed) -- the reader and the oracle accept and reject
+    the same strings and agree on every column of the accepted ones."""
+    import random
+    with open(os.path.join(HERE, "golden", "smiles_sample.txt")) as f:
+        smiles = [l.strip() for l in f if l.strip() and not l.startswith("#")]
+    rnd = random.Random(7)
+    alphabet = "CNOSPFIBclnops[]()=#:.-+H123Brse"
+
+    def mutate(s):
+        s = list(s)
+        for _ in range(rnd.randint(1, 3)):
+            op = rnd.random()
+            if op < 0.35 and s:
+                s[rnd.randrange(len(s))] = rnd.choice(alphabet)
+            elif op < 0.7:
+                s.insert(rnd.randrange(len(s) + 1), rnd.choice(alphabet))
+            elif s:
+                del s[rnd.randrange(len(s))]
+        return "".join(s)
+
+    short = [s for s in smiles if len(s) <= 40]
+    batch = [mutate(rnd.choice(short)) for _ in range(1500)]
+    batch += ["".join(rnd.choice(alphabet + "%@/\\ 0") for _ in range(rnd.randint(0, 25))) for _ in range(300)]
+    n_valid = _check_against_oracle(batch)
+    assert 100 < n_valid < 1000
