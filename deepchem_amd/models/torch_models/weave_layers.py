@@ -197,7 +197,16 @@ class WeaveLayer(nn.Module):
         w_p = torch.zeros((Hp + H2p, w.shape[1]), dtype=torch.float32, device=self.device)
         w_p[:H] = w[:H]
         w_p[Hp:Hp + H2] = w[H:]
-        P_out = self._linear(Z, w_p, b, True)
+        # the output block is padded to a multiple of four columns too: the product runs on the split-bf16 kernel
+        # (which wants 16-byte output quads) and the next layer reads 16-byte addressable pair rows; callers see
+        # the (n_pairs, n_pair_output_feat) view
+        Ho = w.shape[1]
+        Hop = (Ho + 3) // 4 * 4
+        w_po = torch.zeros((Hp + H2p, Hop), dtype=torch.float32, device=self.device)
+        w_po[:, :Ho] = w_p
+        b_po = torch.zeros(Hop, dtype=torch.float32, device=self.device)
+        b_po[:Ho] = b
+        P_out = self._linear(Z, w_po, b_po, True)[:, :Ho]
         return [A_out, P_out]
 
 
