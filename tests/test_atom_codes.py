@@ -125,3 +125,44 @@ def test_training_on_codes_equals_training_on_floats():
     # runs drift apart chaotically (arg-max flips), which is why this stops after two steps
     np.testing.assert_allclose(after[0], after[1], rtol=0, atol=1e-4)
     assert np.abs(after[0] - first[0]).max() > 1e-3  # and the steps did move the model
+
+
+@pytest.mark.gpu
+def test_pipeline_hands_batches_out_in_order_and_shuts_down():
+    """Two collation workers: results come back in the order of the index batches, a failing batch raises in the
+    consumer, and abandoning the iterator does not leave threads behind."""
+    import threading
+    from deepchem_amd.data.packed_dataset import DeviceBatchPipeline
+    coded, _ = dc.feat.ConvMolFeaturizer().featurize_packed(_sample_smiles())
+    n = coded.n_mols
+    y = np.arange(n, dtype=np.float64).reshape(-1, 1)
+    w = np.ones_like(y)
+    rng = np.random.RandomState(0)
+    batches = [(rng.permutation(n)[:rng.randint(5, 60)].astype(np.int64), None) for _ in range(40)]
+    batches = [(idx, idx.shape[0] - (k % 3)) for k, (idx, _) in enumerate(batches)]  # some padded tails
+    sizes = np.diff(coded.atom_ptr)
+    dev = torch.device("cuda:0")
+    before = threading.active_count()
+    for workers in (1, 2, 3):
+        pipe = DeviceBatchPipeline(coded, y, w, iter(batches), dev, None, workers=workers)
+        seen = 0
+        for (idx, n_real), (batch, y_t, w_t) in zip(batches, pipe):
+            assert batch.n_atoms == int(sizes[idx].sum())
+            np.testing.assert_array_equal(y_t.cpu().numpy().reshape(-1), idx.astype(np.float32))
+            expect_w = np.ones(idx.shape[0], np.float32)
+            expect_w[n_real:] = 0
+            np.testing.assert_array_equal(w_t.cpu().numpy().reshape(-1), expect_w)
+            seen += 1
+        assert seen == len(batches)
+    # an index outside the set: the worker's exception surfaces here
+    bad = batches[:3] + [(np.array([0, n + 5], np.int64), 2)] + batches[3:6]
+    with pytest.raises(IndexError):
+        for _ in DeviceBatchPipeline(coded, y, w, iter(bad), dev, None):
+            pass
+    # abandon after two batches
+    it = iter(DeviceBatchPipeline(coded, y, w, iter(batches), dev, None))
+    next(it)
+    next(it)
+    it.close()
+    torch.cuda.synchronize()
+    assert threading.active_count() <= before + 1
