@@ -18,7 +18,7 @@ namespace gcmi {
 constexpr int kBBlock = 256;
 constexpr int kRowsPerBlock = 512;     // smallest share of rows a workgroup takes
 constexpr int kResidentBlocks = 2048;  // 256 CUs x 8 workgroups of 256 threads
-constexpr int kReplicas = 32;  // accumulator replicas: same-address fp64 atomics serialise
+constexpr int kReplicas = kBnReplicas;  // accumulator replicas: same-address fp64 atomics serialise
 // scratch layout (doubles): [0, 2F) backward coefficient vectors (3F floats), then kReplicas blocks
 // of 2F partial sums.  The kernels that consume the partial sums zero them again, so a scratch
 // that starts clean stays clean (the whole-model path zeroes it once per pass).
@@ -372,6 +372,19 @@ int bn_stats_impl(const float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat,
   TimedScope ts(GCMI_K_BATCHNORM, st);
   int rc = launch_col_sums(0, d_x, ldx, nullptr, 0, nullptr, nullptr, n_rows, n_feat, d_acc, acc_clean, st);
   if (rc) return rc;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((n_feat + 255) / 256), dim3(256), 0, st, d_acc, n_rows,
+                     n_feat, d_gamma, d_beta, eps, momentum, d_running_mean, d_running_var, d_mean,
+                     d_invstd, d_scale, d_shift);
+  GCMI_CHECK_LAUNCH("bn_finalize");
+  return GCMI_OK;
+}
+
+int bn_finalize_impl(int64_t n_rows, int32_t n_feat, const float* d_gamma, const float* d_beta, float eps,
+                     float momentum, float* d_running_mean, float* d_running_var, float* d_mean, float* d_invstd,
+                     float* d_scale, float* d_shift, double* d_acc, void* stream) {
+  GCMI_CHECK_ARG(n_feat > 0 && n_rows > 0 && d_scale && d_shift && d_acc, "bn_finalize: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  TimedScope ts(GCMI_K_BATCHNORM, st);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((n_feat + 255) / 256), dim3(256), 0, st, d_acc, n_rows,
                      n_feat, d_gamma, d_beta, eps, momentum, d_running_mean, d_running_var, d_mean,
                      d_invstd, d_scale, d_shift);

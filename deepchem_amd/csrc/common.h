@@ -99,7 +99,22 @@ int launch_seg_gemm4(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg
                      int64_t lda1, int32_t k1, const float* d_w1, const int64_t* w1_off, const float* d_a2,
                      int64_t lda2, int32_t k2, const float* d_w2, const int64_t* w2_off, const float* d_bias,
                      const int64_t* bias_off, int32_t n_out, int32_t trans_w, int32_t act, float* d_out,
-                     int64_t ldo, hipStream_t sm);
+                     int64_t ldo, hipStream_t sm, double* d_stats = nullptr);
+
+// accumulator replicas of the BatchNorm column sums (same-address fp64 atomics serialise); scratch layout in
+// doubles: [0, 2F) backward coefficient vectors, then kBnReplicas blocks of [sum(F) | sum of squares(F)]
+constexpr int kBnReplicas = 32;
+// gcmi_seg_gemm with the column sums of the output (after bias and activation) added into d_stats in that layout
+// by the product's own epilogue; *fused = false (and nothing added) when the kernel in charge cannot do it
+int seg_gemm_stats(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_end, const float* d_a1, int64_t lda1,
+                   int32_t k1, const float* d_w1, const int64_t* w1_off, const float* d_a2, int64_t lda2, int32_t k2,
+                   const float* d_w2, const int64_t* w2_off, const float* d_bias, const int64_t* bias_off,
+                   int32_t n_out, int32_t trans_w, int32_t act, float* d_out, int64_t ldo, double* d_stats,
+                   bool* fused, void* stream);
+// the part of bn_stats_impl after the column sums
+int bn_finalize_impl(int64_t n_rows, int32_t n_feat, const float* d_gamma, const float* d_beta, float eps,
+                     float momentum, float* d_running_mean, float* d_running_var, float* d_mean, float* d_invstd,
+                     float* d_scale, float* d_shift, double* d_acc, void* stream);
 
 // BatchNorm / loss with a caller-guaranteed clean accumulator scratch (bn.hip, loss.hip): the
 // whole-model path zeroes its scratch once per pass instead of once per call.

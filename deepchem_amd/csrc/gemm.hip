@@ -786,6 +786,39 @@ int gcmi_relu_bwd(float* d_g, int64_t ldg, const float* d_y, int64_t ldy, int64_
 
 }  // extern "C"
 
+namespace gcmi {
+
+int seg_gemm_stats(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_end, const float* d_a1, int64_t lda1,
+                   int32_t k1, const float* d_w1, const int64_t* w1_off, const float* d_a2, int64_t lda2, int32_t k2,
+                   const float* d_w2, const int64_t* w2_off, const float* d_bias, const int64_t* bias_off,
+                   int32_t n_out, int32_t trans_w, int32_t act, float* d_out, int64_t ldo, double* d_stats,
+                   bool* fused, void* stream) {
+  *fused = false;
+  // GCMI_GEMM_STATS=0: never fuse the BatchNorm column sums into the product's epilogue
+  static const bool allow = !(getenv("GCMI_GEMM_STATS") && atoi(getenv("GCMI_GEMM_STATS")) == 0);
+  static const bool v3 = getenv("GCMI_GEMM_V3") && atoi(getenv("GCMI_GEMM_V3")) == 1;
+  static const bool v4 = !(getenv("GCMI_GEMM_V4") && atoi(getenv("GCMI_GEMM_V4")) == 0);
+  const bool shapes_ok = n_seg >= 1 && n_seg <= kMaxSeg && seg_begin && seg_end && n_out > 0 && ldo >= n_out && d_out &&
+                         (d_a1 || d_a2) && (d_a1 == nullptr || (d_w1 && w1_off && k1 > 0 && lda1 >= k1)) &&
+                         (d_a2 == nullptr || (d_w2 && w2_off && k2 > 0 && lda2 >= k2)) &&
+                         (d_bias == nullptr || bias_off != nullptr) && (act == 0 || act == 1);
+  if (allow && d_stats && shapes_ok && v4 && !v3 && !gemm_exact_mode()) {
+    hipStream_t sm = (hipStream_t)stream;
+    TimedScope ts(GCMI_K_SEG_GEMM, sm);
+    const int rc = launch_seg_gemm4(n_seg, seg_begin, seg_end, d_a1, lda1, k1, d_w1, w1_off, d_a2, lda2, k2, d_w2,
+                                    w2_off, d_bias, bias_off, n_out, trans_w, act, d_out, ldo, sm, d_stats);
+    if (rc != GCMI_ERR_UNSUPPORTED) {
+      *fused = rc == GCMI_OK;
+      return rc;
+    }
+  }
+  return gcmi_seg_gemm(n_seg, seg_begin, seg_end, d_a1, lda1, k1, d_w1, w1_off, d_a2, lda2, k2, d_w2, w2_off, d_bias,
+                       bias_off, n_out, trans_w, act, d_out, ldo, stream);
+}
+
+}  // namespace gcmi
+
+
 // ------------------------------------------------------------------ diagnostics
 // Peak rate of v_mfma_f32_32x32x2_f32 from registers (no memory traffic): the ceiling the
 // GEMM kernels are priced against on THIS device (tools/kbench.py --only mfma_peak).

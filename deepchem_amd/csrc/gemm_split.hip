@@ -424,13 +424,22 @@ template <bool TRANS, int NT, bool AVEC>
 __global__ void __launch_bounds__(kS3Block) __attribute__((amdgpu_waves_per_eu(NT <= 2 ? 3 : 2)))
 seg_gemm4_kernel(SegTable3 st, const float* __restrict__ a1, int64_t lda1, int k1, const float* __restrict__ w1,
                  const float* __restrict__ a2, int64_t lda2, int k2, const float* __restrict__ w2,
-                 const float* __restrict__ bias, int n_out, int act, float* __restrict__ out, int64_t ldo) {
+                 const float* __restrict__ bias, int n_out, int act, float* __restrict__ out, int64_t ldo,
+                 double* __restrict__ stats) {
   constexpr int NB = NT * 32;
   constexpr int APASS = 4;                       // 128 rows / (256 threads / 8 lanes per row piece)
   constexpr int BPASS = (kS4KC * NB) / kS3Block;  // weight elements per thread per chunk
-  __shared__ __attribute__((aligned(16))) float As[kS3Rows][kS4AStride];
-  __shared__ __attribute__((aligned(16))) unsigned short Ws[3][NB][kS4WStride];
+  // one raw LDS block: the staged operands during the K loop, the output tile of the statistics epilogue after it
+  constexpr int HC = NB < 64 ? NB : 64;           // columns summed per pass of the statistics epilogue
+  constexpr int TP = HC + 1;                      // tile pitch in floats: column reads hit 64 different banks
+  constexpr size_t kOperandBytes = sizeof(float) * kS3Rows * kS4AStride + sizeof(unsigned short) * 3 * NB * kS4WStride;
+  constexpr size_t kTileBytes = sizeof(float) * 4 * 32 * TP;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kOperandBytes > kTileBytes ? kOperandBytes : kTileBytes];
+  float (*As)[kS4AStride] = reinterpret_cast<float (*)[kS4AStride]>(lds_raw);
+  unsigned short (*Ws)[NB][kS4WStride] =
+      reinterpret_cast<unsigned short (*)[NB][kS4WStride]>(lds_raw + sizeof(float) * kS3Rows * kS4AStride);
   __shared__ __attribute__((aligned(16))) float bias_lds[NB];
+  __shared__ double col_part[4][2][NB];           // per-wave column sums / sums of squares
   const int b = blockIdx.x;
   int s = 0;
 #pragma unroll
@@ -615,14 +624,67 @@ seg_gemm4_kernel(SegTable3 st, const float* __restrict__ a1, int64_t lda1, int k
       }
     }
   }
+
+  // ---- BatchNorm statistics of this tile (training forward): column sums and sums of squares of the values just
+  // written (after bias and activation), so that the layer output is not read again for them.  The accumulator
+  // holds out^T (lane = row, registers = columns): every wave lays its 32 x HC tile out in LDS (free after the K
+  // loop), a lane then adds one column over the 32 rows, the four waves' partials meet in LDS and one fp64 atomic
+  // per column and workgroup goes to the replicated accumulators bn_finalize_kernel reads.
+  if (stats != nullptr) {  // uniform
+    float* T = reinterpret_cast<float*>(lds_raw) + wave * 32 * TP;
+    const int rl = lane & 31;
+    const bool row_ok = r < rows_valid;
+    const float4* bias4 = reinterpret_cast<const float4*>(bias_lds);
+#pragma unroll
+    for (int h = 0; h < (NT + 1) / 2; ++h) {
+#pragma unroll
+      for (int tt = 0; tt < (NT >= 2 ? 2 : 1); ++tt) {
+        const int t = 2 * h + tt;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int cl = t * 32 + 8 * rg + 4 * half;
+          const float4 bq = bias4[cl >> 2];
+          float v[4] = {acc[t][4 * rg] + bq.x, acc[t][4 * rg + 1] + bq.y, acc[t][4 * rg + 2] + bq.z,
+                        acc[t][4 * rg + 3] + bq.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x = (act == 1 && !(v[e] > 0.f)) ? 0.f : v[e];
+            if (!row_ok || col0 + cl + e >= n_out) x = 0.f;
+            T[rl * TP + (cl - 64 * h) + e] = x;
+          }
+        }
+      }
+      // the tile is this wave's own: no workgroup barrier between the writes and the column reads
+      if (lane < HC) {
+        double s1 = 0.0, s2 = 0.0;  // fp64 like the stand-alone column-sum kernel: the statistics then differ
+#pragma unroll 8               // from it by summation order only (~1e-16), not by fp32 rounding (~1e-7)
+        for (int rr = 0; rr < 32; ++rr) {
+          const double x = (double)T[rr * TP + lane];
+          s1 += x;
+          s2 += x * x;
+        }
+        col_part[wave][0][64 * h + lane] = s1;
+        col_part[wave][1][64 * h + lane] = s2;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * NB; e += kS3Block) {
+      const int which = e / NB, c = e - which * NB;
+      if (col0 + c < n_out) {
+        const double tot = col_part[0][which][c] + col_part[1][which][c] + col_part[2][which][c] + col_part[3][which][c];
+        atomicAdd(stats + (size_t)2 * n_out * (1 + (blockIdx.x % kBnReplicas)) + (size_t)which * n_out + col0 + c, tot);
+      }
+    }
+  }
 }
 
 int launch_seg_gemm4(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_end, const float* d_a1,
                      int64_t lda1, int32_t k1, const float* d_w1, const int64_t* w1_off, const float* d_a2,
                      int64_t lda2, int32_t k2, const float* d_w2, const int64_t* w2_off, const float* d_bias,
                      const int64_t* bias_off, int32_t n_out, int32_t trans_w, int32_t act, float* d_out,
-                     int64_t ldo, hipStream_t sm) {
+                     int64_t ldo, hipStream_t sm, double* d_stats) {
   if (n_seg > kS3MaxSeg) return GCMI_ERR_UNSUPPORTED;
+  if (d_stats && act == 2) return GCMI_ERR_UNSUPPORTED;
   const bool avec = !((d_a1 && (!aligned16(d_a1) || lda1 % 4)) || (d_a2 && (!aligned16(d_a2) || lda2 % 4)));
   if (n_out % 4 || ldo % 4 || !aligned16(d_out)) return GCMI_ERR_UNSUPPORTED;
   const int nt = n_out <= 32 ? 1 : (n_out <= 64 ? 2 : 4);
@@ -650,10 +712,10 @@ int launch_seg_gemm4(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg
   do {                                                                                                         \
     if (avec)                                                                                                  \
       hipLaunchKernelGGL((seg_gemm4_kernel<TT, NN, true>), grid, dim3(kS3Block), 0, sm, st, d_a1, lda1, k1, d_w1,   \
-                         d_a2, lda2, k2, d_w2, d_bias, n_out, act, d_out, ldo);                                \
+                         d_a2, lda2, k2, d_w2, d_bias, n_out, act, d_out, ldo, d_stats);                       \
     else                                                                                                       \
       hipLaunchKernelGGL((seg_gemm4_kernel<TT, NN, false>), grid, dim3(kS3Block), 0, sm, st, d_a1, lda1, k1, d_w1,  \
-                         d_a2, lda2, k2, d_w2, d_bias, n_out, act, d_out, ldo);                                \
+                         d_a2, lda2, k2, d_w2, d_bias, n_out, act, d_out, ldo, d_stats);                       \
   } while (0)
   if (trans_w) {
     if (nt == 1) LAUNCH_S4(true, 1); else if (nt == 2) LAUNCH_S4(true, 2); else LAUNCH_S4(true, 4);

@@ -169,18 +169,24 @@ int gcmi_model_forward(const gcmi_model_desc* m, const gcmi_graph* g, const floa
     set_error("model_forward: memset failed");
     return GCMI_ERR_LAUNCH;
   }
+  bool stats_fused = false;
   for (int l = 0; l < L; ++l) {
     const int K = l == 0 ? m->n_feat_in : m->conv_width[l - 1];
     const int W = m->conv_width[l];
     const Segs sg = make_segs(g, K, W);
+    stats_fused = false;
     hipLaunchKernelGGL(bias_pack_kernel, dim3(4), dim3(256), 0, st, d_params + m->off_conv_b[l],
                        m->max_deg, W, ws + w.bsum[l]);
     GCMI_CHECK_LAUNCH("bias_pack");
     if (N > 0) {
       RUN(gcmi_gather_sum_fwd(g, x, ldx, (int32_t)w.ngather[l], ws + w.S[l], w.ldS[l], 0, stream));
-      RUN(gcmi_seg_gemm(sg.n, sg.begin, sg.end, ws + w.S[l], w.ldS[l], K, d_params + m->off_conv_w[l],
-                        sg.w_rel, x, ldx, K, d_params + m->off_conv_w[l], sg.w_self, ws + w.bsum[l],
-                        sg.b_off, W, 0, 1, ws + w.gc[l], W, stream));
+      // training with BatchNorm: the product's epilogue also adds the column sums of its output into the
+      // BatchNorm accumulators (clean: zeroed above, self-cleaning afterwards), so the layer output is not read again
+      RUN(seg_gemm_stats(sg.n, sg.begin, sg.end, ws + w.S[l], w.ldS[l], K, d_params + m->off_conv_w[l],
+                         sg.w_rel, x, ldx, K, d_params + m->off_conv_w[l], sg.w_self, ws + w.bsum[l],
+                         sg.b_off, W, 0, 1, ws + w.gc[l], W,
+                         (m->batch_norm && training) ? reinterpret_cast<double*>(ws + w.acc) : nullptr,
+                         &stats_fused, stream));
     }
     float* scale = nullptr;
     float* shift = nullptr;
@@ -188,7 +194,11 @@ int gcmi_model_forward(const gcmi_model_desc* m, const gcmi_graph* g, const floa
       float* bnv = ws + w.bnv[l];
       scale = bnv + 2 * W;
       shift = bnv + 3 * W;
-      if (training) {
+      if (training && stats_fused) {
+        RUN(bn_finalize_impl(N, W, d_params + m->off_bn_gamma[l], d_params + m->off_bn_beta[l], m->bn_eps,
+                             m->bn_momentum, io->d_bn_running_mean[l], io->d_bn_running_var[l], bnv, bnv + W,
+                             scale, shift, reinterpret_cast<double*>(ws + w.acc), stream));
+      } else if (training) {
         RUN(bn_stats_impl(ws + w.gc[l], W, N, W, d_params + m->off_bn_gamma[l],
                           d_params + m->off_bn_beta[l], m->bn_eps, m->bn_momentum,
                           io->d_bn_running_mean[l], io->d_bn_running_var[l], bnv, bnv + W, scale, shift,
@@ -211,9 +221,10 @@ int gcmi_model_forward(const gcmi_model_desc* m, const gcmi_graph* g, const floa
   const int64_t zero64 = 0;
   if (N > 0) {
     const int32_t nN = (int32_t)N;
-    RUN(gcmi_seg_gemm(1, &zero32, &nN, x, ldx, Wl, d_params + m->off_dense_w, &zero64, nullptr, 0, 0,
-                      nullptr, nullptr, d_params + m->off_dense_b, &zero64, D, 1, 1, ws + w.dense, D,
-                      stream));
+    RUN(seg_gemm_stats(1, &zero32, &nN, x, ldx, Wl, d_params + m->off_dense_w, &zero64, nullptr, 0, 0,
+                       nullptr, nullptr, d_params + m->off_dense_b, &zero64, D, 1, 1, ws + w.dense, D,
+                       (m->batch_norm && training) ? reinterpret_cast<double*>(ws + w.acc) : nullptr,
+                       &stats_fused, stream));
   }
   float* scale = nullptr;
   float* shift = nullptr;
@@ -221,7 +232,11 @@ int gcmi_model_forward(const gcmi_model_desc* m, const gcmi_graph* g, const floa
     float* bnv = ws + w.bnv[L];
     scale = bnv + 2 * D;
     shift = bnv + 3 * D;
-    if (training) {
+    if (training && stats_fused) {
+      RUN(bn_finalize_impl(N, D, d_params + m->off_bn_gamma[L], d_params + m->off_bn_beta[L], m->bn_eps,
+                           m->bn_momentum, io->d_bn_running_mean[L], io->d_bn_running_var[L], bnv, bnv + D, scale,
+                           shift, reinterpret_cast<double*>(ws + w.acc), stream));
+    } else if (training) {
       RUN(bn_stats_impl(ws + w.dense, D, N, D, d_params + m->off_bn_gamma[L], d_params + m->off_bn_beta[L],
                         m->bn_eps, m->bn_momentum, io->d_bn_running_mean[L], io->d_bn_running_var[L], bnv,
                         bnv + D, scale, shift, reinterpret_cast<double*>(ws + w.acc), true, stream));
