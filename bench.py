@@ -301,9 +301,9 @@ def main():
                          (N * (64 + 64) + N * (64 + 64 + 64) if args.grad_mode == "full" else 0)),
         # dW = A^T dY per operand: head, dense, GraphConv 1 (S and X), GraphConv 0 (S and X)
         "wgrad": 4 * (B * (256 + 24) + N * (64 + 128) + 2 * N * (64 + 64) + 2 * N * (75 + 64)),
-        # statistics: one read of the layer output (64, 64, 128 wide); backward: dy and y read for the
-        # sums, read again and dx written by the second pass (the 128-wide dy is recomputed, not read)
-        "batchnorm": 4 * N * (64 + 64 + 128) + 4 * N * (5 * 64 + 5 * 64 + 3 * 128),
+        # forward statistics ride in the epilogue of the producing product (no bytes of their own); backward: dy and
+        # y read for the sums, read again and dx written by the second pass (the 128-wide dy is recomputed, not read)
+        "batchnorm": 4 * N * (5 * 64 + 5 * 64 + 3 * 128),
     }
     out["roofline_by_kernel"] = {
         k: {"ms": round(ktimes[k][1] / breakdown_steps, 4), "algorithmic_bytes": int(fam_bytes[k]),
