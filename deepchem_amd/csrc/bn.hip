@@ -32,6 +32,10 @@ struct ReadoutGrad {
   const float* g2;            // n_mols x ldg2 (>= 2F)
   int64_t ldg2;
   const int32_t* arg;         // n_mols x F
+  // optional: what the column sums need to come from per-molecule data (readout_bn_sums_kernel)
+  const float* rawsum = nullptr;  // n_mols x F row sums of the BatchNorm input
+  const int32_t* runs = nullptr;  // n_mols x n_deg x 2 row runs
+  int32_t n_mols = 0, n_deg = 0;
 };
 
 template <int V>
@@ -473,12 +477,70 @@ int bn_bwd_impl(const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx, 
 }
 
 // BatchNorm backward whose incoming gradient is the GraphGather backward, recomputed on the fly
+// Column sums of the BatchNorm backward behind a GraphGather, from per-molecule data only.  The gradient of a row is
+// dy[r,f] = gs[mol][f] + (arg[mol][f] == r) gm[mol][f], so
+//   sum_r dy       = sum_mol n_mol gs + gm                       (gm only where the molecule has an arg-max row)
+//   sum_r dy xhat  = sum_mol gs (sum_{r in mol} xhat) + gm xhat[arg]
+// with sum_{r in mol} xhat = invstd (sum_{r in mol} x - n_mol mean): the readout's forward leaves the per-molecule
+// row sums behind, the arg-max row's value is one gathered element.  B x F work instead of a pass over N x F.
+__global__ void __launch_bounds__(256)
+readout_bn_sums_kernel(int n_mols, int n_feat, int n_deg, const int32_t* __restrict__ runs,
+                       const float* __restrict__ g2, int64_t ldg2, const int32_t* __restrict__ arg,
+                       const float* __restrict__ rawsum, const float* __restrict__ x, int64_t ldx,
+                       const float* __restrict__ mean, const float* __restrict__ invstd, int chunks,
+                       double* __restrict__ sums) {
+  // a wave owns one 64-column chunk and walks molecules; the launcher makes the wave count a multiple of `chunks`
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * blockDim.x) >> 6;
+  const int groups = n_waves / chunks;  // waves past groups * chunks have no chunk of their own
+  if (groups == 0 || wave >= groups * chunks) return;
+  const int chunk = wave % chunks;
+  const int f = chunk * 64 + lane;
+  const bool ok = f < n_feat;
+  const int fc = ok ? f : 0;
+  const double mu = (double)mean[fc], is = (double)invstd[fc];
+  double t1 = 0.0, t2 = 0.0;
+  for (int m = wave / chunks; m < n_mols; m += groups) {
+    // atoms of the molecule: the first n_deg lanes each take one run
+    int len = 0;
+    if (lane < n_deg) {
+      const int2 r = *reinterpret_cast<const int2*>(runs + ((int64_t)m * n_deg + lane) * 2);
+      len = r.y - r.x;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) len += __shfl_xor(len, o, 64);  // n_deg <= 16
+    const int n = __shfl(len, 0, 64);
+    const double gs = (double)g2[(int64_t)m * ldg2 + fc];
+    const int a = arg[(int64_t)m * n_feat + fc];
+    const int ac = a >= 0 ? a : 0;
+    const float gmf = g2[(int64_t)m * ldg2 + n_feat + fc];
+    const float xaf = x[(int64_t)ac * ldx + fc];
+    const float rs = rawsum[(int64_t)m * n_feat + fc];
+    const double gm = a >= 0 ? (double)gmf : 0.0;
+    const double xa = a >= 0 ? ((double)xaf - mu) * is : 0.0;
+    const double xs = ((double)rs - (double)n * mu) * is;
+    t1 += (double)n * gs + gm;
+    t2 += gs * xs + gm * xa;
+  }
+  if (ok) {
+    double* rep = sums + (size_t)2 * n_feat * (1 + (wave / chunks) % kReplicas);
+    atomicAdd(rep + f, t1);
+    atomicAdd(rep + n_feat + f, t2);
+  }
+}
+
 int bn_bwd_readout_impl(const int32_t* d_membership, const float* d_g2, int64_t ldg2, const int32_t* d_arg,
                         const float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat, const float* d_gamma,
                         const float* d_mean, const float* d_invstd, float* d_dgamma, float* d_dbeta, float* d_dx,
-                        int64_t lddx, int32_t relu_mask, double* d_acc, bool acc_clean, void* stream) {
+                        int64_t lddx, int32_t relu_mask, double* d_acc, bool acc_clean, void* stream,
+                        const float* d_rawsum, const int32_t* d_mol_runs, int32_t n_mols, int32_t n_deg) {
   GCMI_CHECK_ARG(d_membership && d_g2 && d_arg && ldg2 >= 2 * (int64_t)n_feat, "bn_bwd_readout: bad readout gradient");
-  const ReadoutGrad rg{d_membership, d_g2, ldg2, d_arg};
+  ReadoutGrad rg{d_membership, d_g2, ldg2, d_arg};
+  rg.rawsum = d_rawsum;
+  rg.runs = d_mol_runs;
+  rg.n_mols = n_mols;
+  rg.n_deg = n_deg;
   return bn_bwd_any(&rg, nullptr, 0, d_x, ldx, n_rows, n_feat, d_gamma, d_mean, d_invstd, d_dgamma, d_dbeta, d_dx,
                     lddx, relu_mask, d_acc, acc_clean, stream);
 }
@@ -492,7 +554,25 @@ static int bn_bwd_any(const ReadoutGrad* rgp, const float* d_dy, int64_t lddy, c
   GCMI_CHECK_ARG(d_dx == nullptr || lddx >= n_feat, "bn_bwd: bad lddx");
   hipStream_t st = (hipStream_t)stream;
   TimedScope ts(GCMI_K_BATCHNORM, st);
-  int rc = launch_col_sums(1, d_dy, lddy, d_x, ldx, d_mean, d_invstd, n_rows, n_feat, d_acc, acc_clean, st, rgp);
+  int rc = GCMI_OK;
+  if (rgp && rgp->rawsum && rgp->runs && rgp->n_mols > 0) {
+    if (!acc_clean &&
+        hipMemsetAsync(d_acc, 0, sizeof(double) * 2 * n_feat * (1 + kReplicas), st) != hipSuccess) {
+      set_error("bn: memset failed");
+      return GCMI_ERR_LAUNCH;
+    }
+    const int chunks = (n_feat + 63) / 64;
+    int waves = 4096 / chunks * chunks;  // resident waves of 256 CUs x 16, a multiple of the chunk count
+    const int64_t jobs = (int64_t)rgp->n_mols * chunks;
+    if (jobs < waves) waves = (int)((jobs + chunks - 1) / chunks * chunks);
+    const int blocks = (waves + 3) / 4;  // waves beyond `waves` (at most 3) simply walk from a later molecule
+    hipLaunchKernelGGL(readout_bn_sums_kernel, dim3(blocks), dim3(256), 0, st, rgp->n_mols, n_feat, rgp->n_deg,
+                       rgp->runs, rgp->g2, rgp->ldg2, rgp->arg, rgp->rawsum, d_x, ldx, d_mean, d_invstd, chunks,
+                       d_acc);
+    GCMI_CHECK_LAUNCH("readout_bn_sums");
+  } else {
+    rc = launch_col_sums(1, d_dy, lddy, d_x, ldx, d_mean, d_invstd, n_rows, n_feat, d_acc, acc_clean, st, rgp);
+  }
   if (rc) return rc;
   // coefficient vectors (3F floats) live in the first 2F doubles of the scratch
   float* coef = reinterpret_cast<float*>(d_acc);

@@ -111,6 +111,10 @@ int seg_gemm_stats(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
                    const float* d_w2, const int64_t* w2_off, const float* d_bias, const int64_t* bias_off,
                    int32_t n_out, int32_t trans_w, int32_t act, float* d_out, int64_t ldo, double* d_stats,
                    bool* fused, void* stream);
+// gcmi_readout_fwd that also leaves the per-molecule sums of the rows before the folded BatchNorm in d_rawsum
+int readout_fwd_impl(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t n_feat, const float* d_scale,
+                     const float* d_shift, int32_t act, float* d_out, int64_t ldo, int32_t* d_arg, float* d_rawsum,
+                     void* stream);
 // the part of bn_stats_impl after the column sums
 int bn_finalize_impl(int64_t n_rows, int32_t n_feat, const float* d_gamma, const float* d_beta, float eps,
                      float momentum, float* d_running_mean, float* d_running_var, float* d_mean, float* d_invstd,
@@ -129,7 +133,9 @@ int bn_bwd_impl(const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx, 
 int bn_bwd_readout_impl(const int32_t* d_membership, const float* d_g2, int64_t ldg2, const int32_t* d_arg,
                         const float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat, const float* d_gamma,
                         const float* d_mean, const float* d_invstd, float* d_dgamma, float* d_dbeta, float* d_dx,
-                        int64_t lddx, int32_t relu_mask, double* d_acc, bool acc_clean, void* stream);
+                        int64_t lddx, int32_t relu_mask, double* d_acc, bool acc_clean, void* stream,
+                        const float* d_rawsum = nullptr, const int32_t* d_mol_runs = nullptr, int32_t n_mols = 0,
+                        int32_t n_deg = 0);
 int readout_grad_prep(float* d_g, int64_t ldg, const float* d_out, int64_t ldo, int64_t n_mols, int n_feat,
                       hipStream_t st);
 int loss_impl(int32_t kind, const float* d_logits, const float* d_labels, const float* d_weights,

@@ -46,7 +46,7 @@ static inline int64_t up4(int64_t n) { return (n + 3) / 4 * 4; }
 struct Ws {
   int64_t S[kMaxL], gc[kMaxL], pool[kMaxL], arg[kMaxL], bsum[kMaxL], bnv[kMaxL + 1];
   int64_t ldS[kMaxL], ngather[kMaxL];
-  int64_t dense, arg_r, dfp, tA, tB, tC, tD, tE, total;
+  int64_t dense, arg_r, rsum, dfp, tA, tB, tC, tD, tE, total;
   // one region the backward zeroes with a single memset: [dlogits | dbsum per layer | lacc | acc]
   int64_t dlogits, dbsum[kMaxL], lacc, acc, z_end;
 };
@@ -83,6 +83,7 @@ static Ws carve(const gcmi_model_desc* m, int64_t N, int64_t B, int64_t ld_featu
   w.bnv[L] = take(4 * D);
   w.dense = take(N * D);
   w.arg_r = take(B * D);
+  w.rsum = take(B * D);  // per-molecule row sums of the dense output (BatchNorm backward behind the readout)
   w.dfp = take(B * 2 * D);
   w.tA = take(N * wmax);
   w.tB = take(N * wmax);
@@ -246,8 +247,9 @@ int gcmi_model_forward(const gcmi_model_desc* m, const gcmi_graph* g, const floa
                             stream));
     }
   }
-  RUN(gcmi_readout_fwd(g, ws + w.dense, D, D, scale, shift, 1, io->d_fingerprint, 2 * D,
-                       reinterpret_cast<int32_t*>(ws + w.arg_r), stream));
+  RUN(readout_fwd_impl(g, ws + w.dense, D, D, scale, shift, 1, io->d_fingerprint, 2 * D,
+                       reinterpret_cast<int32_t*>(ws + w.arg_r), (training && m->batch_norm) ? ws + w.rsum : nullptr,
+                       stream));
   const int TC = m->n_tasks * m->n_classes;
   const int32_t nB = (int32_t)B;
   RUN(gcmi_seg_gemm(1, &zero32, &nB, io->d_fingerprint, 2 * D, 2 * D, d_params + m->off_head_w, &zero64,
@@ -329,7 +331,8 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
     RUN(bn_bwd_readout_impl(g->d_membership, ws + w.dfp, 2 * D, reinterpret_cast<const int32_t*>(ws + w.arg_r),
                             ws + w.dense, D, N, D, d_params + m->off_bn_gamma[L], bnv, bnv + D,
                             d_grads + m->off_bn_gamma[L], d_grads + m->off_bn_beta[L], dxD, D, 1,
-                            reinterpret_cast<double*>(ws + w.acc), true, stream));
+                            reinterpret_cast<double*>(ws + w.acc), true, stream, ws + w.rsum, g->d_mol_runs,
+                            g->n_mols, g->max_deg + 1));
   } else {
     RUN(gcmi_readout_bwd(g, ws + w.dfp, 2 * D, io->d_fingerprint, 2 * D, D, 1,
                          reinterpret_cast<const int32_t*>(ws + w.arg_r), dyD, D, stream));

@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(kRBlock)
 readout_fwd_kernel(int n_mols, int n_deg, const int32_t* __restrict__ runs,
                    const float* __restrict__ x, int64_t ldx, int n_feat, int lpr, int gl,
                    const float* __restrict__ scale, const float* __restrict__ shift, int act,
-                   float* __restrict__ out, int64_t ldo, int32_t* __restrict__ arg) {
+                   float* __restrict__ out, int64_t ldo, int32_t* __restrict__ arg, float* __restrict__ rawsum) {
   const int mpb = kRBlock / gl;  // molecules per workgroup
   const int grp = threadIdx.x / gl;
   const int lane = threadIdx.x - grp * gl;
@@ -63,12 +63,13 @@ readout_fwd_kernel(int n_mols, int n_deg, const int32_t* __restrict__ runs,
   const int32_t* rb = runs + (int64_t)b * n_deg * 2;
   for (int cc = lane; cc < lpr; cc += gl) {
     const int c = cc * V;
-    float sc[V], sh[V], sum[V], mx[V];
+    float sc[V], sh[V], sum[V], mx[V], raw[V];
     int am[V];
 #pragma unroll
     for (int q = 0; q < V; ++q) {
       sc[q] = BN ? scale[c + q] : 1.f;
       sh[q] = BN ? shift[c + q] : 0.f;
+      raw[q] = 0.f;
       sum[q] = 0.f;
       mx[q] = -INFINITY;
       am[q] = -1;
@@ -95,6 +96,7 @@ readout_fwd_kernel(int n_mols, int n_deg, const int32_t* __restrict__ runs,
 #pragma unroll
           for (int q = 0; q < V; ++q) {
             const float a = BN ? fmaf(v[u][q], sc[q], sh[q]) : v[u][q];
+            raw[q] += v[u][q];
             sum[q] += a;
             if (a > mx[q]) { mx[q] = a; am[q] = r; }
           }
@@ -107,6 +109,7 @@ readout_fwd_kernel(int n_mols, int n_deg, const int32_t* __restrict__ runs,
       o[c + q] = act == 1 ? tanhf(sum[q]) : sum[q];
       o[n_feat + c + q] = act == 1 ? tanhf(mx[q]) : mx[q];
       if (arg) arg[(int64_t)b * n_feat + c + q] = am[q];
+      if (rawsum) rawsum[(int64_t)b * n_feat + c + q] = raw[q];  // sum of the rows BEFORE the folded BatchNorm
     }
   }
 }
@@ -221,6 +224,17 @@ int gcmi_build_mol_runs(const gcmi_graph* g, int32_t* d_mol_runs, int32_t* d_fla
 int gcmi_readout_fwd(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t n_feat,
                      const float* d_scale, const float* d_shift, int32_t act, float* d_out,
                      int64_t ldo, int32_t* d_arg, void* stream) {
+  return gcmi::readout_fwd_impl(g, d_x, ldx, n_feat, d_scale, d_shift, act, d_out, ldo, d_arg, nullptr, stream);
+}
+
+}  // extern "C"
+
+namespace gcmi {
+// d_rawsum (may be NULL): [n_mols x n_feat] per-molecule sums of the input rows before the folded BatchNorm -- what
+// the BatchNorm backward behind this readout needs to get its column sums without another pass over the atoms
+int readout_fwd_impl(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t n_feat, const float* d_scale,
+                     const float* d_shift, int32_t act, float* d_out, int64_t ldo, int32_t* d_arg, float* d_rawsum,
+                     void* stream) {
   int rc = check_graph(g, false);
   if (rc) return rc;
   GCMI_CHECK_ARG(n_feat > 0 && ldx >= n_feat && ldo >= 2 * (int64_t)n_feat, "readout: bad n_feat/ld");
@@ -241,7 +255,7 @@ int gcmi_readout_fwd(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t
 #define LAUNCH_RO(VV, BB)                                                                        \
   hipLaunchKernelGGL((readout_fwd_kernel<VV, BB>), dim3(blocks), dim3(kRBlock), 0, st, g->n_mols, \
                      n_deg, g->d_mol_runs, d_x, ldx, n_feat, lpr, gl, d_scale, d_shift, act,     \
-                     d_out, ldo, d_arg)
+                     d_out, ldo, d_arg, d_rawsum)
   if (V == 4) {
     if (bn) LAUNCH_RO(4, true); else LAUNCH_RO(4, false);
   } else {
@@ -251,6 +265,9 @@ int gcmi_readout_fwd(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t
   GCMI_CHECK_LAUNCH("readout_fwd");
   return GCMI_OK;
 }
+}  // namespace gcmi
+
+extern "C" {
 
 int gcmi_readout_bwd(const gcmi_graph* g, const float* d_dout, int64_t lddo, const float* d_out,
                      int64_t ldo, int32_t n_feat, int32_t act, const int32_t* d_arg,
