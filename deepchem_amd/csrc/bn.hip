@@ -33,7 +33,7 @@ struct ReadoutGrad {
   int64_t ldg2;
   const int32_t* arg;         // n_mols x F
   // optional: what the column sums need to come from per-molecule data (readout_bn_sums_kernel)
-  const float* rawsum = nullptr;  // n_mols x F row sums of the BatchNorm input
+  const float* rawsum = nullptr;  // n_mols x 2F: [row sums | arg-max row's value] of the BatchNorm input
   const int32_t* runs = nullptr;  // n_mols x n_deg x 2 row runs
   int32_t n_mols = 0, n_deg = 0;
 };
@@ -482,7 +482,7 @@ int bn_bwd_impl(const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx, 
 //   sum_r dy       = sum_mol n_mol gs + gm                       (gm only where the molecule has an arg-max row)
 //   sum_r dy xhat  = sum_mol gs (sum_{r in mol} xhat) + gm xhat[arg]
 // with sum_{r in mol} xhat = invstd (sum_{r in mol} x - n_mol mean): the readout's forward leaves the per-molecule
-// row sums behind, the arg-max row's value is one gathered element.  B x F work instead of a pass over N x F.
+// row sums and the arg-max row's value behind.  B x F work instead of a pass over N x F.
 __global__ void __launch_bounds__(256)
 readout_bn_sums_kernel(int n_mols, int n_feat, int n_deg, const int32_t* __restrict__ runs,
                        const float* __restrict__ g2, int64_t ldg2, const int32_t* __restrict__ arg,
@@ -513,10 +513,9 @@ readout_bn_sums_kernel(int n_mols, int n_feat, int n_deg, const int32_t* __restr
     const int n = __shfl(len, 0, 64);
     const double gs = (double)g2[(int64_t)m * ldg2 + fc];
     const int a = arg[(int64_t)m * n_feat + fc];
-    const int ac = a >= 0 ? a : 0;
     const float gmf = g2[(int64_t)m * ldg2 + n_feat + fc];
-    const float xaf = x[(int64_t)ac * ldx + fc];
-    const float rs = rawsum[(int64_t)m * n_feat + fc];
+    const float rs = rawsum[(int64_t)m * 2 * n_feat + fc];
+    const float xaf = rawsum[(int64_t)m * 2 * n_feat + n_feat + fc];
     const double gm = a >= 0 ? (double)gmf : 0.0;
     const double xa = a >= 0 ? ((double)xaf - mu) * is : 0.0;
     const double xs = ((double)rs - (double)n * mu) * is;

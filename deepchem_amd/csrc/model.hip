@@ -83,7 +83,7 @@ static Ws carve(const gcmi_model_desc* m, int64_t N, int64_t B, int64_t ld_featu
   w.bnv[L] = take(4 * D);
   w.dense = take(N * D);
   w.arg_r = take(B * D);
-  w.rsum = take(B * D);  // per-molecule row sums of the dense output (BatchNorm backward behind the readout)
+  w.rsum = take(2 * B * D);  // per-molecule [row sums | arg-max row value] of the dense output (BatchNorm backward)
   w.dfp = take(B * 2 * D);
   w.tA = take(N * wmax);
   w.tB = take(N * wmax);

@@ -63,13 +63,14 @@ readout_fwd_kernel(int n_mols, int n_deg, const int32_t* __restrict__ runs,
   const int32_t* rb = runs + (int64_t)b * n_deg * 2;
   for (int cc = lane; cc < lpr; cc += gl) {
     const int c = cc * V;
-    float sc[V], sh[V], sum[V], mx[V], raw[V];
+    float sc[V], sh[V], sum[V], mx[V], raw[V], rawmx[V];
     int am[V];
 #pragma unroll
     for (int q = 0; q < V; ++q) {
       sc[q] = BN ? scale[c + q] : 1.f;
       sh[q] = BN ? shift[c + q] : 0.f;
       raw[q] = 0.f;
+      rawmx[q] = 0.f;
       sum[q] = 0.f;
       mx[q] = -INFINITY;
       am[q] = -1;
@@ -98,7 +99,7 @@ readout_fwd_kernel(int n_mols, int n_deg, const int32_t* __restrict__ runs,
             const float a = BN ? fmaf(v[u][q], sc[q], sh[q]) : v[u][q];
             raw[q] += v[u][q];
             sum[q] += a;
-            if (a > mx[q]) { mx[q] = a; am[q] = r; }
+            if (a > mx[q]) { mx[q] = a; am[q] = r; rawmx[q] = v[u][q]; }
           }
         }
       }
@@ -109,7 +110,10 @@ readout_fwd_kernel(int n_mols, int n_deg, const int32_t* __restrict__ runs,
       o[c + q] = act == 1 ? tanhf(sum[q]) : sum[q];
       o[n_feat + c + q] = act == 1 ? tanhf(mx[q]) : mx[q];
       if (arg) arg[(int64_t)b * n_feat + c + q] = am[q];
-      if (rawsum) rawsum[(int64_t)b * n_feat + c + q] = raw[q];  // sum of the rows BEFORE the folded BatchNorm
+      if (rawsum) {  // [sum of the rows | value of the arg-max row], both BEFORE the folded BatchNorm
+        rawsum[(int64_t)b * 2 * n_feat + c + q] = raw[q];
+        rawsum[(int64_t)b * 2 * n_feat + n_feat + c + q] = rawmx[q];
+      }
     }
   }
 }
@@ -230,7 +234,8 @@ int gcmi_readout_fwd(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t
 }  // extern "C"
 
 namespace gcmi {
-// d_rawsum (may be NULL): [n_mols x n_feat] per-molecule sums of the input rows before the folded BatchNorm -- what
+// d_rawsum (may be NULL): [n_mols x 2 n_feat] per-molecule [sums of the input rows | value of the arg-max row], both
+// before the folded BatchNorm -- what
 // the BatchNorm backward behind this readout needs to get its column sums without another pass over the atoms
 int readout_fwd_impl(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t n_feat, const float* d_scale,
                      const float* d_shift, int32_t act, float* d_out, int64_t ldo, int32_t* d_arg, float* d_rawsum,
