@@ -20,6 +20,7 @@ K_GATHER_SUM, K_GATHER_MAX, K_READOUT, K_SEG_GEMM, K_WGRAD, K_GATHER_MAX_BWD, K_
 
 
 GCMI_OPT_GEMM_EXACT = 1
+GCMI_OPT_FUSED_BN_STATS = 2
 GCMI_WIN_META_INTS = 24
 GCMI_WIN_MAX_SLOTS = 4095
 

@@ -557,6 +557,8 @@ relu_bwd_kernel(float* __restrict__ g, int64_t ldg, const float* __restrict__ y,
 // but with their own rounding.
 static std::atomic<int> g_gemm_exact{getenv("GCMI_GEMM_EXACT") && atoi(getenv("GCMI_GEMM_EXACT")) == 1 ? 1 : 0};
 bool gemm_exact_mode() { return g_gemm_exact.load(std::memory_order_relaxed) != 0; }
+// GCMI_OPT_FUSED_BN_STATS (env GCMI_GEMM_STATS=0 starts it off)
+static std::atomic<int> g_fused_bn_stats{getenv("GCMI_GEMM_STATS") && atoi(getenv("GCMI_GEMM_STATS")) == 0 ? 0 : 1};
 
 }  // namespace gcmi
 
@@ -565,14 +567,18 @@ using namespace gcmi;
 extern "C" {
 
 int gcmi_set_option(int32_t option, int32_t value) {
-  GCMI_CHECK_ARG(option == GCMI_OPT_GEMM_EXACT, "set_option: unknown option %d", option);
-  g_gemm_exact.store(value != 0 ? 1 : 0, std::memory_order_relaxed);
+  GCMI_CHECK_ARG(option == GCMI_OPT_GEMM_EXACT || option == GCMI_OPT_FUSED_BN_STATS, "set_option: unknown option %d",
+                 option);
+  if (option == GCMI_OPT_GEMM_EXACT) g_gemm_exact.store(value != 0 ? 1 : 0, std::memory_order_relaxed);
+  else g_fused_bn_stats.store(value != 0 ? 1 : 0, std::memory_order_relaxed);
   return GCMI_OK;
 }
 
 int gcmi_get_option(int32_t option, int32_t* value) {
-  GCMI_CHECK_ARG(option == GCMI_OPT_GEMM_EXACT && value, "get_option: unknown option %d", option);
-  *value = g_gemm_exact.load(std::memory_order_relaxed);
+  GCMI_CHECK_ARG((option == GCMI_OPT_GEMM_EXACT || option == GCMI_OPT_FUSED_BN_STATS) && value,
+                 "get_option: unknown option %d", option);
+  *value = option == GCMI_OPT_GEMM_EXACT ? g_gemm_exact.load(std::memory_order_relaxed)
+                                         : g_fused_bn_stats.load(std::memory_order_relaxed);
   return GCMI_OK;
 }
 
@@ -794,8 +800,7 @@ int seg_gemm_stats(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
                    int32_t n_out, int32_t trans_w, int32_t act, float* d_out, int64_t ldo, double* d_stats,
                    bool* fused, void* stream) {
   *fused = false;
-  // GCMI_GEMM_STATS=0: never fuse the BatchNorm column sums into the product's epilogue
-  static const bool allow = !(getenv("GCMI_GEMM_STATS") && atoi(getenv("GCMI_GEMM_STATS")) == 0);
+  const bool allow = g_fused_bn_stats.load(std::memory_order_relaxed) != 0;  // GCMI_OPT_FUSED_BN_STATS
   static const bool v3 = getenv("GCMI_GEMM_V3") && atoi(getenv("GCMI_GEMM_V3")) == 1;
   static const bool v4 = !(getenv("GCMI_GEMM_V4") && atoi(getenv("GCMI_GEMM_V4")) == 0);
   const bool shapes_ok = n_seg >= 1 && n_seg <= kMaxSeg && seg_begin && seg_end && n_out > 0 && ldo >= n_out && d_out &&

@@ -107,7 +107,12 @@ int gcmi_version(void);
  * reference's summation order: training trajectories track the reference to ~1e-5); 0 (default) =
  * the split-bf16 kernels (fp32-accurate per product, ~1.25x faster, own rounding).  Also settable
  * by the environment variable GCMI_GEMM_EXACT=1 before the library is loaded.                   */
-enum { GCMI_OPT_GEMM_EXACT = 1 };
+enum {
+  GCMI_OPT_GEMM_EXACT = 1,
+  /* 1 (default): the training forward of the whole-model entry points takes the BatchNorm column sums from the
+   * epilogue of the producing product; 0: separate column-sum launches (same statistics up to summation order) */
+  GCMI_OPT_FUSED_BN_STATS = 2
+};
 int gcmi_set_option(int32_t option, int32_t value);
 int gcmi_get_option(int32_t option, int32_t* value);
 const char* gcmi_last_error(void);

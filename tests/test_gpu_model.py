@@ -486,3 +486,31 @@ def test_real_smiles_end_to_end_regression(tmp_path):
     y = ds.y.reshape(-1)
     r2 = np.corrcoef(pred, y)[0, 1] ** 2
     assert r2 > 0.9, r2
+
+
+def test_bn_statistics_from_the_product_epilogue_equal_the_column_sum_kernel():
+    """GCMI_OPT_FUSED_BN_STATS: the training forward takes the BatchNorm column sums from the epilogue of the
+    producing product (default) or from separate column-sum launches; both accumulate the same fp32 values in
+    fp64, so one step from the same state agrees far below the parity tolerance."""
+    from deepchem_amd import _lib
+    g = load_golden("model_cls_bn.npz")
+    ds, _ = dataset_from(g)
+    results = []
+    try:
+        for fused in (1, 0):
+            _lib.call("gcmi_set_option", _lib.GCMI_OPT_FUSED_BN_STATS, fused)
+            model, cfg, state = build_model(g, "full")
+            losses = []
+            model.fit(ds, nb_epoch=1, deterministic=True, checkpoint_interval=0,
+                      callbacks=[lambda m, s, iteration_loss=None: losses.append(float(iteration_loss))])
+            assert model.model.__dict__.get("_native") is not None
+            sd = {k: v.float().cpu().numpy().copy() for k, v in model.model.state_dict().items()}
+            results.append((losses, sd))
+    finally:
+        _lib.call("gcmi_set_option", _lib.GCMI_OPT_FUSED_BN_STATS, 1)
+    (l1, s1), (l2, s2) = results
+    assert np.allclose(l1[0], l2[0], rtol=1e-6, atol=1e-7)  # first step: same state, same batch
+    assert np.allclose(l1, l2, rtol=1e-4, atol=1e-6)
+    for k in s1:
+        if "running" in k:
+            assert np.abs(s1[k] - s2[k]).max() <= 1e-5 * max(np.abs(s2[k]).max(), 1e-3), k
