@@ -421,7 +421,7 @@ constexpr int kS4WStride = kS4KC + 8;   // bf16 per staged W column: conflict-fr
 // AVEC: the A rows are 16-byte addressable (else four scalar loads per quad: same values, same
 // arithmetic, so the result does not depend on how the caller laid its rows out)
 template <bool TRANS, int NT, bool AVEC>
-__global__ void __launch_bounds__(kS3Block) __attribute__((amdgpu_waves_per_eu(3)))
+__global__ void __launch_bounds__(kS3Block) __attribute__((amdgpu_waves_per_eu(NT <= 2 ? 3 : 2)))
 seg_gemm4_kernel(SegTable3 st, const float* __restrict__ a1, int64_t lda1, int k1, const float* __restrict__ w1,
                  const float* __restrict__ a2, int64_t lda2, int k2, const float* __restrict__ w2,
                  const float* __restrict__ bias, int n_out, int act, float* __restrict__ out, int64_t ldo,
@@ -468,25 +468,19 @@ seg_gemm4_kernel(SegTable3 st, const float* __restrict__ a1, int64_t lda1, int k
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  // prefetch registers, TWO chunks deep: unconditional loads from clamped addresses, masked when stored to LDS.
-  // With one chunk in flight a workgroup's iteration took the memory latency (~2 us) for ~0.3 us of multiply; the
-  // second set doubles the bytes a workgroup keeps in flight (vector types, not HIP's float4 struct: arrays of
-  // those inside lambdas went to scratch memory)
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-  struct Pre {
-    f32x4 ra[APASS];
-    float rb[BPASS];
-    int k0, K;
-  };
-  auto gload = [&](int c, Pre& pr) {
+  // prefetch registers: unconditional loads from clamped addresses, masked when stored to LDS
+  float4 ra[APASS];
+  float rb[BPASS];
+  int pend_k0 = 0, pend_K = 0;
+  auto gload = [&](int c) {
     const bool first = c < n1;
     const float* a = first ? a1 : a2;
     const int64_t lda = first ? lda1 : lda2;
     const int K = first ? k1 : k2;
     const float* w = first ? w1 + woff1 : w2 + woff2;
     const int k0 = (first ? c : c - n1) * kS4KC;
-    pr.k0 = k0;
-    pr.K = K;
+    pend_k0 = k0;
+    pend_K = K;
     const int kcol = k0 + (tid & 7) * 4;
     const int kc = kcol + 4 <= lda ? kcol : 0;
 #pragma unroll
@@ -495,12 +489,12 @@ seg_gemm4_kernel(SegTable3 st, const float* __restrict__ a1, int64_t lda1, int k
       const int rc = r < rows_valid ? r : rows_valid - 1;
       const float* p = a + (int64_t)(row0 + rc) * lda;
       if constexpr (AVEC) {
-        pr.ra[pass] = *reinterpret_cast<const f32x4*>(p + kc);
+        ra[pass] = *reinterpret_cast<const float4*>(p + kc);
       } else {  // clamped scalar loads; columns >= K are zeroed when the quad goes to LDS
-        pr.ra[pass].x = p[kcol + 0 < K ? kcol + 0 : 0];
-        pr.ra[pass].y = p[kcol + 1 < K ? kcol + 1 : 0];
-        pr.ra[pass].z = p[kcol + 2 < K ? kcol + 2 : 0];
-        pr.ra[pass].w = p[kcol + 3 < K ? kcol + 3 : 0];
+        ra[pass].x = p[kcol + 0 < K ? kcol + 0 : 0];
+        ra[pass].y = p[kcol + 1 < K ? kcol + 1 : 0];
+        ra[pass].z = p[kcol + 2 < K ? kcol + 2 : 0];
+        ra[pass].w = p[kcol + 3 < K ? kcol + 3 : 0];
       }
     }
     if constexpr (!TRANS) {  // w is K x n_out
@@ -509,7 +503,7 @@ seg_gemm4_kernel(SegTable3 st, const float* __restrict__ a1, int64_t lda1, int k
 #pragma unroll
       for (int pass = 0; pass < BPASS; ++pass) {
         const int kk = k0 + tid / NB + pass * (kS3Block / NB);
-        pr.rb[pass] = w[(int64_t)(kk < K ? kk : K - 1) * n_out + jc];
+        rb[pass] = w[(int64_t)(kk < K ? kk : K - 1) * n_out + jc];
       }
     } else {  // w is n_out x K
       const int kk = k0 + (tid % kS4KC);
@@ -517,23 +511,23 @@ seg_gemm4_kernel(SegTable3 st, const float* __restrict__ a1, int64_t lda1, int k
 #pragma unroll
       for (int pass = 0; pass < BPASS; ++pass) {
         const int j = col0 + tid / kS4KC + pass * (kS3Block / kS4KC);
-        pr.rb[pass] = w[(int64_t)(j < n_out ? j : n_out - 1) * K + kkc];
+        rb[pass] = w[(int64_t)(j < n_out ? j : n_out - 1) * K + kkc];
       }
     }
   };
-  auto sstore = [&](const Pre& pr) {
+  auto sstore = [&]() {
     const int kq = (tid & 7) * 4;
-    const int tail = pr.K - (pr.k0 + kq);
+    const int tail = pend_K - (pend_k0 + kq);
 #pragma unroll
     for (int pass = 0; pass < APASS; ++pass) {
       const int r = (tid >> 3) + pass * 32;
       const bool ok = r < rows_valid;
-      f32x4 v = pr.ra[pass];
+      float4 v = ra[pass];
       v.x = (ok && tail > 0) ? v.x : 0.f;
       v.y = (ok && tail > 1) ? v.y : 0.f;
       v.z = (ok && tail > 2) ? v.z : 0.f;
       v.w = (ok && tail > 3) ? v.w : 0.f;
-      *reinterpret_cast<f32x4*>(&As[r][kq]) = v;
+      *reinterpret_cast<float4*>(&As[r][kq]) = v;
     }
 #pragma unroll
     for (int pass = 0; pass < BPASS; ++pass) {
@@ -545,7 +539,7 @@ seg_gemm4_kernel(SegTable3 st, const float* __restrict__ a1, int64_t lda1, int k
         kk = tid % kS4KC;
         j = tid / kS4KC + pass * (kS3Block / kS4KC);
       }
-      const float v = (pr.k0 + kk < pr.K && col0 + j < n_out) ? pr.rb[pass] : 0.f;
+      const float v = (pend_k0 + kk < pend_K && col0 + j < n_out) ? rb[pass] : 0.f;
       unsigned p1, p2, p3;
       split3(v, p1, p2, p3);
       Ws[0][j][kk] = (unsigned short)(p1 >> 16);
@@ -553,68 +547,39 @@ seg_gemm4_kernel(SegTable3 st, const float* __restrict__ a1, int64_t lda1, int k
       Ws[2][j][kk] = (unsigned short)(p3 >> 16);
     }
   };
-  auto compute = [&]() {
-#pragma unroll
-    for (int step = 0; step < kS4KC / 16; ++step) {
-      const int kk0 = step * 16 + 8 * half;
-      const float* arow = &As[wave * 32 + (lane & 31)][kk0];
-      const float4 lo = *reinterpret_cast<const float4*>(arow);
-      const float4 hi = *reinterpret_cast<const float4*>(arow + 4);
-      const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-      const Frag3 fa = split_frag(v);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int j = t * 32 + (lane & 31);
-        const u32x4 b1 = *reinterpret_cast<const u32x4*>(&Ws[0][j][kk0]);
-        const u32x4 b2 = *reinterpret_cast<const u32x4*>(&Ws[1][j][kk0]);
-        const u32x4 b3 = *reinterpret_cast<const u32x4*>(&Ws[2][j][kk0]);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b3), as_bf16x8(fa.p[0]), acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b1), as_bf16x8(fa.p[2]), acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b2), as_bf16x8(fa.p[1]), acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b2), as_bf16x8(fa.p[0]), acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b1), as_bf16x8(fa.p[1]), acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b1), as_bf16x8(fa.p[0]), acc[t], 0, 0, 0);
-      }
-    }
-  };
 
-  constexpr bool DEEP = NT <= 2;  // 128 output columns: a second register set does not fit beside the accumulators
   if (nchunks > 0) {
-    Pre pa;
-    if constexpr (DEEP) {
-      Pre pb;  // chunk c is staged from set (c & 1)
-      gload(0, pa);
-      if (nchunks > 1) gload(1, pb);
-      sstore(pa);
-      __syncthreads();
-      for (int c = 0; c < nchunks; c += 2) {
-        // chunk c is in LDS (from set A, which is free again); chunk c+1 waits in set B
-        if (c + 2 < nchunks) gload(c + 2, pa);
-        compute();
-        __syncthreads();
-        if (c + 1 >= nchunks) break;
-        sstore(pb);
-        __syncthreads();
-        // chunk c+1 is in LDS, set B is free
-        if (c + 3 < nchunks) gload(c + 3, pb);
-        compute();
-        __syncthreads();
-        if (c + 2 >= nchunks) break;
-        sstore(pa);
-        __syncthreads();
-      }
-    } else {
-      gload(0, pa);
-      sstore(pa);
-      __syncthreads();
-      for (int c = 0; c < nchunks; ++c) {
-        if (c + 1 < nchunks) gload(c + 1, pa);  // in flight while the matrix pipe works on chunk c
-        compute();
-        __syncthreads();
-        if (c + 1 < nchunks) {
-          sstore(pa);
-          __syncthreads();
+    gload(0);
+    sstore();
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+      if (c + 1 < nchunks) gload(c + 1);  // in flight while the matrix pipe works on chunk c
+#pragma unroll
+      for (int step = 0; step < kS4KC / 16; ++step) {
+        const int kk0 = step * 16 + 8 * half;
+        const float* arow = &As[wave * 32 + (lane & 31)][kk0];
+        const float4 lo = *reinterpret_cast<const float4*>(arow);
+        const float4 hi = *reinterpret_cast<const float4*>(arow + 4);
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const Frag3 fa = split_frag(v);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int j = t * 32 + (lane & 31);
+          const u32x4 b1 = *reinterpret_cast<const u32x4*>(&Ws[0][j][kk0]);
+          const u32x4 b2 = *reinterpret_cast<const u32x4*>(&Ws[1][j][kk0]);
+          const u32x4 b3 = *reinterpret_cast<const u32x4*>(&Ws[2][j][kk0]);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b3), as_bf16x8(fa.p[0]), acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b1), as_bf16x8(fa.p[2]), acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b2), as_bf16x8(fa.p[1]), acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b2), as_bf16x8(fa.p[0]), acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b1), as_bf16x8(fa.p[1]), acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(b1), as_bf16x8(fa.p[0]), acc[t], 0, 0, 0);
         }
+      }
+      __syncthreads();
+      if (c + 1 < nchunks) {
+        sstore();
+        __syncthreads();
       }
     }
   } else {
