@@ -431,7 +431,7 @@ seg_gemm4_kernel(SegTable3 st, const float* __restrict__ a1, int64_t lda1, int k
   constexpr int BPASS = (kS4KC * NB) / kS3Block;  // weight elements per thread per chunk
   // one raw LDS block: the staged operands during the K loop, the output tile of the statistics epilogue after it
   constexpr int HC = NB < 64 ? NB : 64;           // columns summed per pass of the statistics epilogue
-  constexpr int TP = HC + 1;                      // tile pitch in floats: column reads hit 64 different banks
+  constexpr int TP = HC + 4;                      // tile pitch in floats: 16-byte rows, column reads hit 64 different banks
   constexpr size_t kOperandBytes = sizeof(float) * kS3Rows * kS4AStride + sizeof(unsigned short) * 3 * NB * kS4WStride;
   constexpr size_t kTileBytes = sizeof(float) * 4 * 32 * TP;
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kOperandBytes > kTileBytes ? kOperandBytes : kTileBytes];
@@ -587,54 +587,24 @@ seg_gemm4_kernel(SegTable3 st, const float* __restrict__ a1, int64_t lda1, int k
   }
 
   // ---- epilogue (n_out % 4 == 0, 16-byte addressable output rows: checked by the launcher)
+  // The accumulator holds out^T (lane = row, registers = columns): stored straight from registers, one instruction
+  // writes 32-byte pieces of 32 different rows, i.e. four times the write transactions the bytes need (the address
+  // unit stalls on them: TA_ADDR_STALLED_BY_TC 20-100x that of the other streaming kernels).  Every wave therefore
+  // lays its 32 x HC tile out in the LDS the K loop has finished with (pitch HC + 4: 16-byte rows, conflict-free
+  // column reads) and writes whole rows: a lane group of HC/4 lanes per row, 16 bytes per lane.  On the way, for the
+  // training forward, a lane adds one column over the 32 rows in fp64 (BatchNorm statistics of the values just
+  // written, so that the layer output is not read again for them); the four waves' partials meet in LDS and one
+  // fp64 atomic per column and workgroup goes to the replicated accumulators bn_finalize_kernel reads.
+  typedef float f32x4e __attribute__((ext_vector_type(4)));
   const int r = wave * 32 + (lane & 31);
-  if (r < rows_valid) {
-    float* orow = out + (int64_t)(row0 + r) * ldo + col0;
-    const float4* bias4 = reinterpret_cast<const float4*>(bias_lds);
-    // accumulate mode: all pieces of the old output row are requested before the first is used
-    // (a load-add-store chain per piece would pay the memory latency sixteen times)
-    float4 old[NT][4];
-    if (act == 2) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int cl = t * 32 + 8 * rg + 4 * half;
-          old[t][rg] = *reinterpret_cast<const float4*>(orow + (col0 + cl < n_out ? cl : 0));
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int cl = t * 32 + 8 * rg + 4 * half;
-        if (col0 + cl < n_out) {
-          const float4 bq = bias4[cl >> 2];
-          float4 v = make_float4(acc[t][4 * rg] + bq.x, acc[t][4 * rg + 1] + bq.y, acc[t][4 * rg + 2] + bq.z,
-                                 acc[t][4 * rg + 3] + bq.w);
-          if (act == 1) {
-            v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
-            v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
-          }
-          if (act == 2) {
-            v.x += old[t][rg].x; v.y += old[t][rg].y; v.z += old[t][rg].z; v.w += old[t][rg].w;
-          }
-          *reinterpret_cast<float4*>(orow + cl) = v;
-        }
-      }
-    }
-  }
-
-  // ---- BatchNorm statistics of this tile (training forward): column sums and sums of squares of the values just
-  // written (after bias and activation), so that the layer output is not read again for them.  The accumulator
-  // holds out^T (lane = row, registers = columns): every wave lays its 32 x HC tile out in LDS (free after the K
-  // loop), a lane then adds one column over the 32 rows, the four waves' partials meet in LDS and one fp64 atomic
-  // per column and workgroup goes to the replicated accumulators bn_finalize_kernel reads.
-  if (stats != nullptr) {  // uniform
+  {
     float* T = reinterpret_cast<float*>(lds_raw) + wave * 32 * TP;
     const int rl = lane & 31;
     const bool row_ok = r < rows_valid;
-    const float4* bias4 = reinterpret_cast<const float4*>(bias_lds);
+    const f32x4e* bias4 = reinterpret_cast<const f32x4e*>(bias_lds);
+    constexpr int QPR = HC / 4;        // lanes per output row
+    constexpr int RPI = 64 / QPR;      // rows per store instruction
+    const int srow = lane / QPR, sq = lane - srow * QPR;
 #pragma unroll
     for (int h = 0; h < (NT + 1) / 2; ++h) {
 #pragma unroll
@@ -643,19 +613,19 @@ seg_gemm4_kernel(SegTable3 st, const float* __restrict__ a1, int64_t lda1, int k
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
           const int cl = t * 32 + 8 * rg + 4 * half;
-          const float4 bq = bias4[cl >> 2];
-          float v[4] = {acc[t][4 * rg] + bq.x, acc[t][4 * rg + 1] + bq.y, acc[t][4 * rg + 2] + bq.z,
-                        acc[t][4 * rg + 3] + bq.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float x = (act == 1 && !(v[e] > 0.f)) ? 0.f : v[e];
-            if (!row_ok || col0 + cl + e >= n_out) x = 0.f;
-            T[rl * TP + (cl - 64 * h) + e] = x;
+          const f32x4e bq = bias4[cl >> 2];
+          f32x4e v = {acc[t][4 * rg] + bq.x, acc[t][4 * rg + 1] + bq.y, acc[t][4 * rg + 2] + bq.z,
+                      acc[t][4 * rg + 3] + bq.w};
+          if (act == 1) {
+            v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+            v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
           }
+          if (!row_ok || col0 + cl >= n_out) v = f32x4e{0.f, 0.f, 0.f, 0.f};  // n_out % 4 == 0: whole quads
+          *reinterpret_cast<f32x4e*>(T + rl * TP + (cl - 64 * h)) = v;
         }
       }
-      // the tile is this wave's own: no workgroup barrier between the writes and the column reads
-      if (lane < HC) {
+      // the tile is this wave's own: no workgroup barrier between its writes and its reads
+      if (stats != nullptr && lane < HC) {  // `stats` is uniform
         double s1 = 0.0, s2 = 0.0;  // fp64 like the stand-alone column-sum kernel: the statistics then differ
 #pragma unroll 8               // from it by summation order only (~1e-16), not by fp32 rounding (~1e-7)
         for (int rr = 0; rr < 32; ++rr) {
@@ -666,7 +636,35 @@ seg_gemm4_kernel(SegTable3 st, const float* __restrict__ a1, int64_t lda1, int k
         col_part[wave][0][64 * h + lane] = s1;
         col_part[wave][1][64 * h + lane] = s2;
       }
+      // whole rows out: RPI rows per instruction
+      const int cg = col0 + 64 * h + 4 * sq;
+      constexpr int NI = 32 / RPI;           // store instructions per wave and pass
+      constexpr int GI = NI < 4 ? NI : 4;    // ... taken four at a time (old pieces requested together)
+#pragma unroll
+      for (int g0 = 0; g0 < NI; g0 += GI) {
+        f32x4e oldv[GI];
+        if (act == 2) {
+#pragma unroll
+          for (int i = 0; i < GI; ++i) {
+            const int rowl = (g0 + i) * RPI + srow;
+            const bool ok = wave * 32 + rowl < rows_valid && cg < n_out;
+            const int64_t rr = row0 + (wave * 32 + rowl < rows_valid ? wave * 32 + rowl : 0);
+            oldv[i] = *reinterpret_cast<const f32x4e*>(out + rr * ldo + (ok ? cg : col0));
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < GI; ++i) {
+          const int rowl = (g0 + i) * RPI + srow;
+          if (wave * 32 + rowl < rows_valid && cg < n_out) {
+            f32x4e v = *reinterpret_cast<const f32x4e*>(T + rowl * TP + 4 * sq);
+            if (act == 2) v += oldv[i];
+            *reinterpret_cast<f32x4e*>(out + (int64_t)(row0 + wave * 32 + rowl) * ldo + cg) = v;
+          }
+        }
+      }
     }
+  }
+  if (stats != nullptr) {  // uniform
     __syncthreads();
     for (int e = tid; e < 2 * NB; e += kS3Block) {
       const int which = e / NB, c = e - which * NB;
