@@ -1,4 +1,6 @@
-# One counter pass over a bench step: per-kernel averages of the counters named on the command line
+# One counter pass over a bench step: per-kernel averages of the counters named on the command line.
+# Keep to at most two counters of one hardware block (TA_*, TCP_*, TCC_*) per pass: three TA counters plus two TCP
+# counters made rocprofv3 replay/hang until the timeout on this pool.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
