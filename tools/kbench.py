@@ -95,7 +95,7 @@ def main():
         for (k1, k2, n_out, trans, label) in ((75, 75, 64, False, "graphconv0_fwd"), (64, 64, 64, False, "graphconv1_fwd"),
                                              (64, 0, 64, True, "graphconv1_dgrad"), (64, 0, 128, True, "dense_fwd"),
                                              (128, 0, 64, False, "dense_dgrad")):
-            ld1 = 76 if k1 == 75 else k1
+            ld1 = int(os.environ.get("KB_LD75", "76")) if k1 == 75 else k1  # KB_LD75: row stride of the 75-column operands
             a1 = rnd(N, ld1)[:, :k1]
             a2 = rnd(N, ld1)[:, :k2] if k2 else None
             w = rnd(21 * max(k1, 1) * n_out)
