@@ -63,12 +63,13 @@ template <int V, int MODE>
 __global__ void __launch_bounds__(kBBlock)
 col_sums_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ x, int64_t ldx,
                 const float* __restrict__ mean, const float* __restrict__ invstd, int64_t n_rows,
-                int64_t rows_per_block, int n_feat, int lpr, int lx, double* __restrict__ sums, ReadoutGrad rg) {
+                int64_t rows_per_block, int n_feat, int lpr, int lx, double* __restrict__ sums, ReadoutGrad rg,
+                int rev) {
   __shared__ double red[2 * kBBlock * 4];
   const int ry = kBBlock / lx;  // row lanes
   const int ty = threadIdx.x / lx;
   const int tx = threadIdx.x - ty * lx;
-  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r_begin = (int64_t)(rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * rows_per_block;
   const int64_t r_end = (r_begin + rows_per_block < n_rows) ? r_begin + rows_per_block : n_rows;
   // four rows per round, the next round's loads issued before this round is added up: one row per round
   // leaves a single 16-byte load in flight per lane and the loop runs at memory latency
@@ -268,12 +269,12 @@ template <int V, bool RELU, bool RD>
 __global__ void __launch_bounds__(kBBlock)
 bn_bwd_dx_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
                  int64_t ldx, int64_t n_rows, int64_t rows_per_block, int n_feat, int lpr, int lx,
-                 const float* __restrict__ coef, float* __restrict__ dx, int64_t lddx, ReadoutGrad rg) {
+                 const float* __restrict__ coef, float* __restrict__ dx, int64_t lddx, ReadoutGrad rg, int rev) {
   const int ry = kBBlock / lx;
   const int ty = threadIdx.x / lx;
   const int tx = threadIdx.x - ty * lx;
   if (ty >= ry) return;
-  const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r_begin = (int64_t)(rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * rows_per_block;
   const int64_t r_end = (r_begin + rows_per_block < n_rows) ? r_begin + rows_per_block : n_rows;
   for (int cc = tx; cc < lpr; cc += lx) {
     const int c = cc * V;
@@ -352,9 +353,10 @@ static int launch_col_sums(int mode, const float* a, int64_t lda, const float* x
   if (rpb < kRowsPerBlock) rpb = kRowsPerBlock;
   rpb = (rpb + round_rows - 1) / round_rows * round_rows;
   const int blocks = (int)((n_rows + rpb - 1) / rpb);
+  const int rev = next_sweep_direction();
 #define LAUNCH_CS(VV, MM)                                                                     \
   hipLaunchKernelGGL((col_sums_kernel<VV, MM>), dim3(blocks), dim3(kBBlock), 0, st, a, lda, x, \
-                     ldx, mean, invstd, n_rows, rpb, n_feat, lpr, lx, sums, rg)
+                     ldx, mean, invstd, n_rows, rpb, n_feat, lpr, lx, sums, rg, rev)
   if (V == 4) {
     if (mode == 0) LAUNCH_CS(4, 0); else if (mode == 1) LAUNCH_CS(4, 1); else LAUNCH_CS(4, 2);
   } else {
@@ -591,9 +593,10 @@ static int bn_bwd_any(const ReadoutGrad* rgp, const float* d_dy, int64_t lddy, c
     if (rpb < kDxRows) rpb = kDxRows;
     rpb = (rpb + round_rows - 1) / round_rows * round_rows;
     const int blocks = (int)((n_rows + rpb - 1) / rpb);
+    const int rev = next_sweep_direction();
 #define LAUNCH_DX(VV, RR, DD)                                                                     \
   hipLaunchKernelGGL((bn_bwd_dx_kernel<VV, RR, DD>), dim3(blocks), dim3(kBBlock), 0, st, d_dy, lddy, \
-                     d_x, ldx, n_rows, rpb, n_feat, lpr, lx, coef, d_dx, lddx, rg)
+                     d_x, ldx, n_rows, rpb, n_feat, lpr, lx, coef, d_dx, lddx, rg, rev)
 #define LAUNCH_DX_R(VV, RR) \
   do { if (rgp) LAUNCH_DX(VV, RR, true); else LAUNCH_DX(VV, RR, false); } while (0)
     if (V == 4) {

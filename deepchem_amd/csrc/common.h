@@ -12,6 +12,8 @@
 namespace gcmi {
 
 void set_error(const char* fmt, ...);
+// 0 / 1 alternately: whether the next row-streaming launch walks its rows backwards (core.cpp)
+int next_sweep_direction();
 
 #define GCMI_CHECK_ARG(cond, ...)          \
   do {                                     \

@@ -1,4 +1,5 @@
 // libgcmi.so: version, per-thread error string, graph checks, optional kernel timing.
+#include <atomic>
 #include <stdarg.h>
 
 #include <mutex>
@@ -9,6 +10,15 @@
 namespace gcmi {
 
 static thread_local char g_err[512] = "";
+
+// Streaming kernels that walk rows in workgroup order take turns walking them forwards and backwards: a consumer
+// launched right after its producer then starts on the rows the producer wrote LAST, which are the ones still in the
+// 256 MB Infinity Cache (an N x 64 float array of the benchmark batch is 0.31 GB), instead of evicting them while it
+// re-reads the oldest rows from HBM.
+int next_sweep_direction() {
+  static std::atomic<unsigned> counter{0};
+  return (int)(counter.fetch_add(1, std::memory_order_relaxed) & 1u);
+}
 
 void set_error(const char* fmt, ...) {
   va_list ap;

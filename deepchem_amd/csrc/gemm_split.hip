@@ -425,7 +425,7 @@ __global__ void __launch_bounds__(kS3Block) __attribute__((amdgpu_waves_per_eu(N
 seg_gemm4_kernel(SegTable3 st, const float* __restrict__ a1, int64_t lda1, int k1, const float* __restrict__ w1,
                  const float* __restrict__ a2, int64_t lda2, int k2, const float* __restrict__ w2,
                  const float* __restrict__ bias, int n_out, int act, float* __restrict__ out, int64_t ldo,
-                 double* __restrict__ stats) {
+                 double* __restrict__ stats, int rev) {
   constexpr int NB = NT * 32;
   constexpr int APASS = 4;                       // 128 rows / (256 threads / 8 lanes per row piece)
   constexpr int BPASS = (kS4KC * NB) / kS3Block;  // weight elements per thread per chunk
@@ -440,7 +440,7 @@ seg_gemm4_kernel(SegTable3 st, const float* __restrict__ a1, int64_t lda1, int k
       reinterpret_cast<unsigned short (*)[NB][kS4WStride]>(lds_raw + sizeof(float) * kS3Rows * kS4AStride);
   __shared__ __attribute__((aligned(16))) float bias_lds[NB];
   __shared__ double col_part[4][2][NB];           // per-wave column sums / sums of squares
-  const int b = blockIdx.x;
+  const int b = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;  // last-written rows first on alternate launches
   int s = 0;
 #pragma unroll
   for (int k = 1; k < kS3MaxSeg; ++k) s += (k < st.n_seg && b >= st.tile_start[k]) ? 1 : 0;
@@ -706,14 +706,15 @@ int launch_seg_gemm4(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg
   st.tile_start[kS3MaxSeg] = (int32_t)tiles;
   if (tiles == 0) return GCMI_OK;
   dim3 grid((unsigned)tiles, (unsigned)((n_out + nt * 32 - 1) / (nt * 32)));
+  const int rev = next_sweep_direction();
 #define LAUNCH_S4(TT, NN)                                                                                      \
   do {                                                                                                         \
     if (avec)                                                                                                  \
       hipLaunchKernelGGL((seg_gemm4_kernel<TT, NN, true>), grid, dim3(kS3Block), 0, sm, st, d_a1, lda1, k1, d_w1,   \
-                         d_a2, lda2, k2, d_w2, d_bias, n_out, act, d_out, ldo, d_stats);                       \
+                         d_a2, lda2, k2, d_w2, d_bias, n_out, act, d_out, ldo, d_stats, rev);                  \
     else                                                                                                       \
       hipLaunchKernelGGL((seg_gemm4_kernel<TT, NN, false>), grid, dim3(kS3Block), 0, sm, st, d_a1, lda1, k1, d_w1,  \
-                         d_a2, lda2, k2, d_w2, d_bias, n_out, act, d_out, ldo, d_stats);                       \
+                         d_a2, lda2, k2, d_w2, d_bias, n_out, act, d_out, ldo, d_stats, rev);                  \
   } while (0)
   if (trans_w) {
     if (nt == 1) LAUNCH_S4(true, 1); else if (nt == 2) LAUNCH_S4(true, 2); else LAUNCH_S4(true, 4);
@@ -734,8 +735,8 @@ int launch_seg_gemm4(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg
 template <int KT, bool TRANS>
 __global__ void __launch_bounds__(kS3Block)
 wgrad3_kernel(SlabTable st, const float* __restrict__ a, int64_t lda, int k, const float* __restrict__ g,
-              int64_t ldg, int n, int ntw, float* __restrict__ dw, float* __restrict__ dbias) {
-  const int b = blockIdx.x;
+              int64_t ldg, int n, int ntw, float* __restrict__ dw, float* __restrict__ dbias, int rev) {
+  const int b = rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x;  // last-written rows first on alternate launches
   int s = 0;
 #pragma unroll
   for (int q = 1; q < kMaxSegW; ++q) s += (q < st.n_seg && b >= st.slab_start[q]) ? 1 : 0;
@@ -877,15 +878,16 @@ int launch_wgrad3(const SlabTable& st, int slabs, const float* d_a, int64_t lda,
   const int NT = (n + 31) / 32;
   const int ntw = NT >= 3 ? 4 : NT;
   dim3 grid((unsigned)slabs, (unsigned)((NT + ntw - 1) / ntw));
+  const int rev = next_sweep_direction();
 #define LAUNCH_W3(KK)                                                                               \
   do {                                                                                              \
     const size_t lds = ntw == 4 ? 0 : (size_t)ntw * (KK * 16 * 64 + 64) * sizeof(float);            \
     if (trans_w)                                                                                    \
       hipLaunchKernelGGL((wgrad3_kernel<KK, true>), grid, dim3(kS3Block), lds, sm, st, d_a, lda, k, d_g, ldg, n, \
-                         ntw, d_dw, d_dbias);                                                       \
+                         ntw, d_dw, d_dbias, rev);                                                  \
     else                                                                                            \
       hipLaunchKernelGGL((wgrad3_kernel<KK, false>), grid, dim3(kS3Block), lds, sm, st, d_a, lda, k, d_g, ldg, n, \
-                         ntw, d_dw, d_dbias);                                                       \
+                         ntw, d_dw, d_dbias, rev);                                                  \
   } while (0)
   switch (KT) {
     case 1: LAUNCH_W3(1); break;
