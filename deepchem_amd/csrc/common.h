@@ -14,6 +14,7 @@ namespace gcmi {
 void set_error(const char* fmt, ...);
 // 0 / 1 alternately: whether the next row-streaming launch walks its rows backwards (core.cpp)
 int next_sweep_direction();
+int next_sweep_direction_windows();  // the same for the window gathers (GCMI_SWEEP=1 leaves them forwards)
 
 #define GCMI_CHECK_ARG(cond, ...)          \
   do {                                     \

@@ -264,7 +264,7 @@ template <int WT, int LPR, bool AUX, class Op>
 __global__ void __launch_bounds__(WT)
 win_kernel(const int32_t* __restrict__ meta, const uint16_t* __restrict__ edges, int n_norm, int n_win,
            int g_norm, Layout L, Layout Lbig, const float* __restrict__ x, int64_t ldx,
-           const uint8_t* __restrict__ aux, Op op) {
+           const uint8_t* __restrict__ aux, Op op, int rev) {
   // ALL LDS is one array (a second __shared__ object beside an LDS-DMA target makes hipcc wait
   // vmcnt(0) before every ds_read): [window descriptors: it, it+1, it+2][op constants][2 buffers]
   extern __shared__ __attribute__((aligned(16))) char smem_all[];
@@ -289,12 +289,15 @@ win_kernel(const int32_t* __restrict__ meta, const uint16_t* __restrict__ edges,
   }
   const int G = g_norm;
   int w = blockIdx.x;  // < n_norm by construction of the grid
+  // on alternate launches the ordinary windows are walked from the last one (next_sweep_direction, core.cpp): the
+  // rows the previous kernel wrote last are the ones still in the Infinity Cache
+  auto widx = [&](int v) { return (size_t)(rev ? n_norm - 1 - v : v); };
   const int bb = L.buf_bytes();
   int metareg = 0;
   if (t < GCMI_WIN_META_INTS) {
-    ring[0][t] = meta[(size_t)w * GCMI_WIN_META_INTS + t];
-    if (w + G < n_norm) ring[1][t] = meta[(size_t)(w + G) * GCMI_WIN_META_INTS + t];
-    if (w + 2 * G < n_norm) metareg = meta[(size_t)(w + 2 * G) * GCMI_WIN_META_INTS + t];
+    ring[0][t] = meta[widx(w) * GCMI_WIN_META_INTS + t];
+    if (w + G < n_norm) ring[1][t] = meta[widx(w + G) * GCMI_WIN_META_INTS + t];
+    if (w + 2 * G < n_norm) metareg = meta[widx(w + 2 * G) * GCMI_WIN_META_INTS + t];
   }
   __syncthreads();
   stage<WT, LPR, AUX>(smem, L, read_meta(ring[0]), x, ldx, aux, edges);
@@ -305,7 +308,7 @@ win_kernel(const int32_t* __restrict__ meta, const uint16_t* __restrict__ edges,
     const bool has_next = w + G < n_norm;
     if (t < GCMI_WIN_META_INTS) {
       ring[(it + 2) % 3][t] = metareg;  // read from the next round on
-      if (w + 3 * G < n_norm) metareg = meta[(size_t)(w + 3 * G) * GCMI_WIN_META_INTS + t];
+      if (w + 3 * G < n_norm) metareg = meta[widx(w + 3 * G) * GCMI_WIN_META_INTS + t];
     }
     if (has_next)
       stage<WT, LPR, AUX>(smem + ((it + 1) & 1) * bb, L, read_meta(ring[(it + 1) % 3]), x, ldx, aux, edges);
@@ -392,7 +395,7 @@ static int launch_wt(const gcmi_graph* g, const WinPlan& p, const float* x, int6
   const int g_big = std::min(g->n_win_big, 64);
   if (g_norm + g_big == 0) return GCMI_OK;
   hipLaunchKernelGGL(kern, dim3(g_norm + g_big), dim3(WT), p.shmem, st, g->d_win_meta, g->d_win_edges, n_norm,
-                     g->n_win, g_norm, p.L, p.Lbig, x, ldx, aux, op);
+                     g->n_win, g_norm, p.L, p.Lbig, x, ldx, aux, op, next_sweep_direction_windows());
   GCMI_CHECK_LAUNCH(what);
   return GCMI_OK;
 }
