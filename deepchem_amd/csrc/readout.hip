@@ -53,7 +53,8 @@ __global__ void __launch_bounds__(kRBlock)
 readout_fwd_kernel(int n_mols, int n_deg, const int32_t* __restrict__ runs,
                    const float* __restrict__ x, int64_t ldx, int n_feat, int lpr, int gl,
                    const float* __restrict__ scale, const float* __restrict__ shift, int act,
-                   float* __restrict__ out, int64_t ldo, int32_t* __restrict__ arg, float* __restrict__ rawsum) {
+                   float* __restrict__ out, int64_t ldo, int32_t* __restrict__ arg, float* __restrict__ rawsum,
+                   int vec_out) {
   const int mpb = kRBlock / gl;  // molecules per workgroup
   const int grp = threadIdx.x / gl;
   const int lane = threadIdx.x - grp * gl;
@@ -105,12 +106,33 @@ readout_fwd_kernel(int n_mols, int n_deg, const int32_t* __restrict__ runs,
       }
     }
     float* o = out + (int64_t)b * ldo;
+    float so[V], mo[V];
 #pragma unroll
     for (int q = 0; q < V; ++q) {
-      o[c + q] = act == 1 ? tanhf(sum[q]) : sum[q];
-      o[n_feat + c + q] = act == 1 ? tanhf(mx[q]) : mx[q];
+      so[q] = act == 1 ? tanhf(sum[q]) : sum[q];
+      mo[q] = act == 1 ? tanhf(mx[q]) : mx[q];
+    }
+    if constexpr (V == 4) {
+      if (vec_out) {  // uniform: 16-byte stores (four 4-byte stores per lane touch every line four times)
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<f32x4*>(o + c) = f32x4{so[0], so[1], so[2], so[3]};
+        *reinterpret_cast<f32x4*>(o + n_feat + c) = f32x4{mo[0], mo[1], mo[2], mo[3]};
+        if (arg) *reinterpret_cast<i32x4*>(arg + (int64_t)b * n_feat + c) = i32x4{am[0], am[1], am[2], am[3]};
+        if (rawsum) {  // [sum of the rows | value of the arg-max row], both BEFORE the folded BatchNorm
+          *reinterpret_cast<f32x4*>(rawsum + (int64_t)b * 2 * n_feat + c) = f32x4{raw[0], raw[1], raw[2], raw[3]};
+          *reinterpret_cast<f32x4*>(rawsum + (int64_t)b * 2 * n_feat + n_feat + c) =
+              f32x4{rawmx[0], rawmx[1], rawmx[2], rawmx[3]};
+        }
+        continue;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+      o[c + q] = so[q];
+      o[n_feat + c + q] = mo[q];
       if (arg) arg[(int64_t)b * n_feat + c + q] = am[q];
-      if (rawsum) {  // [sum of the rows | value of the arg-max row], both BEFORE the folded BatchNorm
+      if (rawsum) {
         rawsum[(int64_t)b * 2 * n_feat + c + q] = raw[q];
         rawsum[(int64_t)b * 2 * n_feat + n_feat + c + q] = rawmx[q];
       }
@@ -256,11 +278,15 @@ int readout_fwd_impl(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t
   const int blocks = (g->n_mols + mpb - 1) / mpb;
   const bool bn = d_scale != nullptr;
   const int n_deg = g->max_deg + 1;
+  const int vec_out = (n_feat % 4 == 0 && ldo % 4 == 0 && aligned16(d_out) && (d_arg == nullptr || aligned16(d_arg)) &&
+                       (d_rawsum == nullptr || aligned16(d_rawsum)))
+                          ? 1
+                          : 0;
   TimedScope ts(GCMI_K_READOUT, st);
 #define LAUNCH_RO(VV, BB)                                                                        \
   hipLaunchKernelGGL((readout_fwd_kernel<VV, BB>), dim3(blocks), dim3(kRBlock), 0, st, g->n_mols, \
                      n_deg, g->d_mol_runs, d_x, ldx, n_feat, lpr, gl, d_scale, d_shift, act,     \
-                     d_out, ldo, d_arg, d_rawsum)
+                     d_out, ldo, d_arg, d_rawsum, vec_out)
   if (V == 4) {
     if (bn) LAUNCH_RO(4, true); else LAUNCH_RO(4, false);
   } else {
