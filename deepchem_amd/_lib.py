@@ -22,6 +22,7 @@ K_GATHER_SUM, K_GATHER_MAX, K_READOUT, K_SEG_GEMM, K_WGRAD, K_GATHER_MAX_BWD, K_
 GCMI_OPT_GEMM_EXACT = 1
 GCMI_OPT_FUSED_BN_STATS = 2
 GCMI_WIN_META_INTS = 24
+GCMI_COLLATE_WIN_DESC_INTS = 36
 GCMI_WIN_MAX_SLOTS = 4095
 
 
@@ -110,6 +111,10 @@ _SIGNATURES = {
                      c_int64, _P, _G],
     "gcmi_collate_plans": [_P, c_int64, _P, _P, _P, _P, c_int64, c_int32, _P, c_int64, c_int64, _P, _P,
                            c_int64, _P, _P, _I32P, c_int32, _P, _P, _G],
+    "gcmi_molset_tables": [_P, _P, _P, c_int64, c_int32, _P, _P, _P, _I32P, c_int32],
+    "gcmi_collate_plan": [_P, _P, _P, c_int64, c_int32, c_int32, _P, c_int64, _P, _G],
+    "gcmi_collate_rows": [_P, c_int64, _P, _P, _P, _P, _P, _P, _G, _P, c_int64, _P, _P, _P, _P, _P, _P],
+    "gcmi_collate_rows_host": [_P, c_int64, _P, _P, _P, _P, _P, _P, _G, _P, c_int64, _P, _P, _P, _P, _P],
     "gcmi_build_mol_runs": [_G, _P, _P, _P],
     "gcmi_build_rev_pos": [_G, _P, _P, _P],
     "gcmi_gather_sum_fwd": [_G, _P, c_int64, c_int32, _P, c_int64, c_int32, _P],
@@ -156,7 +161,8 @@ _SIGNATURES = {
     "gcmi_timing_read": [c_int32, _I64P, POINTER(c_double), c_int32],
 }
 
-EXPORTS = ["gcmi_version", "gcmi_last_error", "gcmi_model_workspace_floats", "gcmi_smiles_check"] + sorted(_SIGNATURES)
+EXPORTS = ["gcmi_version", "gcmi_last_error", "gcmi_model_workspace_floats", "gcmi_smiles_check",
+           "gcmi_collate_plan_words"] + sorted(_SIGNATURES)
 
 _lib = None
 
@@ -192,6 +198,8 @@ def load():
     lib.gcmi_model_workspace_floats.restype = c_int64
     lib.gcmi_model_workspace_floats.argtypes = [_MD, c_int64, c_int64]
     lib.gcmi_smiles_check.restype = c_char_p
+    lib.gcmi_collate_plan_words.restype = c_int64
+    lib.gcmi_collate_plan_words.argtypes = [c_int64]
     lib.gcmi_smiles_check.argtypes = [c_char_p]
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)

@@ -10,6 +10,7 @@ but hands out molecule INDICES instead of object arrays, so that a batch can be 
 stream, ``depth`` batches ahead of the training loop (the reference collates each batch in
 Python on the training thread, ~2.5 ms per 100 molecules)."""
 import math
+import os
 import queue
 import threading
 from typing import Iterator, Optional, Tuple
@@ -164,10 +165,28 @@ class DeviceBatchPipeline:
     # transform): a batch then costs one index copy and two device gathers instead of host gathers, dtype
     # conversions and two pageable copies (15 ms per 65 536 molecules x 12 tasks -- three times the collation)
     RESIDENT_LABEL_BYTES = 8 << 30
+    # the molecule set itself lives in HBM below this size and batches are collated by the GPU (data/resident.py);
+    # above it, or for a set that lists bonds from one end only, batches are collated on the host as before
+    RESIDENT_SET_BYTES = 64 << 30
 
     def __init__(self, packed: PackedMols, y, w, index_batches, device: torch.device, label_fn=None,
-                 depth: int = 2, workers: int = 2):
+                 depth: int = 2, workers: int = 2, resident: Optional[bool] = None):
         self.workers = workers
+        self.resident = None
+        if resident or (resident is None and torch.device(device).type == "cuda" and packed.n_mols > 0
+                        and os.environ.get("GCMI_RESIDENT_SET", "1") != "0"):
+            from deepchem_amd.data.resident import ResidentMolSet
+            cache = packed.__dict__.setdefault("_resident_sets", {})
+            key = str(torch.device(device))
+            if key in cache:
+                self.resident = cache[key]
+            elif resident or ResidentMolSet.bytes_needed(packed) <= self.RESIDENT_SET_BYTES:
+                try:
+                    self.resident = cache[key] = ResidentMolSet(packed, device)
+                except ValueError:
+                    if resident:
+                        raise
+                    cache[key] = None
         self.packed, self.y, self.w = packed, y, w
         self.index_batches = index_batches
         self.device = device
@@ -185,7 +204,10 @@ class DeviceBatchPipeline:
 
     def _make(self, idx, n_real, stream, ring):
         with torch.cuda.stream(stream):
-            batch = collate_to_device(self.packed, idx, self.device, n_samples=idx.shape[0], ring=ring)
+            if self.resident is not None:
+                batch = self.resident.collate(idx, n_samples=idx.shape[0], ring=ring)
+            else:
+                batch = collate_to_device(self.packed, idx, self.device, n_samples=idx.shape[0], ring=ring)
             idx_t = None
             if self.y_dev is not None or self.w_dev is not None:
                 idx_t = torch.from_numpy(np.ascontiguousarray(idx, np.int64)).to(self.device)
@@ -286,7 +308,7 @@ class DeviceBatchPipeline:
                 # everything the worker's stream allocated and this stream will read: the arena, the feature rows
                 # expanded from atom codes (their own allocation) and the gathered labels / weights -- without the
                 # mark the allocator may hand a block to the worker's next batch while the step still reads it
-                for tns in (batch.graph._arena, batch.atom_features, y_t, w_t):
+                for tns in (batch.graph._arena, getattr(batch.graph, "_plan", None), batch.atom_features, y_t, w_t):
                     if tns is not None:
                         tns.record_stream(cur)
                 yield batch, y_t, w_t

@@ -151,6 +151,44 @@ int gcmi_collate_plans(const float* atom_features, int64_t n_feat, const int64_t
                        int32_t* out_symmetric, int32_t win_cap, int32_t* out_win_meta,
                        uint16_t* out_win_edges, gcmi_graph* graph);
 
+/* ---------------------------------------------------------------- collation on the device
+ * The same batches (ConvMol.agglomerate_mols, feat/mol_graphs.py:256-349; the arena gcmi_collate_plans
+ * writes, byte for byte) built by the GPU from a molecule set that stays in HBM, so that an epoch of
+ * shuffled batches (DiskDataset.iterbatches, data/datasets.py:1518-1623) moves a few MB of row bases per
+ * batch over PCIe instead of the whole batch.
+ *
+ * gcmi_molset_tables (host, once per set): out_mol_hist [n_mols x 11] atoms per degree, out_rank [A] an
+ *   atom's rank among the atoms of its degree in its molecule, out_rev [nnz] the reverse slot of every
+ *   neighbour entry (15 = none; *out_symmetric = 0 then).  Fails on a degree above max_deg or a
+ *   neighbour id outside its molecule, like gcmi_collate_plans.
+ * gcmi_collate_plan (host, per batch): the serial part -- row bases of every molecule in every degree
+ *   block, windows -- into `staging` (int32 words, >= gcmi_collate_plan_words(n_sel); only the first
+ *   out_offsets[6] words are used and need copying).  out_offsets[8]: word offsets of
+ *   base, mol_win, atom_off, atom0 (int64), win_meta (what graph->d_win_meta must point at on the
+ *   device), window descriptors; [6] words used; [7] uint16 entries of the window edge array.
+ *   *graph is filled as by gcmi_collate_plans.
+ * gcmi_collate_rows (device, per batch): one thread per atom writes features (n_feat floats per atom of
+ *   the resident set; 2 for 8-byte atom codes), membership, col_idx, rev_pos (NULL = skip), window
+ *   entries; a second launch writes mol_runs (NULL = skip).  d_staging is the device copy of the plan.
+ * gcmi_collate_rows_host: the same routine run by host loops over host buffers, for tests without a GPU. */
+#define GCMI_COLLATE_WIN_DESC_INTS 36
+int gcmi_molset_tables(const int64_t* atom_ptr, const int64_t* adj_ptr, const int32_t* adj_idx, int64_t n_mols,
+                       int32_t max_deg, int32_t* out_mol_hist, int32_t* out_rank, uint8_t* out_rev,
+                       int32_t* out_symmetric, int32_t n_threads);
+int64_t gcmi_collate_plan_words(int64_t n_sel);
+int gcmi_collate_plan(const int32_t* mol_hist, const int64_t* atom_ptr, const int64_t* sel, int64_t n_sel,
+                      int32_t max_deg, int32_t win_cap, int32_t* staging, int64_t staging_words,
+                      int64_t* out_offsets, gcmi_graph* graph);
+int gcmi_collate_rows(const void* d_features, int64_t n_feat, const int64_t* d_adj_ptr, const int32_t* d_adj_idx,
+                      const int32_t* d_rank, const uint8_t* d_rev, const int32_t* d_staging,
+                      const int64_t* offsets, const gcmi_graph* plan, float* d_out_features, int64_t out_ld,
+                      int32_t* d_membership, int32_t* d_col_idx, int32_t* d_mol_runs, uint8_t* d_rev_pos,
+                      uint16_t* d_win_edges, void* stream);
+int gcmi_collate_rows_host(const void* features, int64_t n_feat, const int64_t* adj_ptr, const int32_t* adj_idx,
+                           const int32_t* rank, const uint8_t* rev, const int32_t* staging, const int64_t* offsets,
+                           const gcmi_graph* plan, float* out_features, int64_t out_ld, int32_t* membership,
+                           int32_t* col_idx, int32_t* mol_runs, uint8_t* rev_pos, uint16_t* win_edges);
+
 /* ---------------------------------------------------------------- graph plan
  * d_mol_runs from d_membership (device).  d_flag (1 int, device) is set to 1
  * when membership is NOT ascending inside a degree block or out of range.   */
