@@ -113,7 +113,7 @@ _SIGNATURES = {
                            c_int64, _P, _P, _I32P, c_int32, _P, _P, _G],
     "gcmi_molset_tables": [_P, _P, _P, c_int64, c_int32, _P, _P, _P, _I32P, c_int32],
     "gcmi_collate_plan": [_P, _P, _P, c_int64, c_int32, c_int32, _P, c_int64, _P, _G],
-    "gcmi_collate_rows": [_P, c_int64, _P, _P, _P, _P, _P, _P, _G, _P, c_int64, _P, _P, _P, _P, _P, _P],
+    "gcmi_collate_rows": [_P, c_int64, _P, _P, _P, _P, _P, _P, _G, _P, c_int64, _P, _P, _P, _P, _P, _P, _P],
     "gcmi_collate_rows_host": [_P, c_int64, _P, _P, _P, _P, _P, _P, _G, _P, c_int64, _P, _P, _P, _P, _P],
     "gcmi_build_mol_runs": [_G, _P, _P, _P],
     "gcmi_build_rev_pos": [_G, _P, _P, _P],

@@ -43,6 +43,8 @@ struct Win {
 // every degree block, which LDS window it belongs to, and the window descriptors.
 struct BatchPlan {
   std::vector<int32_t> base, mol_win;
+  int32_t* base_ext = nullptr;     // when set, row bases / window ids are written here instead of the vectors
+  int32_t* mol_win_ext = nullptr;
   std::vector<Win> wins;
   int64_t deg_start[ND + 1], edge_start[ND + 1];
   int64_t n_atoms = 0, n_edges = 0, win_entries = 0;
@@ -86,10 +88,10 @@ int plan_serial(const int32_t* hist_p, int64_t n_sel, int n_deg, int32_t win_cap
                  (long long)cap_atoms, (long long)cap_edges, (long long)n_atoms, (long long)n_edges);
   // a molecule larger than win_cap gets a window of its own; slots are 12-bit in the edge entries
   if (want_win && max_mol > GCMI_WIN_MAX_SLOTS) want_win = false;
-  std::vector<int32_t>& base = P.base;  // first row of molecule p inside degree block d
-  base.assign((size_t)n_sel * ND, 0);
-  std::vector<int32_t>& mol_win = P.mol_win;
-  mol_win.assign(want_win ? (size_t)n_sel : 0, 0);
+  if (!P.base_ext) P.base.assign((size_t)n_sel * ND, 0);
+  if (!P.mol_win_ext) P.mol_win.assign(want_win ? (size_t)n_sel : 0, 0);
+  int32_t* base = P.base_ext ? P.base_ext : P.base.data();  // first row of molecule p inside degree block d
+  int32_t* mol_win = P.mol_win_ext ? P.mol_win_ext : P.mol_win.data();
   std::vector<Win>& wins = P.wins;
   wins.clear();
   {
@@ -118,6 +120,7 @@ int plan_serial(const int32_t* hist_p, int64_t n_sel, int n_deg, int32_t win_cap
         base[(size_t)p * ND + d] = (int32_t)cursor[d];
         cursor[d] += hist[(size_t)p * ND + d];
       }
+      for (int d = n_deg; d < ND; ++d) base[(size_t)p * ND + d] = 0;
     }
     // close the windows: counts -> prefixes, edge offsets (every window padded to 8 entries = 16 B).
     // Descriptors are emitted with the ordinary windows first and the oversized ones (a single
@@ -244,8 +247,8 @@ int gcmi_collate_plans(const float* atom_features, int64_t n_feat, const int64_t
   GCMI_CHECK_ARG(P.n_atoms == 0 || (out_features && out_membership), "collate: NULL output");
   GCMI_CHECK_ARG(P.n_edges == 0 || (out_col_idx && adj_idx), "collate: NULL edge buffers");
   want_win = P.want_win;
-  const std::vector<int32_t>& base = P.base;
-  const std::vector<int32_t>& mol_win = P.mol_win;
+  const int32_t* base = P.base.data();
+  const int32_t* mol_win = P.mol_win.data();
   const std::vector<Win>& wins = P.wins;
   const int64_t* deg_start = P.deg_start;
   const int64_t* edge_start = P.edge_start;
@@ -408,6 +411,7 @@ struct RowsArgs {
   int32_t* mol_runs;
   uint8_t* rev_pos;
   uint16_t* win_edges;
+  int64_t* src_atom;  // when set: row -> atom of the set, and the rows are copied by collate_features_kernel
   int32_t deg_start[ND + 1], edge_start[ND + 1];
   int32_t n_sel, n_atoms, n_deg, want_win;
 };
@@ -427,10 +431,14 @@ __host__ __device__ inline void collate_atom(const RowsArgs& A, int32_t i) {
   const int d = (int)(A.adj_ptr[a + 1] - e0);
   const int32_t* base = A.base + (int64_t)p * ND;
   const int32_t row = base[d] + A.rank[a];
-  float* dst = A.out_feat + (int64_t)row * A.out_ld;
-  const float* src = A.feat + a * A.n_feat;
-  for (int64_t f = 0; f < A.n_feat; ++f) dst[f] = src[f];
-  for (int64_t f = A.n_feat; f < A.out_ld; ++f) dst[f] = 0.f;
+  if (A.src_atom) {
+    A.src_atom[row] = a;
+  } else {
+    float* dst = A.out_feat + (int64_t)row * A.out_ld;
+    const float* src = A.feat + a * A.n_feat;
+    for (int64_t f = 0; f < A.n_feat; ++f) dst[f] = src[f];
+    for (int64_t f = A.n_feat; f < A.out_ld; ++f) dst[f] = 0.f;
+  }
   A.membership[row] = p;
   const int64_t eb = (int64_t)A.edge_start[d] + (int64_t)(row - A.deg_start[d]) * d;
   const int32_t* W = A.want_win ? A.desc + (int64_t)A.mol_win[p] * WD : nullptr;
@@ -461,6 +469,14 @@ __host__ __device__ inline void collate_run(const RowsArgs& A, int32_t k) {
 __global__ void __launch_bounds__(256) collate_rows_kernel(RowsArgs A) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < A.n_atoms) collate_atom(A, (int32_t)i);
+}
+
+// wide feature rows: consecutive lanes copy consecutive columns of a row (the per-atom thread only noted its source)
+__global__ void __launch_bounds__(256) collate_features_kernel(RowsArgs A) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)A.n_atoms * A.out_ld) return;
+  const int64_t row = t / A.out_ld, c = t - row * A.out_ld;
+  A.out_feat[t] = c < A.n_feat ? A.feat[A.src_atom[row] * A.n_feat + c] : 0.f;
 }
 
 __global__ void __launch_bounds__(256) collate_runs_kernel(RowsArgs A) {
@@ -498,6 +514,7 @@ int fill_rows_args(RowsArgs& A, const void* features, int64_t n_feat, const int6
   A.mol_runs = mol_runs;
   A.rev_pos = rev_pos;
   A.win_edges = win_edges;
+  A.src_atom = nullptr;
   for (int d = 0; d <= ND; ++d) {
     A.deg_start[d] = plan->deg_start[d];
     A.edge_start[d] = plan->edge_start[d];
@@ -599,34 +616,57 @@ int gcmi_collate_plan(const int32_t* mol_hist, const int64_t* atom_ptr, const in
   const int64_t o_base = 0, o_win = n_sel * ND, o_off = o_win + n_sel;
   const int64_t o_a0 = (o_off + n_sel + 1 + 1) / 2 * 2, o_meta = o_a0 + 2 * n_sel;
   std::vector<int32_t> hist((size_t)n_sel * ND);
+  std::vector<int32_t> size_of((size_t)n_sel);
   int32_t* atom_off = staging + o_off;
   int64_t* atom0 = reinterpret_cast<int64_t*>(staging + o_a0);
+  // the histograms of the selected molecules are scattered over the set's table (44 bytes each, one cache miss per
+  // molecule): gathered by a few threads with the next rows prefetched; everything after this is sequential
+  const int nt = (int)std::min<int64_t>(std::max<int64_t>(1, n_sel / 8192),
+                                        std::min(4u, std::max(1u, std::thread::hardware_concurrency())));
+  std::vector<int> bad(nt, 0);
+  parallel_for(n_sel, nt, [&](int64_t p0, int64_t p1, int t) {
+    for (int64_t p = p0; p < p1; ++p) {
+      const int64_t m = sel[p];
+      if (m < 0) {
+        bad[t] = 1;
+        continue;
+      }
+      if (p + 12 < p1 && sel[p + 12] >= 0) {
+        __builtin_prefetch(mol_hist + sel[p + 12] * ND);
+        __builtin_prefetch(atom_ptr + sel[p + 12]);
+      }
+      const int32_t* h = mol_hist + m * ND;
+      int32_t sz = 0;
+      for (int d = 0; d < ND; ++d) {
+        hist[(size_t)p * ND + d] = h[d];
+        sz += h[d];
+      }
+      if (sz != atom_ptr[m + 1] - atom_ptr[m]) bad[t] = 2;
+      size_of[(size_t)p] = sz;
+      atom0[p] = atom_ptr[m];
+    }
+  });
+  for (int b : bad) {
+    GCMI_CHECK_ARG(b != 1, "collate_plan: negative molecule index");
+    GCMI_CHECK_ARG(b != 2, "collate_plan: a molecule's histogram does not match its atoms");
+  }
   int64_t acc = 0;
   for (int64_t p = 0; p < n_sel; ++p) {
-    const int64_t m = sel[p];
-    GCMI_CHECK_ARG(m >= 0, "collate_plan: negative molecule index");
-    const int32_t* h = mol_hist + m * ND;
-    int64_t sz = 0;
-    for (int d = 0; d < ND; ++d) {
-      hist[(size_t)p * ND + d] = h[d];
-      sz += h[d];
-    }
-    GCMI_CHECK_ARG(sz == atom_ptr[m + 1] - atom_ptr[m], "collate_plan: histogram of molecule %lld does not match its atoms",
-                   (long long)m);
-    GCMI_CHECK_ARG(acc + sz < (1LL << 31), "collate: batch too large for int32 rows");
     atom_off[p] = (int32_t)acc;
-    atom0[p] = atom_ptr[m];
-    acc += sz;
+    acc += size_of[(size_t)p];
+    GCMI_CHECK_ARG(acc < (1LL << 31), "collate: batch too large for int32 rows");
   }
   atom_off[n_sel] = (int32_t)acc;
   BatchPlan P;
+  P.base_ext = staging + o_base;
+  P.mol_win_ext = staging + o_win;
   const int rc = plan_serial(hist.data(), n_sel, n_deg, win_cap, win_cap > 0, (1LL << 31), (1LL << 31),
                              staging + o_meta, nullptr, P);
   if (rc != GCMI_OK) return rc;
+  if (!P.want_win)
+    for (int64_t p = 0; p < n_sel; ++p) staging[o_win + p] = 0;
   const int64_t n_win = P.want_win ? (int64_t)P.wins.size() : 0;
   const int64_t o_desc = o_meta + n_win * GCMI_WIN_META_INTS;
-  for (int64_t i = 0; i < n_sel * ND; ++i) staging[o_base + i] = P.base[(size_t)i];
-  for (int64_t p = 0; p < n_sel; ++p) staging[o_win + p] = P.want_win ? P.mol_win[(size_t)p] : 0;
   for (int64_t w = 0; w < n_win; ++w) {
     const Win& W = P.wins[(size_t)w];
     int32_t* D = staging + o_desc + w * WD;
@@ -675,7 +715,7 @@ int gcmi_collate_rows(const void* d_features, int64_t n_feat, const int64_t* d_a
                       const int32_t* d_rank, const uint8_t* d_rev, const int32_t* d_staging, const int64_t* offsets,
                       const gcmi_graph* plan, float* d_out_features, int64_t out_ld, int32_t* d_membership,
                       int32_t* d_col_idx, int32_t* d_mol_runs, uint8_t* d_rev_pos, uint16_t* d_win_edges,
-                      void* stream_) {
+                      int64_t* d_src_atom, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   RowsArgs A;
   const int rc = fill_rows_args(A, d_features, n_feat, d_adj_ptr, d_adj_idx, d_rank, d_rev, d_staging, offsets, plan,
@@ -686,9 +726,16 @@ int gcmi_collate_rows(const void* d_features, int64_t n_feat, const int64_t* d_a
       ::gcmi::set_error("collate_rows: hipMemsetAsync failed");
       return GCMI_ERR_LAUNCH;
     }
+  A.src_atom = d_src_atom;
   if (A.n_atoms > 0) {
     collate_rows_kernel<<<(unsigned)((A.n_atoms + 255) / 256), 256, 0, stream>>>(A);
     GCMI_CHECK_LAUNCH("collate_rows_kernel");
+    if (d_src_atom) {
+      const int64_t n_el = (int64_t)A.n_atoms * A.out_ld;
+      GCMI_CHECK_ARG(n_el / 256 < (1LL << 31), "collate_rows: feature block too large for one launch");
+      collate_features_kernel<<<(unsigned)((n_el + 255) / 256), 256, 0, stream>>>(A);
+      GCMI_CHECK_LAUNCH("collate_features_kernel");
+    }
   }
   const int64_t n_runs = (int64_t)A.n_sel * A.n_deg;
   if (d_mol_runs && n_runs > 0) {

@@ -138,11 +138,13 @@ class ResidentMolSet:
         off = plan.off
         d_off = plan.offsets
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        # wide float rows are copied by their own launch (lanes along the columns); 8-byte codes by the atom's thread
+        src_atom = None if self.n_feat <= 4 else torch.empty(max(plan.n_atoms, 1), dtype=torch.int64, device=dev)
         _lib.call("gcmi_collate_rows", self.d_feats.data_ptr(), self.n_feat, self.d_adj_ptr.data_ptr(),
                   self.d_adj_idx.data_ptr(), self.d_rank.data_ptr(), self.d_rev.data_ptr(), d_plan.data_ptr(),
                   ctypes.cast(d_off, ctypes.c_void_p), ctypes.byref(plan.g), base, self.ld,
                   base + 4 * off["mem"], base + 4 * off["col"], base + 4 * off["runs"], base + 4 * off["rev"],
-                  base + 4 * off["loc"], stream)
+                  base + 4 * off["loc"], None if src_atom is None else src_atom.data_ptr(), stream)
         graph = BatchGraph(hb.deg_counts, hb.part("col_idx", arena), hb.part("membership", arena), n_mols=n_sel,
                            mol_runs=hb.part("mol_runs", arena), symmetric=True)
         graph._arena = arena

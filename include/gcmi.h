@@ -170,6 +170,9 @@ int gcmi_collate_plans(const float* atom_features, int64_t n_feat, const int64_t
  * gcmi_collate_rows (device, per batch): one thread per atom writes features (n_feat floats per atom of
  *   the resident set; 2 for 8-byte atom codes), membership, col_idx, rev_pos (NULL = skip), window
  *   entries; a second launch writes mol_runs (NULL = skip).  d_staging is the device copy of the plan.
+ *   d_src_atom (NULL, or n_atoms int64 of scratch): with it the per-atom threads only note their source
+ *   atom and a further launch copies the feature rows with consecutive lanes on consecutive columns
+ *   (wide float rows); without it every thread copies its own row (8-byte atom codes).
  * gcmi_collate_rows_host: the same routine run by host loops over host buffers, for tests without a GPU. */
 #define GCMI_COLLATE_WIN_DESC_INTS 36
 int gcmi_molset_tables(const int64_t* atom_ptr, const int64_t* adj_ptr, const int32_t* adj_idx, int64_t n_mols,
@@ -183,7 +186,7 @@ int gcmi_collate_rows(const void* d_features, int64_t n_feat, const int64_t* d_a
                       const int32_t* d_rank, const uint8_t* d_rev, const int32_t* d_staging,
                       const int64_t* offsets, const gcmi_graph* plan, float* d_out_features, int64_t out_ld,
                       int32_t* d_membership, int32_t* d_col_idx, int32_t* d_mol_runs, uint8_t* d_rev_pos,
-                      uint16_t* d_win_edges, void* stream);
+                      uint16_t* d_win_edges, int64_t* d_src_atom, void* stream);
 int gcmi_collate_rows_host(const void* features, int64_t n_feat, const int64_t* adj_ptr, const int32_t* adj_idx,
                            const int32_t* rank, const uint8_t* rev, const int32_t* staging, const int64_t* offsets,
                            const gcmi_graph* plan, float* out_features, int64_t out_ld, int32_t* membership,
