@@ -168,28 +168,23 @@ class DeviceBatchPipeline:
     # the molecule set itself lives in HBM below this size and batches are collated by the GPU (data/resident.py);
     # above it, or for a set that lists bonds from one end only, batches are collated on the host as before
     RESIDENT_SET_BYTES = 64 << 30
+    RESIDENT_MIN_BATCH = 512
 
     def __init__(self, packed: PackedMols, y, w, index_batches, device: torch.device, label_fn=None,
                  depth: int = 2, workers: int = 2, resident: Optional[bool] = None):
         self.workers = workers
-        self.resident = None
-        if resident or (resident is None and torch.device(device).type == "cuda" and packed.n_mols > 0
-                        and os.environ.get("GCMI_RESIDENT_SET", "1") != "0"):
-            from deepchem_amd.data.resident import ResidentMolSet
-            cache = packed.__dict__.setdefault("_resident_sets", {})
-            key = str(torch.device(device))
-            if key in cache:
-                self.resident = cache[key]
-            elif resident or ResidentMolSet.bytes_needed(packed) <= self.RESIDENT_SET_BYTES:
-                try:
-                    self.resident = cache[key] = ResidentMolSet(packed, device)
-                except ValueError:
-                    if resident:
-                        raise
-                    cache[key] = None
+        # None = decide per batch (device collation from RESIDENT_MIN_BATCH molecules up), True = always, False = never
+        self._resident_mode = resident
+        if resident is None and (torch.device(device).type != "cuda" or packed.n_mols == 0
+                                 or os.environ.get("GCMI_RESIDENT_SET", "1") == "0"):
+            self._resident_mode = False
+        self._resident_lock = threading.Lock()
+        self._resident_set = None
         self.packed, self.y, self.w = packed, y, w
         self.index_batches = index_batches
         self.device = device
+        if resident:
+            self._resident_for(1 << 30)
         self.label_fn = label_fn
         self.depth = max(1, depth)
         self.y_dev = self.w_dev = None
@@ -202,10 +197,42 @@ class DeviceBatchPipeline:
         if w is not None and len(w) == n and n > 0 and int(np.prod(np.shape(w)[1:])) * 4 * n <= self.RESIDENT_LABEL_BYTES:
             self.w_dev = torch.as_tensor(np.ascontiguousarray(w, np.float32)).to(device)
 
+    @property
+    def resident(self):
+        """The resident set batches are collated from, once one has been built (None before / without)."""
+        return self._resident_set
+
+    def _resident_for(self, n_sel: int):
+        """The set in HBM when this batch should be collated by the GPU, else None.  Small batches stay on the host:
+        below a few hundred molecules one H2D copy of a tiny arena beats a plan upload plus three launches."""
+        if self._resident_mode is False or (self._resident_mode is None and n_sel < self.RESIDENT_MIN_BATCH):
+            return None
+        if self._resident_set is not None:
+            return self._resident_set
+        with self._resident_lock:
+            if self._resident_set is None and self._resident_mode is not False:
+                from deepchem_amd.data.resident import ResidentMolSet
+                cache = self.packed.__dict__.setdefault("_resident_sets", {})
+                key = str(torch.device(self.device))
+                if key not in cache:
+                    forced = self._resident_mode is True
+                    cache[key] = None
+                    if forced or ResidentMolSet.bytes_needed(self.packed) <= self.RESIDENT_SET_BYTES:
+                        try:
+                            cache[key] = ResidentMolSet(self.packed, self.device)
+                        except ValueError:  # bonds listed from one end only
+                            if forced:
+                                raise
+                if cache[key] is None:
+                    self._resident_mode = False
+                self._resident_set = cache[key]
+        return self._resident_set
+
     def _make(self, idx, n_real, stream, ring):
         with torch.cuda.stream(stream):
-            if self.resident is not None:
-                batch = self.resident.collate(idx, n_samples=idx.shape[0], ring=ring)
+            rset = self._resident_for(int(idx.shape[0]))
+            if rset is not None:
+                batch = rset.collate(idx, n_samples=idx.shape[0], ring=ring)
             else:
                 batch = collate_to_device(self.packed, idx, self.device, n_samples=idx.shape[0], ring=ring)
             idx_t = None
