@@ -43,6 +43,8 @@ struct Win {
 // every degree block, which LDS window it belongs to, and the window descriptors.
 struct BatchPlan {
   std::vector<int32_t> base, mol_win;
+  bool have_counts = false;        // deg_count_in / max_mol_in already summed by the caller's histogram pass
+  int64_t deg_count_in[ND] = {0}, max_mol_in = 0;
   int32_t* base_ext = nullptr;     // when set, row bases / window ids are written here instead of the vectors
   int32_t* mol_win_ext = nullptr;
   std::vector<Win> wins;
@@ -62,15 +64,21 @@ int plan_serial(const int32_t* hist_p, int64_t n_sel, int n_deg, int32_t win_cap
   } hist{hist_p};
   int32_t win_alloc = 0, win_ecap = 0, win_alloc_big = 0, win_ecap_big = 0, n_win_big = 0;
   // serial prefix over molecules: degree-block starts, per-molecule row bases, windows
+  // (rows of hist are zero from n_deg on, so the loops below run over all ND columns: fixed trip counts)
   int64_t deg_count[ND] = {0};
   int64_t max_mol = 0;
-  for (int64_t p = 0; p < n_sel; ++p) {
-    int64_t sz = 0;
-    for (int d = 0; d < n_deg; ++d) {
-      deg_count[d] += hist[(size_t)p * ND + d];
-      sz += hist[(size_t)p * ND + d];
+  if (P.have_counts) {
+    for (int d = 0; d < ND; ++d) deg_count[d] = P.deg_count_in[d];
+    max_mol = P.max_mol_in;
+  } else {
+    for (int64_t p = 0; p < n_sel; ++p) {
+      int64_t sz = 0;
+      for (int d = 0; d < ND; ++d) {
+        deg_count[d] += hist[(size_t)p * ND + d];
+        sz += hist[(size_t)p * ND + d];
+      }
+      max_mol = std::max(max_mol, sz);
     }
-    max_mol = std::max(max_mol, sz);
   }
   int64_t* deg_start = P.deg_start;
   int64_t* edge_start = P.edge_start;
@@ -99,8 +107,9 @@ int plan_serial(const int32_t* hist_p, int64_t n_sel, int n_deg, int32_t win_cap
     for (int d = 0; d < ND; ++d) cursor[d] = deg_start[d];
     int64_t in_win = 0;
     for (int64_t p = 0; p < n_sel; ++p) {
+      const int32_t* hp = hist_p + (size_t)p * ND;
       int64_t sz = 0;
-      for (int d = 0; d < n_deg; ++d) sz += hist[(size_t)p * ND + d];
+      for (int d = 0; d < ND; ++d) sz += hp[d];
       if (want_win) {
         if (p == 0 || in_win + sz > win_cap) {  // open a new window at molecule p
           Win w;
@@ -114,13 +123,15 @@ int plan_serial(const int32_t* hist_p, int64_t n_sel, int n_deg, int32_t win_cap
         }
         in_win += sz;
         mol_win[(size_t)p] = (int32_t)wins.size() - 1;
-        for (int d = 0; d < n_deg; ++d) wins.back().sb[d] += hist[(size_t)p * ND + d];
+        int32_t* sb = wins.back().sb;
+        for (int d = 0; d < ND; ++d) sb[d] += hp[d];
       }
-      for (int d = 0; d < n_deg; ++d) {
-        base[(size_t)p * ND + d] = (int32_t)cursor[d];
-        cursor[d] += hist[(size_t)p * ND + d];
+      int32_t* bp = base + (size_t)p * ND;
+      for (int d = 0; d < ND; ++d) {
+        bp[d] = (int32_t)cursor[d];
+        cursor[d] += hp[d];
       }
-      for (int d = n_deg; d < ND; ++d) base[(size_t)p * ND + d] = 0;
+      for (int d = n_deg; d < ND; ++d) bp[d] = 0;
     }
     // close the windows: counts -> prefixes, edge offsets (every window padded to 8 entries = 16 B).
     // Descriptors are emitted with the ordinary windows first and the oversized ones (a single
@@ -624,7 +635,9 @@ int gcmi_collate_plan(const int32_t* mol_hist, const int64_t* atom_ptr, const in
   const int nt = (int)std::min<int64_t>(std::max<int64_t>(1, n_sel / 8192),
                                         std::min(4u, std::max(1u, std::thread::hardware_concurrency())));
   std::vector<int> bad(nt, 0);
+  std::vector<int64_t> part((size_t)nt * (ND + 1), 0);  // per thread: atoms per degree, largest molecule
   parallel_for(n_sel, nt, [&](int64_t p0, int64_t p1, int t) {
+    int64_t dc[ND] = {0}, mx = 0;
     for (int64_t p = p0; p < p1; ++p) {
       const int64_t m = sel[p];
       if (m < 0) {
@@ -640,11 +653,15 @@ int gcmi_collate_plan(const int32_t* mol_hist, const int64_t* atom_ptr, const in
       for (int d = 0; d < ND; ++d) {
         hist[(size_t)p * ND + d] = h[d];
         sz += h[d];
+        dc[d] += h[d];
       }
+      mx = std::max<int64_t>(mx, sz);
       if (sz != atom_ptr[m + 1] - atom_ptr[m]) bad[t] = 2;
       size_of[(size_t)p] = sz;
       atom0[p] = atom_ptr[m];
     }
+    for (int d = 0; d < ND; ++d) part[(size_t)t * (ND + 1) + d] = dc[d];
+    part[(size_t)t * (ND + 1) + ND] = mx;
   });
   for (int b : bad) {
     GCMI_CHECK_ARG(b != 1, "collate_plan: negative molecule index");
@@ -658,6 +675,13 @@ int gcmi_collate_plan(const int32_t* mol_hist, const int64_t* atom_ptr, const in
   }
   atom_off[n_sel] = (int32_t)acc;
   BatchPlan P;
+  P.have_counts = true;
+  for (int t = 0; t < nt; ++t) {
+    for (int d = 0; d < ND; ++d) P.deg_count_in[d] += part[(size_t)t * (ND + 1) + d];
+    P.max_mol_in = std::max(P.max_mol_in, part[(size_t)t * (ND + 1) + ND]);
+  }
+  for (int d = max_deg + 1; d < ND; ++d)
+    GCMI_CHECK_ARG(P.deg_count_in[d] == 0, "collate: an atom has more than max_deg=%d neighbours", max_deg);
   P.base_ext = staging + o_base;
   P.mol_win_ext = staging + o_win;
   const int rc = plan_serial(hist.data(), n_sel, n_deg, win_cap, win_cap > 0, (1LL << 31), (1LL << 31),
