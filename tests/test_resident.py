@@ -152,6 +152,12 @@ def test_one_sided_bonds_and_bad_neighbours_are_reported():
         molset_tables(bad)
     with pytest.raises(_lib.GcmiError, match="max_deg"):
         molset_tables(_pack(0, n=20), max_deg=2)
+    small = _pack(0, n=20)
+    hist, _, _, _ = molset_tables(small)
+    with pytest.raises(_lib.GcmiError, match="max_deg"):   # tables of a wider set planned with a narrower degree range
+        plan_batch(hist, np.ascontiguousarray(small.atom_ptr, np.int64), np.arange(small.n_mols), 8, 8, max_deg=2)
+    empty = plan_batch(hist, np.ascontiguousarray(small.atom_ptr, np.int64), np.zeros(0, np.int64), 8, 8)
+    assert empty.n_atoms == 0 and empty.n_edges == 0 and int(empty.g.n_win) == 0
     with pytest.raises(IndexError):
         hist, _, _, _ = molset_tables(_pack(0, n=20))
         plan_batch(hist, np.ascontiguousarray(_pack(0, n=20).atom_ptr, np.int64), np.array([10 ** 6]), 8, 8)
