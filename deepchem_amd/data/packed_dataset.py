@@ -171,7 +171,7 @@ class DeviceBatchPipeline:
     RESIDENT_MIN_BATCH = 512
 
     def __init__(self, packed: PackedMols, y, w, index_batches, device: torch.device, label_fn=None,
-                 depth: int = 2, workers: int = 2, resident: Optional[bool] = None):
+                 depth: int = 2, workers: int = 2, resident: Optional[bool] = None, label_key=None):
         self.workers = workers
         # None = decide per batch (device collation from RESIDENT_MIN_BATCH molecules up), True = always, False = never
         self._resident_mode = resident
@@ -192,10 +192,34 @@ class DeviceBatchPipeline:
         if y is not None and len(y) == n and n > 0:
             per_row = int(np.prod(np.shape(y)[1:])) * (2 if label_fn is not None else 1) * 4
             if per_row * n <= self.RESIDENT_LABEL_BYTES:
-                y_all = np.asarray(y) if label_fn is None else label_fn(np.asarray(y))
-                self.y_dev = torch.as_tensor(np.ascontiguousarray(y_all, np.float32)).to(device)
+                self.y_dev = self._labels_in_hbm(y, label_fn, ("y", label_key) if (label_fn is None or label_key) else None)
         if w is not None and len(w) == n and n > 0 and int(np.prod(np.shape(w)[1:])) * 4 * n <= self.RESIDENT_LABEL_BYTES:
-            self.w_dev = torch.as_tensor(np.ascontiguousarray(w, np.float32)).to(device)
+            self.w_dev = self._labels_in_hbm(w, None, ("w", None))
+
+    def _labels_in_hbm(self, arr, fn, tag):
+        """float32 copy of the whole label (or weight) array on the device, after ``fn`` (the one-hot transform).
+        Successive fit() calls over the same set find it again: the copy is kept on the molecule set under a
+        fingerprint of the host array's bytes (a changed label array is converted and uploaded afresh)."""
+        a = np.ascontiguousarray(np.asarray(arr))
+        cache = key = mark = None
+        if tag is not None and a.dtype != object:
+            try:
+                import xxhash
+                digest = xxhash.xxh3_128_hexdigest(a.data)
+            except ImportError:
+                import hashlib
+                digest = hashlib.blake2b(a.data, digest_size=16).hexdigest()
+            cache = self.packed.__dict__.setdefault("_label_cache", {})
+            key = (str(torch.device(self.device)), tag)
+            mark = (digest, a.shape, a.dtype.str)
+            hit = cache.get(key)
+            if hit is not None and hit[0] == mark:
+                return hit[1]
+        conv = a if fn is None else fn(a)
+        t = torch.as_tensor(np.ascontiguousarray(conv, np.float32)).to(self.device)
+        if cache is not None:
+            cache[key] = (mark, t)
+        return t
 
     @property
     def resident(self):

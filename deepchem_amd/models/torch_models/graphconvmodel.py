@@ -368,7 +368,9 @@ class GraphConvModel(TorchModel):
         if self.mode == 'classification' and mode != 'predict':
             label_fn = lambda y_b: to_one_hot(y_b.flatten(), self.n_classes).reshape(
                 -1, self.n_tasks, self.n_classes)
-        pipe = DeviceBatchPipeline(packed, y, w, index_batches, self.device, label_fn)
+        # label_key names the transform, so that the converted labels uploaded by one fit() serve the next
+        pipe = DeviceBatchPipeline(packed, y, w, index_batches, self.device, label_fn,
+                                   label_key=None if label_fn is None else ("one_hot", self.n_tasks, self.n_classes))
 
         def gen():
             for batch, y_t, w_t in pipe:

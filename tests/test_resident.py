@@ -221,3 +221,26 @@ def test_pipeline_over_a_resident_set_hands_out_the_same_batches():
     for ra, rb in zip(out[True], out[False]):
         for x, z in zip(ra, rb):
             assert torch.equal(x, z)
+
+
+@pytest.mark.gpu
+def test_labels_uploaded_by_one_fit_serve_the_next_until_they_change():
+    from deepchem_amd.data.packed_dataset import DeviceBatchPipeline
+    dev = torch.device("cuda:0")
+    packed = _pack(4, n=100, n_feat=75)
+    n = packed.n_mols
+    y = (np.random.RandomState(0).rand(n, 3) < 0.5).astype(np.float64)
+    w = np.ones((n, 3))
+    one_hot = lambda a: np.stack([1 - a, a], axis=-1)
+    p1 = DeviceBatchPipeline(packed, y, w, [], dev, one_hot, label_key=("one_hot", 3, 2))
+    p2 = DeviceBatchPipeline(packed, y, w, [], dev, one_hot, label_key=("one_hot", 3, 2))
+    assert p2.y_dev is p1.y_dev and p2.w_dev is p1.w_dev
+    assert torch.equal(p1.y_dev.cpu(), torch.as_tensor(one_hot(y).astype(np.float32)))
+    y[0, 0] = 1 - y[0, 0]                                  # edited in place: the fingerprint of the bytes changes
+    p3 = DeviceBatchPipeline(packed, y, w, [], dev, one_hot, label_key=("one_hot", 3, 2))
+    assert p3.y_dev is not p1.y_dev and p3.w_dev is p1.w_dev
+    assert torch.equal(p3.y_dev.cpu(), torch.as_tensor(one_hot(y).astype(np.float32)))
+    p4 = DeviceBatchPipeline(packed, y, w, [], dev, None)  # another transform of the same labels: its own copy
+    assert p4.y_dev.shape == (n, 3)
+    p5 = DeviceBatchPipeline(packed, y, w, [], dev, one_hot)  # a transform nobody named is never reused
+    assert p5.y_dev is not p3.y_dev
