@@ -244,3 +244,24 @@ def test_labels_uploaded_by_one_fit_serve_the_next_until_they_change():
     assert p4.y_dev.shape == (n, 3)
     p5 = DeviceBatchPipeline(packed, y, w, [], dev, one_hot)  # a transform nobody named is never reused
     assert p5.y_dev is not p3.y_dev
+
+
+@pytest.mark.gpu
+def test_device_collation_at_the_benchmark_batch_size():
+    """65 536 shuffled molecules out of 100 000 (BASELINE.json's batch): every array equal to the host collation's."""
+    from deepchem_amd.data.collate import collate_to_device
+    from deepchem_amd.data.resident import ResidentMolSet
+    dev = torch.device("cuda:0")
+    packed = synthetic_molecules(100000, seed=21, n_feat=75)
+    rset = ResidentMolSet(packed, dev)
+    sel = np.random.RandomState(8).permutation(packed.n_mols)[:65536]
+    a = rset.collate(sel)
+    b = collate_to_device(packed, sel, dev)
+    torch.cuda.synchronize()
+    assert a.graph.n_atoms == b.graph.n_atoms > 10 ** 6
+    assert torch.equal(a.atom_features, b.atom_features)
+    for name in ("col_idx", "membership", "mol_runs", "rev_pos", "win_meta"):
+        assert torch.equal(getattr(a.graph, name), getattr(b.graph, name)), name
+    n = int((a.graph.win_meta.view(-1, _lib.GCMI_WIN_META_INTS)[:, 2 * ND] +
+             (a.graph.win_meta.view(-1, _lib.GCMI_WIN_META_INTS)[:, 2 * ND + 1] + 7) // 8 * 8).max().item())
+    assert torch.equal(a.graph.win_edges[:n], b.graph.win_edges[:n])
