@@ -45,6 +45,13 @@ class PackedMols:
         self.atom_ptr, self.adj_ptr, self.adj_idx = atom_ptr, adj_ptr, adj_idx
         self.atom_codes = None if atom_codes is None else np.ascontiguousarray(atom_codes, np.uint8).reshape(-1, 8)
 
+    def __getstate__(self):
+        # the copies the training pipeline keeps in HBM (resident set, labels) belong to this process and device
+        state = dict(self.__dict__)
+        state.pop("_resident_sets", None)
+        state.pop("_label_cache", None)
+        return state
+
     @property
     def atom_features(self) -> np.ndarray:
         if self._features is not None:
