@@ -172,7 +172,7 @@ class DeviceBatchPipeline:
 
     def __init__(self, packed: PackedMols, y, w, index_batches, device: torch.device, label_fn=None,
                  depth: int = 2, workers: int = 2, resident: Optional[bool] = None, label_key=None):
-        self.workers = workers
+        self.workers = int(os.environ.get("GCMI_PIPELINE_WORKERS", workers))
         # None = decide per batch (device collation from RESIDENT_MIN_BATCH molecules up), True = always, False = never
         self._resident_mode = resident
         if resident is None and (torch.device(device).type != "cuda" or packed.n_mols == 0
