@@ -399,7 +399,8 @@ int gcmi_collate(const float* atom_features, int64_t n_feat, const int64_t* atom
 // row bases, windows; a few MB instead of the batch's whole arena cross PCIe) and one kernel with a thread per atom
 // writes the same arena gcmi_collate_plans writes, byte for byte.
 // ---------------------------------------------------------------------------------------------------------------
-namespace {
+namespace gcmi {
+namespace collate_dev {  // named, so that the kernels show up under their names in rocprofv3 traces
 
 constexpr int WD = GCMI_COLLATE_WIN_DESC_INTS;  // begin[ND] | sb[ND] | eb[ND] | eoff | 2 spare
 
@@ -537,7 +538,9 @@ int fill_rows_args(RowsArgs& A, const void* features, int64_t n_feat, const int6
   return GCMI_OK;
 }
 
-}  // namespace
+}  // namespace collate_dev
+}  // namespace gcmi
+using namespace gcmi::collate_dev;
 
 extern "C" {
 
