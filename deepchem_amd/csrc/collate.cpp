@@ -491,6 +491,22 @@ __global__ void __launch_bounds__(256) collate_features_kernel(RowsArgs A) {
   A.out_feat[t] = c < A.n_feat ? A.feat[A.src_atom[row] * A.n_feat + c] : 0.f;
 }
 
+// the same with one 16-byte store per lane (out_ld % 4 == 0, 16-byte aligned output; the source rows of n_feat floats
+// are only 4-byte aligned, so they are read as scalars): quads = out_ld / 4 lanes per row, 32-bit index arithmetic
+__global__ void __launch_bounds__(256) collate_features_quad_kernel(RowsArgs A, uint32_t quads, uint32_t n_quads) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= n_quads) return;
+  const uint32_t row = t / quads, c = (t - row * quads) * 4u;
+  const float* src = A.feat + A.src_atom[row] * A.n_feat;
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  f32x4 v;
+  v.x = c + 0 < (uint32_t)A.n_feat ? src[c + 0] : 0.f;
+  v.y = c + 1 < (uint32_t)A.n_feat ? src[c + 1] : 0.f;
+  v.z = c + 2 < (uint32_t)A.n_feat ? src[c + 2] : 0.f;
+  v.w = c + 3 < (uint32_t)A.n_feat ? src[c + 3] : 0.f;
+  *reinterpret_cast<f32x4*>(A.out_feat + (int64_t)row * A.out_ld + c) = v;
+}
+
 __global__ void __launch_bounds__(256) collate_runs_kernel(RowsArgs A) {
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (k < (int64_t)A.n_sel * A.n_deg) collate_run(A, (int32_t)k);
@@ -760,7 +776,12 @@ int gcmi_collate_rows(const void* d_features, int64_t n_feat, const int64_t* d_a
     if (d_src_atom) {
       const int64_t n_el = (int64_t)A.n_atoms * A.out_ld;
       GCMI_CHECK_ARG(n_el / 256 < (1LL << 31), "collate_rows: feature block too large for one launch");
-      collate_features_kernel<<<(unsigned)((n_el + 255) / 256), 256, 0, stream>>>(A);
+      if (A.out_ld % 4 == 0 && ((uintptr_t)A.out_feat & 15) == 0 && n_el / 4 < (1LL << 31)) {
+        const uint32_t n_quads = (uint32_t)(n_el / 4);
+        collate_features_quad_kernel<<<(n_quads + 255u) / 256u, 256, 0, stream>>>(A, (uint32_t)(A.out_ld / 4), n_quads);
+      } else {
+        collate_features_kernel<<<(unsigned)((n_el + 255) / 256), 256, 0, stream>>>(A);
+      }
       GCMI_CHECK_LAUNCH("collate_features_kernel");
     }
   }
