@@ -300,3 +300,21 @@ def test_fit_over_the_resident_set_equals_fit_over_host_collation(monkeypatch):
     apart = np.abs(after[0] - after[1]).max()
     print("moved %.3e apart %.3e" % (moved, apart))
     assert apart < 2e-5 and moved > 1e-3
+
+
+@pytest.mark.gpu
+def test_device_collation_with_unpadded_feature_rows():
+    """Rows of 75 floats (no padding to a multiple of four): the element-wise copy launch instead of the 16-byte one."""
+    from deepchem_amd.data.collate import collate_to_device
+    from deepchem_amd.data.resident import ResidentMolSet
+    dev = torch.device("cuda:0")
+    packed = _pack(13, n=500, n_feat=75)
+    rset = ResidentMolSet(packed, dev, pad_features_to=1)
+    assert rset.ld == 75
+    sel = np.random.RandomState(6).permutation(packed.n_mols)
+    a = rset.collate(sel)
+    b = collate_to_device(packed, sel, dev, pad_features_to=1)
+    torch.cuda.synchronize()
+    assert a.atom_features.shape == b.atom_features.shape == (a.graph.n_atoms, 75)
+    assert torch.equal(a.atom_features, b.atom_features)
+    assert torch.equal(a.graph.col_idx, b.graph.col_idx) and torch.equal(a.graph.membership, b.graph.membership)
