@@ -238,8 +238,8 @@ class DeviceBatchPipeline:
                 from deepchem_amd.data.resident import ResidentMolSet
                 cache = self.packed.__dict__.setdefault("_resident_sets", {})
                 key = str(torch.device(self.device))
-                if key not in cache:
-                    forced = self._resident_mode is True
+                forced = self._resident_mode is True
+                if key not in cache or (forced and cache[key] is None):
                     cache[key] = None
                     if forced or ResidentMolSet.bytes_needed(self.packed) <= self.RESIDENT_SET_BYTES:
                         try:

@@ -318,3 +318,24 @@ def test_device_collation_with_unpadded_feature_rows():
     assert a.atom_features.shape == b.atom_features.shape == (a.graph.n_atoms, 75)
     assert torch.equal(a.atom_features, b.atom_features)
     assert torch.equal(a.graph.col_idx, b.graph.col_idx) and torch.equal(a.graph.membership, b.graph.membership)
+
+
+@pytest.mark.gpu
+def test_one_sided_sets_stay_on_the_host_collation():
+    """A set that lists some bond from one end only cannot use the reverse-slot tables: the pipeline collates it on the
+    host (atomic backward kernels) when left to choose, and says so when the resident set is demanded."""
+    from deepchem_amd.data.packed_dataset import DeviceBatchPipeline
+    dev = torch.device("cuda:0")
+    good = synthetic_molecules(600, seed=2, n_feat=75)
+    adj_ptr = np.array([0, 1, 1], np.int64)  # atom 0 -> atom 1, never back
+    lone = PackedMols(np.zeros((2, 75), np.float32), np.array([0, 2], np.int64), adj_ptr, np.array([1], np.int32))
+    packed = concat_packed([good, lone])
+    n = packed.n_mols
+    y, w = np.zeros((n, 1)), np.ones((n, 1))
+    batches = [(np.arange(n, dtype=np.int64), n)]
+    pipe = DeviceBatchPipeline(packed, y, w, batches, dev)
+    out = list(pipe)
+    assert len(out) == 1 and out[0][0].graph.n_mols == n and pipe.resident is None
+    assert out[0][0].graph.rev_pos is None       # not symmetric: no reverse slots attached
+    with pytest.raises(ValueError, match="one end only"):
+        DeviceBatchPipeline(packed, y, w, batches, dev, resident=True)
