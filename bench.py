@@ -1,6 +1,11 @@
 """bench.py -- molecules/s of the GraphConvModel training step on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: either launched by ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``
+(RANK / LOCAL_RANK / WORLD_SIZE from the environment), or -- when WORLD_SIZE is not set -- this process
+starts that launcher itself as a CHILD, before anything has touched the GPU, and exits with its code.
+A WORLD_SIZE that disagrees with --gpus, or fewer GPUs than ranks, is an error, never a silent 1-rank run.
 
 One STEP = one optimizer step of ``GraphConvModel`` (forward, loss, backward,
 gradient all-reduce when N > 1, Adam) over one collated batch of Tox21-like
@@ -38,7 +43,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=65536, help="molecules per GPU per step")
+    ap.add_argument("--batch", type=int, default=65536, help="molecules per GPU per step (weak scaling)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch molecules per GPU; strong: --global-batch molecules split over the GPUs")
+    ap.add_argument("--global-batch", type=int, default=65536, help="molecules per step over all GPUs (strong scaling)")
+    ap.add_argument("--gemm-mode", default="fast", choices=["fast", "exact"],
+                    help="arithmetic of the matrix products (deepchem_amd.set_gemm_mode)")
     ap.add_argument("--tasks", type=int, default=12)
     ap.add_argument("--grad-mode", default="full", choices=["full", "reference"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -171,11 +181,41 @@ def cpu_baseline(args, seconds):
     }
 
 
+def launch_ranks(args):
+    """--gpus N > 1 without a launcher: start ``torch.distributed.run`` with N ranks of this script as a child
+    process.  Nothing in this process has initialised the GPU yet (``import torch`` and ``device_count`` do not),
+    and the parent only waits, so no GPU context is ever replaced."""
+    import socket
+    import subprocess
+    backend = os.environ.get("GCMI_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: this node has %d GPU(s); refusing to run fewer ranks than asked "
+                         "(GCMI_BENCH_BACKEND=gloo rehearses the rank logic on shared devices)" % (args.gpus, have))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d; the two must agree" % (args.gpus, world))
+    if args.scaling == "strong":
+        if args.global_batch % world:
+            raise SystemExit("bench.py: --global-batch %d is not divisible by %d ranks" % (args.global_batch, world))
+        args.batch = args.global_batch // world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU implementation)")
     import torch.distributed as dist
@@ -192,7 +232,9 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    import deepchem_amd
     from deepchem_amd import ops
+    deepchem_amd.set_gemm_mode(args.gemm_mode)
     from deepchem_amd._lib import (K_BATCHNORM, K_GATHER_MAX, K_GATHER_MAX_BWD, K_GATHER_SUM, K_READOUT,
                                    K_SEG_GEMM, K_WGRAD)
 
@@ -259,7 +301,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(wall / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
@@ -270,6 +312,8 @@ def main():
             "atoms_per_gpu_per_step": g.n_atoms,
             "directed_edges_per_gpu_per_step": g.n_edges,
             "grad_mode": args.grad_mode,
+            "gemm_mode": args.gemm_mode + (" (split-bf16 x3 products on v_mfma_f32_32x32x16_bf16, fp32-accurate)"
+                                           if args.gemm_mode == "fast" else " (v_mfma_f32_32x32x2_f32 chain)"),
             "parallelism": "dp%d (molecules sharded by rank, one flat all-reduce per step)" % world,
         },
         "roofline": {

@@ -368,7 +368,13 @@ class DiskDataset(Dataset):
         return DiskDataset.create_dataset([(dataset.X, dataset.y, dataset.w, dataset.ids)],
                                           data_dir=data_dir, tasks=tasks)
 
+    def _content_changed(self) -> None:
+        """Called by every in-place mutator: derived copies (the packed molecule set of the native batch
+        pipeline, with the resident set and labels in HBM behind it) describe the old rows."""
+        self.__dict__.pop("_gcmi_packed", None)
+
     def save_to_disk(self) -> None:
+        self._content_changed()
         DiskDataset._save_metadata(self.metadata_df, self.data_dir, self.tasks)
         self._cached_shards = None
 
@@ -459,6 +465,7 @@ class DiskDataset(Dataset):
     def set_shard(self, shard_num: int, X, y=None, w=None, ids=None) -> None:
         DiskDataset.write_data_to_disk(self.data_dir, "shard-%d" % shard_num, X, y, w, ids)
         self._cached_shards = None
+        self._content_changed()
         self.legacy_metadata = True
 
     def itershards(self) -> Iterator[Batch]:
@@ -734,6 +741,7 @@ class DiskDataset(Dataset):
         shutil.move(reshard_dir, self.data_dir)
         self.legacy_metadata = False
         self.metadata_df = resharded.metadata_df
+        self._content_changed()
         self.save_to_disk()
 
     def subset(self, shard_nums: Sequence[int], subset_dir: Optional[str] = None) -> "DiskDataset":
@@ -840,6 +848,7 @@ class DiskDataset(Dataset):
             p = np.random.permutation(X.shape[0])
             DiskDataset.write_data_to_disk(self.data_dir, basename, X[p], y[p], w[p], ids[p])
         self._cached_shards = None
+        self._content_changed()
 
     def shuffle_shards(self) -> None:
         rows = self.metadata_df.values.tolist()

@@ -10,6 +10,7 @@ but hands out molecule INDICES instead of object arrays, so that a batch can be 
 stream, ``depth`` batches ahead of the training loop (the reference collates each batch in
 Python on the training thread, ~2.5 ms per 100 molecules)."""
 import collections
+import logging
 import math
 import os
 import queue
@@ -22,6 +23,9 @@ import torch
 from deepchem_amd.data.collate import DeviceBatch, PinnedRing, collate_to_device
 from deepchem_amd.data.datasets import Dataset
 from deepchem_amd.utils.synthetic import PackedMols
+
+
+logger = logging.getLogger(__name__)
 
 
 class PackedDataset(Dataset):
@@ -118,13 +122,35 @@ def packed_from_convmols(X) -> PackedMols:
                       np.concatenate(idx) if idx else np.zeros(0, np.int32), codes)
 
 
+def _disk_fingerprint(dataset):
+    """What the packed copy of a DiskDataset depends on: the metadata rows in their current order and, per shard
+    file, its size and modification time.  ``set_shard`` / ``shuffle_each_shard`` / ``sparse_shuffle`` rewrite
+    files in place, ``shuffle_shards`` / ``add_shard`` / ``reshard`` change the rows; all of them change this."""
+    marks = []
+    for row in dataset.metadata_df.values.tolist():
+        files = []
+        for cell in row:
+            path = os.path.join(dataset.data_dir, cell) if isinstance(cell, str) and cell.endswith(".npy") else None
+            if path is not None:
+                try:
+                    st = os.stat(path)
+                    files.append((cell, st.st_size, st.st_mtime_ns))
+                except OSError:
+                    files.append((cell, -1, -1))
+        marks.append((tuple(str(c) for c in row), tuple(files)))
+    return tuple(marks)
+
+
 def packed_from_disk(dataset):
     """A DiskDataset of ConvMol objects as ONE PackedMols (+ labels, weights and the first molecule
-    index of every shard), converted shard by shard once and cached on the dataset object.
-    Returns None when the samples are not ConvMol-like."""
+    index of every shard), converted shard by shard once and cached on the dataset object under a
+    fingerprint of the shard files (an in-place mutation of the dataset invalidates the copy, and with it
+    the resident set and labels in HBM that hang off it).  Returns None when the samples are not
+    ConvMol-like."""
     from deepchem_amd.utils.synthetic import concat_packed
+    mark = _disk_fingerprint(dataset)
     cached = dataset.__dict__.get("_gcmi_packed")
-    if cached is not None and cached[4] == dataset.get_number_shards():
+    if cached is not None and cached[4] == mark:
         return cached[:4]
     parts, ys, ws, lens = [], [], [], []
     for X, y, w, _ in dataset.itershards():
@@ -141,7 +167,7 @@ def packed_from_disk(dataset):
     y = None if ys[0] is None else np.concatenate(ys, axis=0)
     w = None if ws[0] is None else np.concatenate(ws, axis=0)
     offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-    dataset.__dict__["_gcmi_packed"] = (packed, y, w, offsets, dataset.get_number_shards())
+    dataset.__dict__["_gcmi_packed"] = (packed, y, w, offsets, mark)
     return packed, y, w, offsets
 
 
@@ -381,7 +407,7 @@ class DeviceBatchPipeline:
             # references go -- once per iteration of a whole epoch set, where fit()/predict() synchronise anyway
             try:
                 torch.cuda.current_stream(dev).synchronize()
-            except Exception:
-                pass
+            except Exception:  # a failed synchronize means a kernel on a held batch faulted: say so, then let go
+                logger.exception("DeviceBatchPipeline: synchronizing the consumer stream failed while releasing batches")
             held.clear()
 

@@ -38,13 +38,16 @@ class Model(object):
                  per_task_metrics: bool = False) -> Dict[str, float]:
         """``metrics``: callables ``f(y_true, y_pred, w) -> float or per-task array``
         (a stand-in for dc.metrics.Metric, which is used as-is when DeepChem itself is
-        installed; models/models.py:162-223).  Returns {name: score}."""
-        if len(transformers):
-            raise NotImplementedError("undo_transforms is outside the GraphConv hot path")
-        y_pred = self.predict(dataset)
+        installed; models/models.py:162-223).  As the reference's Evaluator does
+        (utils/evaluate.py:197-307), labels and predictions are both taken back through the
+        y-transformers before scoring.  Returns {name: score}."""
+        from deepchem_amd.trans.transformers import undo_transforms
+        output_transformers = [t for t in transformers if t.transform_y]
+        y_true = undo_transforms(dataset.y, output_transformers)
+        y_pred = self.predict(dataset, output_transformers)
         out = {}
         for m in metrics:
             name = getattr(m, "name", getattr(m, "__name__", "metric"))
-            score = m(dataset.y, y_pred, dataset.w)
+            score = m(y_true, y_pred, dataset.w)
             out[name] = score if per_task_metrics else float(np.nanmean(score))
         return out

@@ -121,6 +121,9 @@ class GcmiAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        # after a flat (native) step the parameters of the trained range share ONE step tensor: it advances once
+        # per call here, not once per parameter that points at it
+        bumped = set()
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
             for p in group["params"]:
@@ -131,7 +134,9 @@ class GcmiAdam(torch.optim.Optimizer):
                     state["step"] = torch.tensor(0.0, dtype=torch.float32)
                     state["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                state["step"] += 1
+                if id(state["step"]) not in bumped:
+                    bumped.add(id(state["step"]))
+                    state["step"] += 1
                 if not p.is_cuda:
                     raise RuntimeError("GcmiAdam: parameters must be CUDA tensors")
                 ops.adam_step_(p.data, p.grad.data if p.grad.is_contiguous() else p.grad.contiguous(),

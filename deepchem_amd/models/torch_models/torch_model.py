@@ -1,19 +1,21 @@
-"""``TorchModel``: the training / prediction / checkpoint loop the GraphConv
-model runs under.  A restatement of the parts of
-deepchem/models/torch_models/torch_model.py the path uses -- ``fit`` :289,
-``fit_generator`` :345-496, ``_predict`` :547-652, ``predict`` :731,
-``predict_embedding`` :763, ``predict_uncertainty`` :784, ``_prepare_batch``
-:923-952, ``save_checkpoint`` :996-1042, ``restore`` :1061-1090,
-``load_from_pretrained`` :1196-1264, ``_StandardLoss`` :1267-1294 -- with the
-same argument meaning, return values and errors.  TensorBoard / W&B hooks and
-``compile`` are not part of the path and are absent.
+"""``TorchModel``: the fit / predict / checkpoint driver the GraphConv models run under.
 
-MI355X-side changes (none alters results):
-* ``_StandardLoss`` hands criterion + weighting + mean to one fused HIP kernel
-  when the loss is L2Loss / SoftmaxCrossEntropy and the tensors are on the GPU;
-* the default optimizer steps on the HIP Adam kernel;
-* 0-dim integer inputs (``n_samples``) stay on the host, so trimming the
-  output never synchronises the stream.
+The public surface is the reference's (deepchem/models/torch_models/torch_model.py: ``fit`` :289,
+``fit_generator`` :345, ``fit_on_batch`` :498, ``predict*`` :654-839, ``save_checkpoint`` :996,
+``restore`` :1061, ``load_from_pretrained`` :1196, ``_StandardLoss`` :1267): method names, argument
+meaning, return values, checkpoint dictionary keys, ``checkpoint<N>.pt`` rotation and error messages
+are contract.  How the work is organised underneath is this repository's own:
+
+* a fit is a ``_FitRun``: it resolves optimizer + schedule once, owns a ``_LossWindow`` that sums the
+  batch losses ON THE DEVICE (the host reads one number per logging window, never one per step) and a
+  checkpoint cadence; ``TorchModel._train_step`` is the single overridable unit of work (the
+  GraphConv model swaps in its fused native step there);
+* a prediction pass is an ``_OutputSink``: it picks the requested output roles, leaves the batch
+  outputs in HBM (no device->host copy, hence no stream drain, per batch), joins them on the device,
+  copies once and undoes the y-transformers on the joined array (they are row-wise maps);
+* ``_OutputRoles`` indexes the model's output list by role once, at construction.
+
+TensorBoard / W&B hooks and ``torch.compile`` are not part of this path and are absent.
 """
 import logging
 import os
@@ -29,8 +31,177 @@ from deepchem_amd.data.datasets import NumpyDataset
 from deepchem_amd.models.losses import Loss
 from deepchem_amd.models.models import Model
 from deepchem_amd.models.optimizers import Adam, LearningRateSchedule, Optimizer
+from deepchem_amd.trans.transformers import undo_transforms
 
 logger = logging.getLogger(__name__)
+
+
+class _OutputRoles:
+    """Positions of the model outputs by role (``output_types``; torch_model.py:229-254)."""
+
+    ROLES = ("prediction", "loss", "variance")
+
+    def __init__(self, output_types: Optional[List[str]]):
+        self.declared = output_types is not None
+        by_role: Dict[str, List[int]] = {r: [] for r in self.ROLES}
+        other: List[int] = []
+        for pos, kind in enumerate(output_types or ()):
+            by_role[kind].append(pos) if kind in by_role else other.append(pos)
+        self.prediction, self.variance, self.other = by_role["prediction"], by_role["variance"], other
+        # a model without dedicated loss outputs is scored on its predictions
+        self.loss = by_role["loss"] or self.prediction
+
+    def attr(self, positions: List[int]) -> Optional[List[int]]:
+        """The reference exposes ``None`` instead of lists when no output_types were given."""
+        return positions if self.declared else None
+
+
+class _LossWindow:
+    """Running mean of the batch losses between two log lines; the sum lives on the device."""
+
+    def __init__(self, collect: Optional[List[float]]):
+        self.total: Any = 0.0
+        self.count = 0
+        self.last_mean = 0.0
+        self.collect = collect
+
+    def add(self, batch_loss: torch.Tensor) -> None:
+        self.total = self.total + batch_loss.detach()
+        self.count += 1
+
+    def close(self, step: int) -> None:
+        if self.count == 0:
+            return
+        self.last_mean = float(self.total) / self.count  # the only device->host read of the window
+        logger.info('Ending global_step %d: Average loss %g' % (step, self.last_mean))
+        if self.collect is not None:
+            self.collect.append(self.last_mean)
+        self.total, self.count = 0.0, 0
+
+
+class _FitRun:
+    """Everything one ``fit_generator`` call needs besides the batches."""
+
+    def __init__(self, owner: "TorchModel", variables, loss, callbacks, max_keep: int, interval: int,
+                 all_losses: Optional[List[float]]):
+        self.owner = owner
+        self.loss = owner._loss_fn if loss is None else loss
+        self.optimizer, self.schedule = owner._optimizer_and_schedule(variables)
+        self.callbacks = list(callbacks) if isinstance(callbacks, SequenceCollection) else [callbacks]
+        self.max_keep, self.interval = max_keep, interval
+        self.window = _LossWindow(all_losses)
+
+    def after_step(self, batch_loss: torch.Tensor) -> None:
+        owner = self.owner
+        if self.schedule is not None:
+            self.schedule.step()
+        owner._global_step += 1
+        step = owner._global_step
+        self.window.add(batch_loss)
+        if step % owner.log_frequency == 0:
+            self.window.close(step)
+        if self.interval > 0 and step % self.interval == self.interval - 1:
+            owner.save_checkpoint(self.max_keep)
+        for cb in self.callbacks:
+            try:
+                cb(owner, step, iteration_loss=batch_loss)
+            except TypeError:  # callbacks written against the two-argument form
+                cb(owner, step)
+
+    def finish(self) -> float:
+        self.window.close(self.owner._global_step)
+        if self.interval > 0:
+            self.owner.save_checkpoint(self.max_keep)
+        return self.window.last_mean
+
+
+class _OutputSink:
+    """Collects the requested outputs of a prediction pass batch by batch."""
+
+    def __init__(self, roles: _OutputRoles, transformers: List, uncertainty: bool, other_output_types):
+        self.roles = roles
+        self.transformers = list(transformers)
+        self.uncertainty = uncertainty
+        if other_output_types:
+            self.take = list(roles.other)
+        elif roles.declared:
+            self.take = list(roles.prediction)
+        else:
+            self.take = []
+        self.columns: Optional[List["_Column"]] = None
+        self.var_columns: Optional[List["_Column"]] = None
+        self._pending = 0
+
+    @staticmethod
+    def check(roles: _OutputRoles, uncertainty: bool, other_output_types) -> None:
+        if uncertainty and (other_output_types is not None):
+            raise ValueError(
+                'This model cannot compute uncertainties and other output types simultaneously. Please invoke one at a time.'
+            )
+        if uncertainty:
+            if not roles.declared or len(roles.variance) == 0:
+                raise ValueError('This model cannot compute uncertainties')
+            if len(roles.variance) != len(roles.prediction):
+                raise ValueError('The number of variances must exactly match the number of outputs')
+        if other_output_types:
+            if not roles.declared or len(roles.other) == 0:
+                raise ValueError(
+                    'This model cannot compute other outputs since no other output_types were specified.'
+                )
+
+    FLUSH_BYTES = 1 << 30  # outputs wait in HBM until this much has piled up, then move to the host in one go
+
+    def push(self, outputs: List[torch.Tensor]) -> None:
+        """Queue one batch.  Nothing is copied to the host here: a per-batch ``.cpu()`` would drain the
+        stream after every batch, which is what bounds small-batch prediction."""
+        outputs = [t.detach() for t in outputs]
+        if self.uncertainty:
+            var = [outputs[i] for i in self.roles.variance]
+            if self.var_columns is None:
+                self.var_columns = [_Column() for _ in var]
+            for col, v in zip(self.var_columns, var):
+                col.add(v)
+        picked = [outputs[i] for i in self.take] if self.take else outputs
+        if self.transformers and len(picked) > 1:
+            raise ValueError("predict() does not support Transformers for models with multiple outputs.")
+        if self.columns is None:
+            self.columns = [_Column() for _ in picked]
+        for col, p in zip(self.columns, picked):
+            col.add(p)
+        self._pending += sum(p.numel() * p.element_size() for p in picked)
+        if self._pending > self.FLUSH_BYTES:
+            for col in (self.columns or []) + (self.var_columns or []):
+                col.to_host()
+            self._pending = 0
+
+    def result(self):
+        joined = [c.joined() for c in (self.columns or [])]
+        if self.transformers:  # row-wise maps: undoing them on the joined array equals batch by batch
+            joined = [undo_transforms(a, self.transformers) for a in joined]
+        if self.uncertainty and self.var_columns is not None:
+            return zip(joined, [c.joined() for c in self.var_columns])
+        return joined[0] if len(joined) == 1 else joined
+
+
+class _Column:
+    """One output across the batches of a pass: device tensors until moved, then numpy pieces."""
+
+    def __init__(self):
+        self.device_parts: List[torch.Tensor] = []
+        self.host_parts: List[np.ndarray] = []
+
+    def add(self, t: torch.Tensor) -> None:
+        self.device_parts.append(t)
+
+    def to_host(self) -> None:
+        if self.device_parts:
+            whole = self.device_parts[0] if len(self.device_parts) == 1 else torch.cat(self.device_parts, dim=0)
+            self.host_parts.append(whole.cpu().numpy())
+            self.device_parts = []
+
+    def joined(self) -> np.ndarray:
+        self.to_host()
+        return self.host_parts[0] if len(self.host_parts) == 1 else np.concatenate(self.host_parts, axis=0)
 
 
 class TorchModel(Model):
@@ -43,47 +214,37 @@ class TorchModel(Model):
                  regularization_loss: Optional[Callable] = None, **kwargs) -> None:
         super(TorchModel, self).__init__(model=model, model_dir=model_dir, **kwargs)
         self.loss = loss
+        self._loss_fn = _StandardLoss(self, loss) if isinstance(loss, Loss) else loss
         self.learning_rate = learning_rate
-        self.output_types = output_types
-        if isinstance(loss, Loss):
-            self._loss_fn = _StandardLoss(self, loss)
-        else:
-            self._loss_fn = loss
-        self.batch_size = batch_size
-        self.optimizer = Adam(learning_rate=learning_rate) if optimizer is None else optimizer
+        self.optimizer = optimizer if optimizer is not None else Adam(learning_rate=learning_rate)
         self.regularization_loss = regularization_loss
-        if device is None:
-            device = torch.device('cuda') if torch.cuda.is_available() else torch.device('cpu')
-        if device.type == 'cuda' and device.index is None:
-            device = torch.device('cuda', torch.cuda.current_device())
-        self.device = device
-        self.model = model.to(device)
+        self.batch_size = batch_size
         self.log_frequency = log_frequency
-        if output_types is None:
-            self._prediction_outputs = None
-            self._loss_outputs = None
-            self._variance_outputs = None
-            self._other_outputs = None
-        else:
-            self._prediction_outputs = []
-            self._loss_outputs = []
-            self._variance_outputs = []
-            self._other_outputs = []
-            for i, type_ in enumerate(output_types):
-                if type_ == 'prediction':
-                    self._prediction_outputs.append(i)
-                elif type_ == 'loss':
-                    self._loss_outputs.append(i)
-                elif type_ == 'variance':
-                    self._variance_outputs.append(i)
-                else:
-                    self._other_outputs.append(i)
-            if len(self._loss_outputs) == 0:
-                self._loss_outputs = self._prediction_outputs
+        self.device = self._pick_device(device)
+        self.model = model.to(self.device)
+        self.output_types = output_types
+        self._roles = _OutputRoles(output_types)
+        # the reference's attribute names (read by subclasses and user code)
+        self._prediction_outputs = self._roles.attr(self._roles.prediction)
+        self._loss_outputs = self._roles.attr(self._roles.loss)
+        self._variance_outputs = self._roles.attr(self._roles.variance)
+        self._other_outputs = self._roles.attr(self._roles.other)
         self._built = False
         self._optimizer_for_vars: Dict[Any, Any] = {}
         # set by deepchem_amd.dist.shard_model(); None = single process
         self._grad_sync: Optional[Callable] = None
+
+    @staticmethod
+    def _pick_device(device: Optional[torch.device]) -> torch.device:
+        if device is None:
+            device = torch.device('cuda' if torch.cuda.is_available() else 'cpu')
+        if device.type == 'cuda' and device.index is None:
+            device = torch.device('cuda', torch.cuda.current_device())
+        return device
+
+    def _new_schedule(self, torch_optimizer):
+        lr = self.optimizer.learning_rate
+        return lr._create_pytorch_schedule(torch_optimizer) if isinstance(lr, LearningRateSchedule) else None
 
     def _ensure_built(self) -> None:
         if self._built:
@@ -91,110 +252,68 @@ class TorchModel(Model):
         self._built = True
         self._global_step = 0
         self._pytorch_optimizer = self.optimizer._create_pytorch_optimizer(self.model.parameters())
-        if isinstance(self.optimizer.learning_rate, LearningRateSchedule):
-            self._lr_schedule = self.optimizer.learning_rate._create_pytorch_schedule(
-                self._pytorch_optimizer)
-        else:
-            self._lr_schedule = None
+        self._lr_schedule = self._new_schedule(self._pytorch_optimizer)
+
+    def _optimizer_and_schedule(self, variables):
+        """The model-wide optimizer, or one per distinct ``variables`` subset (kept across calls so
+        that its moments survive; torch_model.py:402-421)."""
+        if variables is None:
+            return self._pytorch_optimizer, self._lr_schedule
+        key = tuple(variables)
+        if key not in self._optimizer_for_vars:
+            opt = self.optimizer._create_pytorch_optimizer(key)
+            self._optimizer_for_vars[key] = (opt, self._new_schedule(opt))
+        return self._optimizer_for_vars[key]
 
     # ------------------------------------------------------------------ fitting
     def fit(self, dataset, nb_epoch: int = 10, max_checkpoints_to_keep: int = 5,
             checkpoint_interval: int = 1000, deterministic: bool = False, restore: bool = False,
             variables=None, loss=None, callbacks: Union[Callable, List[Callable]] = [],
             all_losses: Optional[List[float]] = None) -> float:
-        return self.fit_generator(
-            self._batch_generator(dataset, epochs=nb_epoch, deterministic=deterministic),
-            max_checkpoints_to_keep, checkpoint_interval, restore, variables, loss, callbacks,
-            all_losses)
+        batches = self._batch_generator(dataset, epochs=nb_epoch, deterministic=deterministic)
+        return self.fit_generator(batches, max_checkpoints_to_keep, checkpoint_interval, restore, variables,
+                                  loss, callbacks, all_losses)
 
     def fit_generator(self, generator: Iterable[Tuple[Any, Any, Any]],
                       max_checkpoints_to_keep: int = 5, checkpoint_interval: int = 1000,
                       restore: bool = False, variables=None, loss=None,
                       callbacks: Union[Callable, List[Callable]] = [],
                       all_losses: Optional[List[float]] = None) -> float:
-        if not isinstance(callbacks, SequenceCollection):
-            callbacks = [callbacks]
         self._ensure_built()
         self.model.train()
-        avg_loss = 0.0
-        last_avg_loss = 0.0
-        averaged_batches = 0
-        if loss is None:
-            loss = self._loss_fn
-        if variables is None:
-            optimizer = self._pytorch_optimizer
-            lr_schedule = self._lr_schedule
-        else:
-            variables_tuple = tuple(variables)
-            if variables_tuple in self._optimizer_for_vars:
-                optimizer, lr_schedule = self._optimizer_for_vars[variables_tuple]
-            else:
-                optimizer = self.optimizer._create_pytorch_optimizer(variables_tuple)
-                if isinstance(self.optimizer.learning_rate, LearningRateSchedule):
-                    lr_schedule = self.optimizer.learning_rate._create_pytorch_schedule(optimizer)
-                else:
-                    lr_schedule = None
-                self._optimizer_for_vars[variables_tuple] = (optimizer, lr_schedule)
-        time1 = time.time()
-        current_step = self._global_step
-
+        run = _FitRun(self, variables, loss, callbacks, max_checkpoints_to_keep, checkpoint_interval, all_losses)
+        started = time.time()
+        pending_restore = restore
         for batch in generator:
-            if restore:
+            if pending_restore:  # after the first batch exists, as the reference does (lazily built models)
                 self.restore()
-                restore = False
+                pending_restore = False
             inputs, labels, weights = self._prepare_batch(batch)
-            if isinstance(inputs, list) and len(inputs) == 1:
-                inputs = inputs[0]
-            batch_loss = self._train_step(inputs, labels, weights, loss, optimizer)
-            if lr_schedule is not None:
-                lr_schedule.step()
-            self._global_step += 1
-            current_step = self._global_step
+            run.after_step(self._train_step(self._unwrap_single(inputs), labels, weights, run.loss, run.optimizer))
+        mean_loss = run.finish()
+        logger.info("TIMING: model fitting took %0.3f s" % (time.time() - started))
+        return mean_loss
 
-            avg_loss = avg_loss + batch_loss.detach()  # stays on the device: no sync per step
-            averaged_batches += 1
-            should_log = (current_step % self.log_frequency == 0)
-            if should_log:
-                avg_loss = float(avg_loss) / averaged_batches
-                logger.info('Ending global_step %d: Average loss %g' % (current_step, avg_loss))
-                if all_losses is not None:
-                    all_losses.append(avg_loss)
-                last_avg_loss = avg_loss
-                avg_loss = 0.0
-                averaged_batches = 0
-            if checkpoint_interval > 0 and current_step % checkpoint_interval == checkpoint_interval - 1:
-                self.save_checkpoint(max_checkpoints_to_keep)
-            for c in callbacks:
-                try:
-                    c(self, current_step, iteration_loss=batch_loss)
-                except TypeError:
-                    c(self, current_step)
+    @staticmethod
+    def _unwrap_single(inputs):
+        return inputs[0] if isinstance(inputs, list) and len(inputs) == 1 else inputs
 
-        if averaged_batches > 0:
-            avg_loss = float(avg_loss) / averaged_batches
-            logger.info('Ending global_step %d: Average loss %g' % (current_step, avg_loss))
-            if all_losses is not None:
-                all_losses.append(avg_loss)
-            last_avg_loss = avg_loss
-        if checkpoint_interval > 0:
-            self.save_checkpoint(max_checkpoints_to_keep)
-        time2 = time.time()
-        logger.info("TIMING: model fitting took %0.3f s" % (time2 - time1))
-        return last_avg_loss
+    def _forward_lists(self, inputs) -> List[torch.Tensor]:
+        out = self.model(inputs)
+        return [out] if isinstance(out, torch.Tensor) else list(out)
 
     def _train_step(self, inputs, labels, weights, loss, optimizer):
-        """zero_grad, forward, loss, backward, (gradient all-reduce), optimizer step
-        (torch_model.py:435-443).  Subclasses may replace it by a fused native step."""
+        """One optimizer step on one prepared batch (torch_model.py:435-443): zero_grad, forward,
+        loss over the loss outputs, backward, gradient all-reduce on data-parallel ranks, step.
+        Subclasses replace this by a fused native step."""
         optimizer.zero_grad()
-        outputs = self.model(inputs)
-        if isinstance(outputs, torch.Tensor):
-            outputs = [outputs]
-        if self._loss_outputs is not None:
-            outputs = [outputs[i] for i in self._loss_outputs]
+        outputs = self._forward_lists(inputs)
+        if self._roles.declared:
+            outputs = [outputs[i] for i in self._roles.loss]
         batch_loss = loss(outputs, labels, weights)
         batch_loss.backward()
         if self._grad_sync is not None:
-            self._grad_sync(self.model)  # data-parallel ranks: one flat all-reduce per step
+            self._grad_sync(self.model)
         optimizer.step()
         return batch_loss
 
@@ -202,122 +321,59 @@ class TorchModel(Model):
                      callbacks: Union[Callable, List[Callable]] = [], checkpoint: bool = True,
                      max_checkpoints_to_keep: int = 5) -> float:
         self._ensure_built()
-        dataset = NumpyDataset(X, y, w)
-        return self.fit(dataset, nb_epoch=1, max_checkpoints_to_keep=max_checkpoints_to_keep,
-                        checkpoint_interval=self._global_step + 2 if checkpoint else 0,
-                        variables=variables, loss=loss, callbacks=callbacks)
+        # an interval that the single step of this call hits exactly when a checkpoint is wanted
+        interval = self._global_step + 2 if checkpoint else 0
+        return self.fit(NumpyDataset(X, y, w), nb_epoch=1, max_checkpoints_to_keep=max_checkpoints_to_keep,
+                        checkpoint_interval=interval, variables=variables, loss=loss, callbacks=callbacks)
 
     # ------------------------------------------------------------------ prediction
     def _predict(self, generator: Iterable[Tuple[Any, Any, Any]], transformers: List,
                  uncertainty: bool, other_output_types):
-        results: Optional[List[List[np.ndarray]]] = None
-        variances: Optional[List[List[np.ndarray]]] = None
-        if uncertainty and (other_output_types is not None):
-            raise ValueError(
-                'This model cannot compute uncertainties and other output types simultaneously. Please invoke one at a time.'
-            )
-        if uncertainty:
-            if self._variance_outputs is None or len(self._variance_outputs) == 0:
-                raise ValueError('This model cannot compute uncertainties')
-            if len(self._variance_outputs) != len(self._prediction_outputs):
-                raise ValueError('The number of variances must exactly match the number of outputs')
-        if other_output_types:
-            if self._other_outputs is None or len(self._other_outputs) == 0:
-                raise ValueError(
-                    'This model cannot compute other outputs since no other output_types were specified.'
-                )
-        if len(transformers) > 0:
-            raise NotImplementedError("undo_transforms is outside the GraphConv hot path")
+        _OutputSink.check(self._roles, uncertainty, other_output_types)
+        sink = _OutputSink(self._roles, transformers, uncertainty, other_output_types)
         self._ensure_built()
         self.model.eval()
-        for batch in generator:
-            inputs, labels, weights = batch
-            inputs, _, _ = self._prepare_batch((inputs, None, None))
-            if isinstance(inputs, list) and len(inputs) == 1:
-                inputs = inputs[0]
-            with torch.no_grad():
-                output_values = self.model(inputs)
-            if isinstance(output_values, torch.Tensor):
-                output_values = [output_values]
-            output_values = [t.detach().cpu().numpy() for t in output_values]
-            if uncertainty:
-                var = [output_values[i] for i in self._variance_outputs]
-                if variances is None:
-                    variances = [var]
-                else:
-                    for i, t in enumerate(var):
-                        variances[i].append(t)
-            access_values = []
-            if other_output_types:
-                access_values += self._other_outputs
-            elif self._prediction_outputs is not None:
-                access_values += self._prediction_outputs
-            if len(access_values) > 0:
-                output_values = [output_values[i] for i in access_values]
-            if results is None:
-                results = [[] for i in range(len(output_values))]
-            for i, t in enumerate(output_values):
-                results[i].append(t)
-
-        final_results = []
-        final_variances = []
-        if results is not None:
-            for r in results:
-                final_results.append(np.concatenate(r, axis=0))
-        if uncertainty and variances is not None:
-            for v in variances:
-                final_variances.append(np.concatenate(v, axis=0))
-            return zip(final_results, final_variances)
-        if len(final_results) == 1:
-            return final_results[0]
-        return final_results
+        with torch.no_grad():
+            for inputs, _labels, _weights in generator:
+                prepared, _, _ = self._prepare_batch((inputs, None, None))
+                sink.push(self._forward_lists(self._unwrap_single(prepared)))
+        return sink.result()
 
     def predict_on_generator(self, generator, transformers: List = [], output_types=None):
         return self._predict(generator, transformers, False, output_types)
 
     def predict_on_batch(self, X, transformers: List = []):
-        dataset = NumpyDataset(X=X, y=None)
-        return self.predict(dataset, transformers)
+        return self.predict(NumpyDataset(X=X, y=None), transformers)
 
     def predict_uncertainty_on_batch(self, X: Sequence, masks: int = 50):
-        dataset = NumpyDataset(X=X, y=None)
-        return self.predict_uncertainty(dataset, masks)
+        return self.predict_uncertainty(NumpyDataset(X=X, y=None), masks)
 
     def predict(self, dataset, transformers: List = [], output_types: Optional[List[str]] = None):
-        generator = self._batch_generator(dataset, mode='predict', pad_batches=False)
-        return self.predict_on_generator(generator, transformers=transformers,
-                                         output_types=output_types)
+        batches = self._batch_generator(dataset, mode='predict', pad_batches=False)
+        return self.predict_on_generator(batches, transformers=transformers, output_types=output_types)
 
     def predict_embedding(self, dataset):
-        generator = self._batch_generator(dataset, mode='predict', pad_batches=False)
-        return self._predict(generator, [], False, ['embedding'])
+        batches = self._batch_generator(dataset, mode='predict', pad_batches=False)
+        return self._predict(batches, [], False, ['embedding'])
 
     def predict_uncertainty(self, dataset, masks: int = 50):
-        sum_pred: List[np.ndarray] = []
-        sum_sq_pred: List[np.ndarray] = []
-        sum_var: List[np.ndarray] = []
-        for i in range(masks):
-            generator = self._batch_generator(dataset, mode='uncertainty', pad_batches=False)
-            results = self._predict(generator, [], True, None)
-            if len(sum_pred) == 0:
-                for p, v in results:
-                    sum_pred.append(p)
-                    sum_sq_pred.append(p * p)
-                    sum_var.append(v)
-            else:
-                for j, (p, v) in enumerate(results):
-                    sum_pred[j] += p
-                    sum_sq_pred[j] += p * p
-                    sum_var[j] += v
-        output = []
-        std = []
-        for i in range(len(sum_pred)):
-            p = sum_pred[i] / masks
-            output.append(p)
-            std.append(np.sqrt(sum_sq_pred[i] / masks - p * p + sum_var[i] / masks))
-        if len(output) == 1:
-            return (output[0], std[0])
-        return list(zip(output, std))
+        """Mean prediction and total standard deviation over ``masks`` stochastic passes: aleatoric
+        (mean predicted variance) + epistemic (spread of the predictions) (torch_model.py:784-839)."""
+        moments = None  # per output: [sum p, sum p^2, sum var]
+        for _ in range(masks):
+            batches = self._batch_generator(dataset, mode='uncertainty', pad_batches=False)
+            passes = list(self._predict(batches, [], True, None))
+            if moments is None:
+                moments = [[np.zeros_like(p), np.zeros_like(p), np.zeros_like(v)] for p, v in passes]
+            for acc, (p, v) in zip(moments, passes):
+                acc[0] += p
+                acc[1] += p * p
+                acc[2] += v
+        pairs = []
+        for s1, s2, sv in moments or []:
+            mean = s1 / masks
+            pairs.append((mean, np.sqrt(s2 / masks - mean * mean + sv / masks)))
+        return pairs[0] if len(pairs) == 1 else pairs
 
     # ------------------------------------------------------------------ batches
     def _to_device(self, x):
@@ -327,74 +383,69 @@ class TorchModel(Model):
         if x.dtype == np.float64:
             x = x.astype(np.float32)
         if x.ndim == 0 and x.dtype.kind in "iu":
-            return torch.as_tensor(x)  # sizes stay on the host
+            return torch.as_tensor(x)  # sizes stay on the host: trimming never synchronises the stream
         return torch.as_tensor(x, device=self.device)
 
     def _prepare_batch(self, batch: Tuple[Any, Any, Any]):
+        """float64 -> float32, everything onto the device (torch_model.py:923-952); a ``DeviceBatch``
+        (already collated in HBM) passes through."""
         inputs, labels, weights = batch
-        if hasattr(inputs, "graph"):  # a DeviceBatch: already collated and resident in HBM
-            input_tensors = inputs
-        else:
-            input_tensors = [self._to_device(x) for x in inputs]
-        label_tensors = [self._to_device(x) for x in labels] if labels is not None else []
-        weight_tensors = [self._to_device(x) for x in weights] if weights is not None else []
-        return (input_tensors, label_tensors, weight_tensors)
+        moved = inputs if hasattr(inputs, "graph") else [self._to_device(x) for x in inputs]
+        return (moved, [self._to_device(x) for x in labels or ()], [self._to_device(x) for x in weights or ()])
 
     def _batch_generator(self, dataset, epochs: int = 1, mode: str = 'fit', deterministic: bool = True,
                          pad_batches: bool = True):
-        """The generator fit()/predict*() use; subclasses may substitute a faster equivalent of
+        """What fit()/predict*() iterate; subclasses may substitute a faster equivalent of
         ``default_generator``."""
         return self.default_generator(dataset, epochs=epochs, mode=mode, deterministic=deterministic,
                                       pad_batches=pad_batches)
 
     def default_generator(self, dataset, epochs: int = 1, mode: str = 'fit',
                           deterministic: bool = True, pad_batches: bool = True):
-        for epoch in range(epochs):
-            for (X_b, y_b, w_b, ids_b) in dataset.iterbatches(batch_size=self.batch_size,
-                                                              deterministic=deterministic,
-                                                              pad_batches=pad_batches):
+        for _ in range(epochs):
+            for X_b, y_b, w_b, _ids in dataset.iterbatches(batch_size=self.batch_size, deterministic=deterministic,
+                                                           pad_batches=pad_batches):
                 yield ([X_b], [y_b], [w_b])
 
     # ------------------------------------------------------------------ checkpoints
+    @staticmethod
+    def _slot(model_dir: str, n: int) -> str:
+        return os.path.join(model_dir, 'checkpoint%d.pt' % n)
+
     def save_checkpoint(self, max_checkpoints_to_keep: int = 5, model_dir: Optional[str] = None) -> None:
+        """checkpoint1.pt is always the newest; older ones shift up by one and the oldest beyond
+        ``max_checkpoints_to_keep`` is dropped (torch_model.py:996-1042)."""
         if max_checkpoints_to_keep == 0:
             return
         self._ensure_built()
-        if model_dir is None:
-            model_dir = self.model_dir
-        if not os.path.exists(model_dir):
-            os.makedirs(model_dir)
-        data = {
-            'model_state_dict': self.model.state_dict(),
-            'optimizer_state_dict': self._pytorch_optimizer.state_dict(),
-            'global_step': self._global_step
-        }
-        temp_file = os.path.join(model_dir, 'temp_checkpoint.pt')
-        torch.save(data, temp_file)
-        paths = [os.path.join(model_dir, 'checkpoint%d.pt' % (i + 1)) for i in range(max_checkpoints_to_keep)]
-        if os.path.exists(paths[-1]):
-            os.remove(paths[-1])
-        for i in reversed(range(max_checkpoints_to_keep - 1)):
-            if os.path.exists(paths[i]):
-                os.rename(paths[i], paths[i + 1])
-        os.rename(temp_file, paths[0])
+        model_dir = model_dir or self.model_dir
+        os.makedirs(model_dir, exist_ok=True)
+        staged = os.path.join(model_dir, 'temp_checkpoint.pt')
+        torch.save({'model_state_dict': self.model.state_dict(),
+                    'optimizer_state_dict': self._pytorch_optimizer.state_dict(),
+                    'global_step': self._global_step}, staged)
+        oldest = self._slot(model_dir, max_checkpoints_to_keep)
+        if os.path.exists(oldest):
+            os.remove(oldest)
+        for n in range(max_checkpoints_to_keep - 1, 0, -1):
+            if os.path.exists(self._slot(model_dir, n)):
+                os.rename(self._slot(model_dir, n), self._slot(model_dir, n + 1))
+        os.rename(staged, self._slot(model_dir, 1))
 
     def get_checkpoints(self, model_dir: Optional[str] = None):
-        if model_dir is None:
-            model_dir = self.model_dir
-        files = sorted(os.listdir(model_dir))
-        files = [f for f in files if f.startswith('checkpoint') and f.endswith('.pt')]
-        return [os.path.join(model_dir, f) for f in files]
+        model_dir = model_dir or self.model_dir
+        return [os.path.join(model_dir, f) for f in sorted(os.listdir(model_dir))
+                if f.startswith('checkpoint') and f.endswith('.pt')]
 
     def restore(self, checkpoint: Optional[str] = None, model_dir: Optional[str] = None,
                 strict: Optional[bool] = True) -> None:
         logger.info('Restoring model')
         self._ensure_built()
         if checkpoint is None:
-            checkpoints = sorted(self.get_checkpoints(model_dir))
-            if len(checkpoints) == 0:
+            found = sorted(self.get_checkpoints(model_dir))
+            if not found:
                 raise ValueError('No checkpoint found')
-            checkpoint = checkpoints[0]
+            checkpoint = found[0]  # checkpoint1.pt: the newest
         data = torch.load(checkpoint, map_location=self.device)
         self.model.load_state_dict(data['model_state_dict'], strict=strict)
         self._pytorch_optimizer.load_state_dict(data['optimizer_state_dict'])
@@ -405,23 +456,18 @@ class TorchModel(Model):
 
     # ------------------------------------------------------------------ transfer
     def _create_assignment_map(self, source_model: "TorchModel", include_top: bool = True, **kwargs):
-        assignment_map: Dict[Any, Any] = {}
-        source_vars = list(source_model.model.parameters())
-        dest_vars = list(self.model.parameters())
-        if not include_top:
-            source_vars = source_vars[:-2]
-            dest_vars = dest_vars[:-2]
-        for source_var, dest_var in zip(source_vars, dest_vars):
-            assignment_map[source_var] = dest_var
-        return assignment_map
+        """source parameter -> own parameter, pairwise in ``parameters()`` order; without the top
+        the last weight + bias pair is left out (torch_model.py:1134-1170)."""
+        pairs = list(zip(source_model.model.parameters(), self.model.parameters()))
+        return dict(pairs if include_top else pairs[:-2])
 
     def _create_value_map(self, source_model: "TorchModel", **kwargs):
-        return {v: v.detach().cpu().numpy() for v in source_model.model.parameters()}
+        return {p: p.detach().cpu().numpy() for p in source_model.model.parameters()}
 
     def load_from_pretrained(self, source_model: "TorchModel", assignment_map=None, value_map=None,
                              checkpoint: Optional[str] = None, model_dir: Optional[str] = None,
                              include_top: bool = True, inputs=None, **kwargs) -> None:
-        if inputs is not None:
+        if inputs is not None:  # lazily built modules get their shapes from one forward each
             source_model.model(inputs)
             self.model(inputs)
         self._ensure_built()
@@ -429,16 +475,15 @@ class TorchModel(Model):
             source_model.restore(model_dir=model_dir, checkpoint=checkpoint)
             value_map = self._create_value_map(source_model=source_model)
         if assignment_map is None:
-            assignment_map = self._create_assignment_map(source_model=source_model,
-                                                         include_top=include_top)
-        for source_var, dest_var in assignment_map.items():
-            assert source_var.shape == dest_var.shape
-            dest_var.data = torch.as_tensor(value_map[source_var], device=self.device)
+            assignment_map = self._create_assignment_map(source_model=source_model, include_top=include_top)
+        for src, dst in assignment_map.items():
+            assert src.shape == dst.shape
+            dst.data = torch.as_tensor(value_map[src], device=self.device)
 
 
 class _StandardLoss(object):
-    """mean(w * criterion(outputs, labels)) [+ regularization]
-    (torch_model.py:1267-1294)."""
+    """``mean(w * criterion(outputs, labels))`` [+ regularization] (torch_model.py:1267-1294).
+    L2Loss / SoftmaxCrossEntropy on GPU tensors run criterion, weighting and mean as ONE HIP kernel."""
 
     def __init__(self, model: TorchModel, loss: Loss) -> None:
         self.model = model
@@ -451,16 +496,15 @@ class _StandardLoss(object):
         out, lab, w = outputs[0], labels[0], weights[0]
         kind = getattr(self.loss, "_gcmi_kind", None)
         if kind is not None and out.is_cuda and self._fusable(kind, out, lab, w):
-            loss = ops.StandardLossFn.apply(out, lab, w, kind)
+            value = ops.StandardLossFn.apply(out, lab, w, kind)
         else:
-            losses = self.criterion(out, lab)
-            if len(w.shape) < len(losses.shape):
-                shape = tuple(w.shape)
-                w = w.reshape(shape + (1,) * (len(losses.shape) - len(w.shape)))
-            loss = (losses * w).mean()
-        if self.model.regularization_loss is not None:
-            loss = loss + self.model.regularization_loss()
-        return loss
+            per_element = self.criterion(out, lab)
+            missing = per_element.dim() - w.dim()
+            if missing > 0:  # weights broadcast over trailing axes
+                w = w.reshape(tuple(w.shape) + (1,) * missing)
+            value = (per_element * w).mean()
+        reg = self.model.regularization_loss
+        return value if reg is None else value + reg()
 
     @staticmethod
     def _fusable(kind, out, lab, w) -> bool:

@@ -224,7 +224,12 @@ class NativeNet:
             raise ValueError("labels %s do not match (%d, %d, %d)" % (tuple(labels.shape), n_rows, d.n_tasks,
                                                                       d.n_classes))
         if weights is not None:
-            weights = weights.contiguous().to(torch.float32)
+            weights = weights.to(torch.float32)
+            if d.n_tasks > 1 and weights.numel() * d.n_tasks == labels.numel() // d.n_classes:
+                # one weight per molecule ((n,) or (n, 1): what NumpyDataset(X, y) creates): the reference's
+                # _StandardLoss broadcasts it over the tasks (torch_model.py:1285-1291)
+                weights = weights.reshape(-1, 1).expand(-1, d.n_tasks)
+            weights = weights.contiguous()
             if weights.numel() != n_rows * d.n_tasks:
                 raise ValueError("weights %s do not match (%d, %d)" % (tuple(weights.shape), n_rows, d.n_tasks))
         lo, hi = ctypes.c_int64(0), ctypes.c_int64(0)

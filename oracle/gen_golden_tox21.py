@@ -1,0 +1,119 @@
+"""Generate tests/golden/tox21_ref.npz by training THE REFERENCE on the real Tox21 file.
+
+Run once, in the build container (the reference does not travel to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden_tox21.py
+
+BASELINE.json config 2 "Tox21 (~8k mols, 12 tasks) GraphConvModel".  The recipe is MolNet's
+(molnet/load_function/tox21_datasets.py:14-75 -- CSV -> ConvMolFeaturizer -> BalancingTransformer
+on the train split; index split 80/10/10 as examples/stable_results.csv:5 was produced with;
+molnet/preset_hyper_parameters.py:49-56 -- batch 64, 40 epochs, learning rate 5e-4), with two
+deliberate substitutions that the fixture records:
+
+* the featurizer is this repository's native SMILES featurizer (rdkit is absent here; the very same
+  featurized molecules feed the reference and, in the test, the GPU path -- what is pinned is the
+  training path, not the chemistry of the feature columns);
+* the initial weights come from ``oracle.graphconv_oracle.init_state(cfg, 123)`` so that the test can
+  rebuild them from a seed.
+
+The data file ``tests/golden/tox21.csv.gz`` is a byte copy of the reference tree's data file
+``/root/reference/datasets/tox21.csv.gz`` (a fixture: data, not source).
+
+Written: for every run (batch 64 preset; batch 100 = the reference's default batch, lr 1e-3, 10
+epochs) the reference's valid-split probabilities after training, its per-task ROC-AUC on train and
+valid, the mean loss fit() returned, and its wall time on this container's cores.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+from gen_golden import import_reference, ref_convmols  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+CSV = os.path.join(OUT, "tox21.csv.gz")
+TASKS = ['NR-AR', 'NR-AR-LBD', 'NR-AhR', 'NR-Aromatase', 'NR-ER', 'NR-ER-LBD', 'NR-PPAR-gamma', 'SR-ARE',
+         'SR-ATAD5', 'SR-HSE', 'SR-MMP', 'SR-p53']
+RUNS = {
+    # name: (batch, epochs, learning rate, numpy seed for the shuffles)
+    "b64": (64, 40, 5e-4, 123),
+    "b100": (100, 10, 1e-3, 123),
+}
+
+
+def load_featurized():
+    """CSV -> (PackedMols, y, w) with the native featurizer; rows the featurizer rejects are dropped as
+    the reference's loader drops rdkit failures (data/data_loader.py:321-330)."""
+    from deepchem_amd.data.data_loader import convert_df_to_numpy, load_csv_files
+    from deepchem_amd.feat import ConvMolFeaturizer
+    # one shard: load_csv_files turns missing cells into "" (data/data_loader.py:874-906), which
+    # convert_df_to_numpy then maps to y = 0, w = 0 (:35-69)
+    df = next(iter(load_csv_files([CSV], shard_size=8192)))
+    packed, keep = ConvMolFeaturizer().featurize_packed(df["smiles"].tolist())
+    y, w = convert_df_to_numpy(df, TASKS)
+    return packed, y[keep], w[keep]
+
+
+def index_split(n, frac_train=0.8, frac_valid=0.1):
+    """IndexSplitter.split (splits/splitters.py:1050-1090)."""
+    a, b = int(frac_train * n), int((frac_train + frac_valid) * n)
+    return np.arange(0, a), np.arange(a, b), np.arange(b, n)
+
+
+def main():
+    import torch
+    dc = import_reference()
+    from deepchem.models.torch_models import GraphConvModel
+    from deepchem_amd.metrics import roc_auc_per_task
+    from oracle import graphconv_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    packed, y, w = load_featurized()
+    n = packed.n_mols
+    tr_i, va_i, te_i = index_split(n)
+    print("molecules", n, "atoms", packed.n_atoms, "split", len(tr_i), len(va_i), len(te_i))
+    from deepchem_amd.utils.synthetic import PackedMols
+    # the set is kept as 8-byte atom codes: expand once to the 75 float columns for the reference
+    packed = PackedMols(packed.atom_features, packed.atom_ptr, packed.adj_ptr, packed.adj_idx)
+    X = ref_convmols(dc, packed)
+    train = dc.data.NumpyDataset(X[tr_i], y[tr_i], w[tr_i])
+    valid = dc.data.NumpyDataset(X[va_i], y[va_i], w[va_i])
+    bal = dc.trans.BalancingTransformer(dataset=train)
+    train = bal.transform(train)
+    out = {"n_mols": np.array(n), "n_atoms": np.array(packed.n_atoms), "train_w_balanced": train.w,
+           "split": np.array([len(tr_i), len(va_i), len(te_i)])}
+    for name, (B, epochs, lr, seed) in RUNS.items():
+        cfg = O.ModelConfig(12, batch_size=B)
+        state = O.init_state(cfg, 123)
+        model = GraphConvModel(12, number_input_features=[75, 64], batch_size=B, mode="classification",
+                               learning_rate=lr)
+        model.model.load_state_dict({k: v.clone() for k, v in state.items()}, strict=True)
+        np.random.seed(seed)
+        t0 = time.time()
+        loss = model.fit(train, nb_epoch=epochs, checkpoint_interval=0)
+        wall = time.time() - t0
+        pv = np.asarray(model.predict(valid))
+        pt = np.asarray(model.predict(train))
+        auc_v = roc_auc_per_task(valid.y, pv, valid.w)
+        auc_t = roc_auc_per_task(train.y, pt, train.w)
+        print(name, "loss %.5f" % loss, "wall %.1f s (%d cores) = %.0f molecules/s" %
+              (wall, torch.get_num_threads(), epochs * len(tr_i) / wall))
+        print("  valid AUC mean %.4f" % np.nanmean(auc_v), np.round(auc_v, 4))
+        print("  train AUC mean %.4f" % np.nanmean(auc_t))
+        out[name + "_cfg"] = np.array([B, epochs, seed], np.int64)
+        out[name + "_lr"] = np.array(lr)
+        out[name + "_loss"] = np.array(loss)
+        out[name + "_valid_probs"] = pv.astype(np.float32)
+        out[name + "_valid_auc"] = auc_v
+        out[name + "_train_auc"] = auc_t
+        out[name + "_wall_s"] = np.array(wall)
+        out[name + "_cores"] = np.array(torch.get_num_threads())
+    np.savez_compressed(os.path.join(OUT, "tox21_ref.npz"), **out)
+    print("wrote", os.path.join(OUT, "tox21_ref.npz"))
+
+
+if __name__ == "__main__":
+    main()
