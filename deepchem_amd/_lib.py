@@ -97,6 +97,21 @@ class GcmiModelIO(Structure):
     ]
 
 
+class GcmiSmallBatch(Structure):
+    """struct gcmi_small_batch (include/gcmi.h)."""
+    _fields_ = [
+        ("graph", GcmiGraph),
+        ("d_atom_features", c_void_p),
+        ("ld_features", c_int64),
+        ("d_labels", c_void_p),
+        ("d_weights", c_void_p),
+        ("n_rows", c_int64),
+        ("d_logits", c_void_p),
+        ("d_probs", c_void_p),
+        ("d_fingerprint", c_void_p),
+    ]
+
+
 _P = c_void_p
 _G = POINTER(GcmiGraph)
 _MD = POINTER(GcmiModelDesc)
@@ -151,6 +166,9 @@ _SIGNATURES = {
     "gcmi_lstm_cell": [_P, c_int64, c_int32, c_int64, _P, c_int64, _P, c_int64, _P],
     "gcmi_model_forward": [_MD, _G, _P, _MIO, c_int32, _P],
     "gcmi_model_loss_backward": [_MD, _G, _P, _P, _MIO, _P, _P, c_int64, _I64P, _I64P, _P],
+    "gcmi_small_fit": [_MD, _P, _P, _P, _P, _MIO, _P, c_int64, c_int64, c_int64, c_float, c_float, c_float, c_float,
+                       c_int64, _P, _I64P, _I64P, _P],
+    "gcmi_small_predict": [_MD, _P, _MIO, _P, c_int64, c_int64, c_int64, _P],
     "gcmi_diag_mfma_peak": [c_int32, c_int32, _P, _P],
     "gcmi_set_option": [c_int32, c_int32],
     "gcmi_get_option": [c_int32, _I32P],
@@ -161,8 +179,8 @@ _SIGNATURES = {
     "gcmi_timing_read": [c_int32, _I64P, POINTER(c_double), c_int32],
 }
 
-EXPORTS = ["gcmi_version", "gcmi_last_error", "gcmi_model_workspace_floats", "gcmi_smiles_check",
-           "gcmi_collate_plan_words"] + sorted(_SIGNATURES)
+EXPORTS = ["gcmi_version", "gcmi_last_error", "gcmi_model_workspace_floats", "gcmi_small_workspace_floats",
+           "gcmi_smiles_check", "gcmi_collate_plan_words"] + sorted(_SIGNATURES)
 
 _lib = None
 
@@ -197,6 +215,8 @@ def load():
     lib.gcmi_last_error.restype = c_char_p
     lib.gcmi_model_workspace_floats.restype = c_int64
     lib.gcmi_model_workspace_floats.argtypes = [_MD, c_int64, c_int64]
+    lib.gcmi_small_workspace_floats.restype = c_int64
+    lib.gcmi_small_workspace_floats.argtypes = [_MD, c_int64, c_int64]
     lib.gcmi_smiles_check.restype = c_char_p
     lib.gcmi_collate_plan_words.restype = c_int64
     lib.gcmi_collate_plan_words.argtypes = [c_int64]

@@ -1,0 +1,1566 @@
+// The small-batch engine: one optimizer step of GraphConvModel as 8 launches (reference gradient
+// semantics) or 12 (full), for batches whose activations live in L2 (the reference's default batch of
+// 100 molecules is ~1 850 atoms; MolNet's Tox21 preset uses 64).
+//
+// Why a second execution model.  The large-batch kernels of this library (gather_lds.hip, gemm_split.hip,
+// bn.hip, readout.hip) are streaming kernels: 128-row tiles, persistent workgroups, one pass per operand.
+// At 2 000 atoms they occupy ~15 of 256 CUs and the step is ~45 launches of a few microseconds each,
+// bounded by launch cadence.  Here the unit of work is a 16-row tile of ONE degree block (so the per-degree
+// weights of GraphConv, models/torch_models/layers.py:6199-6229, are workgroup-uniform): one workgroup of
+// four waves per tile, each wave owning 16 output columns per pass on v_mfma_f32_16x16x4_f32 (fp32 operands,
+// fp32 accumulate: the reference's arithmetic), operands staged through LDS, everything else of a layer --
+// neighbour gather, bias, ReLU, BatchNorm statistics, folded BatchNorm, pooling, readout, task head, loss,
+// their backwards -- fused around it.  A kernel boundary is needed only where the model has a batch-wide
+// dependency (BatchNorm statistics; neighbour rows written by other tiles):
+//
+//   forward  conv0 | pool0 | conv1 | pool1+dense | readout+head+loss(+d head input)
+//   backward dense (dgrad tiles + weight-gradient slabs + head weight gradient) | pool1 (+BatchNorm 1 grads)
+//            [full mode: conv1 | dP0 | pool0 | conv0]
+//   adam     (+ loss, running statistics, counters, zeroing for the next step)
+//
+// Reference functions replaced: GraphConv.forward + sum_neigh (layers.py:6167-6246), GraphPool.forward
+// (:6319-6367), GraphGather.forward (:6450-6479), nn.BatchNorm1d / nn.Linear of _GraphConvTorchModel.forward
+// (graphconvmodel.py:188-249), SoftmaxCrossEntropy / L2Loss through _StandardLoss (losses.py:251-259, :85-94;
+// torch_model.py:1275-1294), torch.optim.Adam (optimizers.py:231-241), the step of fit_generator
+// (torch_model.py:435-443), over MANY batches per call: the host loop here replaces the Python loop.
+#include <math.h>
+
+#include "common.h"
+
+namespace gcmi {
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+constexpr int kTileRows = 16;
+constexpr int kSlabRows = 64;
+constexpr int kSBlock = 256;
+constexpr int kMaxL = GCMI_MAX_CONV_LAYERS;
+
+// A collated batch as the kernels see it (by value in the kernarg segment).
+struct SmallGraph {
+  int32_t n_atoms, n_mols, max_deg, n_tiles;
+  int32_t deg_start[GCMI_MAX_DEG + 2];
+  int32_t edge_start[GCMI_MAX_DEG + 2];
+  int32_t tile_start[GCMI_MAX_DEG + 2];  // 16-row tiles per degree block, prefix
+  const int32_t* col_idx;
+  const int32_t* membership;
+  const int32_t* mol_runs;
+  const uint8_t* rev_pos;
+};
+
+struct Tile {
+  int d, row0, nrows, e0;  // degree, first row, rows (<= 16), first edge of row0
+};
+
+__device__ __forceinline__ Tile tile_of(const SmallGraph& g, int t) {
+  int d = 0;
+#pragma unroll
+  for (int k = 1; k <= GCMI_MAX_DEG; ++k) d += (k <= g.max_deg && t >= g.tile_start[k]) ? 1 : 0;
+  Tile tl;
+  tl.d = d;
+  tl.row0 = g.deg_start[d] + (t - g.tile_start[d]) * kTileRows;
+  const int left = g.deg_start[d + 1] - tl.row0;
+  tl.nrows = left < kTileRows ? left : kTileRows;
+  tl.e0 = g.edge_start[d] + (tl.row0 - g.deg_start[d]) * d;
+  return tl;
+}
+
+__device__ __forceinline__ f4v mfma16(float a, float b, f4v c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// LDS pitch (floats) of a K-column operand tile read as MFMA A fragments (lane = row + 16*kq reads
+// [row][4*ks + kq]): conflict-free when pitch/4 is odd.
+__host__ __device__ inline int pitch_a(int k4) { return ((k4 / 4) & 1) ? k4 : k4 + 4; }
+// pitch for tiles read "transposed" (lane = col + 16*kq reads [4*ks + kq][col0 + col]): pitch % 64 == 16
+__host__ __device__ inline int pitch_t(int n) { return ((n + 63) / 64) * 64 + 16; }
+
+// BatchNorm coefficients of one column from the accumulated sums (training) or the running statistics (eval)
+struct BnCol {
+  float mean, invstd, scale, shift;
+};
+__device__ __forceinline__ BnCol bn_col_train(const double* __restrict__ acc, int width, int c, int n_rows,
+                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                              float eps) {
+  const double inv_n = 1.0 / (double)n_rows;
+  const double mean = acc[c] * inv_n;
+  double var = acc[width + c] * inv_n - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+  BnCol b;
+  b.mean = (float)mean;
+  b.invstd = (float)(1.0 / sqrt(var + (double)eps));
+  b.scale = gamma[c] * b.invstd;
+  b.shift = beta[c] - b.mean * b.scale;
+  return b;
+}
+__device__ __forceinline__ BnCol bn_col_eval(const float* __restrict__ rm, const float* __restrict__ rv, int c,
+                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                             float eps) {
+  BnCol b;
+  b.mean = rm[c];
+  b.invstd = (float)(1.0 / sqrt((double)rv[c] + (double)eps));
+  b.scale = gamma[c] * b.invstd;
+  b.shift = beta[c] - b.mean * b.scale;
+  return b;
+}
+
+struct BnArgs {          // how a kernel obtains the folded BatchNorm of its input
+  int mode;              // 0 none, 1 batch statistics from acc, 2 running statistics
+  const double* acc;     // [sum(width) | sum of squares(width)]
+  const float* rm;
+  const float* rv;
+  const float* gamma;
+  const float* beta;
+  float eps;
+  int n_rows;
+};
+
+__device__ __forceinline__ BnCol bn_col(const BnArgs& a, int width, int c) {
+  if (a.mode == 1) return bn_col_train(a.acc, width, c, a.n_rows, a.gamma, a.beta, a.eps);
+  if (a.mode == 2) return bn_col_eval(a.rm, a.rv, c, a.gamma, a.beta, a.eps);
+  BnCol b;
+  b.mean = 0.f;
+  b.invstd = 1.f;
+  b.scale = 1.f;
+  b.shift = 0.f;
+  return b;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// ------------------------------------------------------------------------------------------------ conv forward
+// out[rows of degree d] = relu(S . W_rel[d] + X . W_self[d] + b_rel[d] + b_self[d]),  S = sum of neighbour rows
+// (degree 0: X . W_self[0] + b_self[0]); optional column sums of out and out^2 into acc (fp64 atomics).
+// W_list order: rel_1, self_1, ..., rel_10, self_10, self_0 (layers.py:6189-6224).
+template <int NT>
+__global__ void __launch_bounds__(kSBlock)
+small_conv_fwd_kernel(SmallGraph g, const float* __restrict__ x, int ldx, int K, const float* __restrict__ Wl,
+                      const float* __restrict__ bl, float* __restrict__ out, double* __restrict__ acc) {
+  extern __shared__ float smem[];
+  const int t = blockIdx.x;
+  if (t >= g.n_tiles) return;
+  const Tile tl = tile_of(g, t);
+  const int W = 64 * NT;
+  const int K4 = (K + 3) & ~3;
+  const int KP = pitch_a(K4);
+  float* sS = smem;                 // [16][KP] neighbour sums
+  float* sX = smem + kTileRows * KP;  // [16][KP] own rows
+  const int q4 = K4 / 4;
+  for (int idx = threadIdx.x; idx < kTileRows * q4; idx += kSBlock) {
+    const int r = idx / q4, q = idx - r * q4;
+    float4 self = make_float4(0.f, 0.f, 0.f, 0.f), s = self;
+    if (r < tl.nrows) {
+      const int row = tl.row0 + r;
+      self = ld4(x + (int64_t)row * ldx + 4 * q);
+      const int32_t* nb = g.col_idx + tl.e0 + r * tl.d;
+      for (int j = 0; j < tl.d; ++j) {
+        const float4 v = ld4(x + (int64_t)nb[j] * ldx + 4 * q);
+        s.x += v.x;
+        s.y += v.y;
+        s.z += v.z;
+        s.w += v.w;
+      }
+      if (4 * q + 3 >= K) {  // columns beyond K (alignment padding of the input) never count
+        float* sf = reinterpret_cast<float*>(&self);
+        float* ss = reinterpret_cast<float*>(&s);
+        for (int c = 0; c < 4; ++c)
+          if (4 * q + c >= K) sf[c] = ss[c] = 0.f;
+      }
+    }
+    st4(sX + r * KP + 4 * q, self);
+    st4(sS + r * KP + 4 * q, s);
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lr = lane & 15, kq = lane >> 4;
+  const int64_t blk = (int64_t)K * W;
+  const float* Wself = Wl + (tl.d == 0 ? (int64_t)(2 * g.max_deg) * blk : (int64_t)(2 * (tl.d - 1) + 1) * blk);
+  const float* Wrel = tl.d == 0 ? nullptr : Wl + (int64_t)(2 * (tl.d - 1)) * blk;
+  f4v c[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) c[i] = (f4v){0.f, 0.f, 0.f, 0.f};
+  for (int ks = 0; ks < q4; ++ks) {
+    const int k = 4 * ks + kq;
+    const int kc = k < K ? k : K - 1;  // A is zero there
+    const float ax = sX[lr * KP + k];
+    const float as = sS[lr * KP + k];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int col = 16 * (wave + 4 * i) + lr;
+      c[i] = mfma16(ax, Wself[(int64_t)kc * W + col], c[i]);
+      if (Wrel) c[i] = mfma16(as, Wrel[(int64_t)kc * W + col], c[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int col = 16 * (wave + 4 * i) + lr;
+    float bias = tl.d == 0 ? bl[(int64_t)(2 * g.max_deg) * W + col]
+                           : bl[(int64_t)(2 * (tl.d - 1)) * W + col] + bl[(int64_t)(2 * (tl.d - 1) + 1) * W + col];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 4 * kq + j;
+      if (r < tl.nrows) {
+        const float v = fmaxf(c[i][j] + bias, 0.f);
+        out[(int64_t)(tl.row0 + r) * W + col] = v;
+        s1 += v;
+        s2 += v * v;
+      }
+    }
+    if (acc) {
+      s1 += __shfl_xor(s1, 16);
+      s2 += __shfl_xor(s2, 16);
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (kq == 0) {
+        atomicAdd(acc + col, (double)s1);
+        atomicAdd(acc + W + col, (double)s2);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ pool forward
+// One row of GraphPool over the folded BatchNorm of gc: max over {self} U neighbours, first maximum wins
+// (self, then neighbours in table order: layers.py:6353-6361; torch.max(dim) tie rule).  arg: 0 = self, j+1.
+__device__ __forceinline__ void pool_row_chunk(const SmallGraph& g, const Tile& tl, int r, const float* __restrict__ gc,
+                                               int W, int q, const float* sScale, const float* sShift, float4& best,
+                                               uint32_t& arg) {
+  const int row = tl.row0 + r;
+  const float4 sc = ld4(sScale + 4 * q), sh = ld4(sShift + 4 * q);
+  float4 v = ld4(gc + (int64_t)row * W + 4 * q);
+  best = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+  uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  const int32_t* nb = g.col_idx + tl.e0 + r * tl.d;
+  for (int j = 0; j < tl.d; ++j) {
+    v = ld4(gc + (int64_t)nb[j] * W + 4 * q);
+    const float y0 = fmaf(v.x, sc.x, sh.x), y1 = fmaf(v.y, sc.y, sh.y), y2 = fmaf(v.z, sc.z, sh.z),
+                y3 = fmaf(v.w, sc.w, sh.w);
+    if (y0 > best.x) { best.x = y0; a0 = j + 1; }
+    if (y1 > best.y) { best.y = y1; a1 = j + 1; }
+    if (y2 > best.z) { best.z = y2; a2 = j + 1; }
+    if (y3 > best.w) { best.w = y3; a3 = j + 1; }
+  }
+  arg = a0 | (a1 << 8) | (a2 << 16) | (a3 << 24);
+}
+
+__device__ __forceinline__ void fold_bn_to_lds(const BnArgs& bn, int W, float* sScale, float* sShift) {
+  for (int c = threadIdx.x; c < W; c += kSBlock) {
+    const BnCol b = bn_col(bn, W, c);
+    sScale[c] = b.scale;
+    sShift[c] = b.shift;
+  }
+}
+
+__global__ void __launch_bounds__(kSBlock)
+small_pool_fwd_kernel(SmallGraph g, const float* __restrict__ gc, int W, BnArgs bn, float* __restrict__ pool,
+                      uint8_t* __restrict__ arg) {
+  extern __shared__ float smem[];
+  const int t = blockIdx.x;
+  if (t >= g.n_tiles) return;
+  const Tile tl = tile_of(g, t);
+  float* sScale = smem;
+  float* sShift = smem + W;
+  fold_bn_to_lds(bn, W, sScale, sShift);
+  __syncthreads();
+  const int q4 = W / 4;
+  for (int idx = threadIdx.x; idx < tl.nrows * q4; idx += kSBlock) {
+    const int r = idx / q4, q = idx - r * q4;
+    float4 best;
+    uint32_t a;
+    pool_row_chunk(g, tl, r, gc, W, q, sScale, sShift, best, a);
+    st4(pool + (int64_t)(tl.row0 + r) * W + 4 * q, best);
+    if (arg) *reinterpret_cast<uint32_t*>(arg + (int64_t)(tl.row0 + r) * W + 4 * q) = a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ pool + dense forward
+// The last GraphPool fused with the atom-level nn.Linear(K -> D) + ReLU (graphconvmodel.py:222-223): the pooled
+// tile goes to LDS (and to HBM with its arg-max, for the backward) and straight into the product.
+// Wd is (D, K) row-major (nn.Linear).  Column sums of the output into acc (training).
+template <int NT>
+__global__ void __launch_bounds__(kSBlock)
+small_pool_dense_fwd_kernel(SmallGraph g, const float* __restrict__ gc, int K, BnArgs bn, float* __restrict__ pool,
+                            uint8_t* __restrict__ arg, const float* __restrict__ Wd, const float* __restrict__ bd,
+                            float* __restrict__ dense, double* __restrict__ acc) {
+  extern __shared__ float smem[];
+  const int t = blockIdx.x;
+  if (t >= g.n_tiles) return;
+  const Tile tl = tile_of(g, t);
+  const int D = 64 * NT;
+  const int KP = pitch_a(K);
+  float* sScale = smem;
+  float* sShift = smem + K;
+  float* sP = smem + 2 * K;  // [16][KP]
+  fold_bn_to_lds(bn, K, sScale, sShift);
+  __syncthreads();
+  const int q4 = K / 4;
+  for (int idx = threadIdx.x; idx < kTileRows * q4; idx += kSBlock) {
+    const int r = idx / q4, q = idx - r * q4;
+    float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < tl.nrows) {
+      uint32_t a;
+      pool_row_chunk(g, tl, r, gc, K, q, sScale, sShift, best, a);
+      st4(pool + (int64_t)(tl.row0 + r) * K + 4 * q, best);
+      if (arg) *reinterpret_cast<uint32_t*>(arg + (int64_t)(tl.row0 + r) * K + 4 * q) = a;
+    }
+    st4(sP + r * KP + 4 * q, best);
+  }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lr = lane & 15, kq = lane >> 4;
+  f4v c[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) c[i] = (f4v){0.f, 0.f, 0.f, 0.f};
+  for (int ks = 0; ks < q4; ++ks) {
+    const int k = 4 * ks + kq;
+    const float a = sP[lr * KP + k];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int col = 16 * (wave + 4 * i) + lr;
+      c[i] = mfma16(a, Wd[(int64_t)col * K + k], c[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int col = 16 * (wave + 4 * i) + lr;
+    const float bias = bd[col];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 4 * kq + j;
+      if (r < tl.nrows) {
+        const float v = fmaxf(c[i][j] + bias, 0.f);
+        dense[(int64_t)(tl.row0 + r) * D + col] = v;
+        s1 += v;
+        s2 += v * v;
+      }
+    }
+    if (acc) {
+      s1 += __shfl_xor(s1, 16);
+      s2 += __shfl_xor(s2, 16);
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (kq == 0) {
+        atomicAdd(acc + col, (double)s1);
+        atomicAdd(acc + D + col, (double)s2);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ readout + head + loss
+// One wave per molecule: GraphGather = [segment sum | segment max] of the folded BatchNorm of the dense output,
+// tanh (layers.py:6450-6479, graphconvmodel.py:174-175); task head (nn.Linear(2F, T*C), (T*C, 2F) row-major);
+// softmax (classification predictions); in training the loss term of every (molecule, task), d loss / d logits,
+// the gradient w.r.t. the fingerprint through tanh, and the column sums the BatchNorm backward of the dense layer
+// needs -- sum_r dy and sum_r dy * xhat -- formed per molecule from what the wave already holds:
+//   dy[r] = gs + [r == arg] gm   =>   sum_r dy = n gs + gm,   sum_r dy xhat = gs sum_r xhat + gm xhat[arg].
+struct ReadoutArgs {
+  const float* dense;   // N x F
+  BnArgs bn;
+  const float* Wh;      // TC x 2F
+  const float* bh;      // TC
+  float* fp;            // B x 2F   (output: embedding)
+  float* logits;        // B x TC
+  float* probs;         // B x TC or NULL
+  // training only (labels == NULL: prediction)
+  const float* labels;  // B x T x C (classification one-hot) or B x T
+  const float* weights; // B x T or NULL
+  int n_rows;           // molecules that count in the loss
+  float inv_count;      // 1 / (n_rows * T)
+  float* dlogits;       // B x TC
+  float* g2;            // B x 2F: gradient w.r.t. the gather output (before tanh)
+  int32_t* argrow;      // B x F: row of the maximum (-1: empty molecule)
+  double* loss_acc;     // 1
+  double* bsum;         // [sum dy (F) | sum dy*xhat (F)]
+  int F, T, C, mode;    // mode 0 classification, 1 regression
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <int NF>  // F = 64 * NF
+__global__ void __launch_bounds__(kSBlock)
+small_readout_kernel(SmallGraph g, ReadoutArgs a) {
+  extern __shared__ float smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + wave;
+  const int F = 64 * NF, TC = a.T * a.C;
+  float* sfp = smem + wave * (2 * F + 2 * TC);  // [2F] fingerprint, [TC] logits, [TC] dlogits
+  float* slog = sfp + 2 * F;
+  float* sdl = slog + TC;
+  if (m >= g.n_mols) return;
+  BnCol bn[NF];
+  float s[NF], raw[NF], mx[NF], rawarg[NF];
+  int arow[NF];
+#pragma unroll
+  for (int u = 0; u < NF; ++u) {
+    bn[u] = bn_col(a.bn, F, lane + 64 * u);
+    s[u] = raw[u] = rawarg[u] = 0.f;
+    mx[u] = -INFINITY;
+    arow[u] = -1;
+  }
+  int n_m = 0;
+  const int32_t* runs = g.mol_runs + (int64_t)m * (g.max_deg + 1) * 2;
+  for (int dd = 0; dd <= g.max_deg; ++dd) {
+    const int b = runs[2 * dd], e = runs[2 * dd + 1];
+    n_m += e - b;
+    for (int r = b; r < e; ++r) {
+#pragma unroll
+      for (int u = 0; u < NF; ++u) {
+        const float v = a.dense[(int64_t)r * F + lane + 64 * u];
+        const float y = fmaf(v, bn[u].scale, bn[u].shift);
+        raw[u] += v;
+        s[u] += y;
+        if (y > mx[u]) {
+          mx[u] = y;
+          arow[u] = r;
+          rawarg[u] = v;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < NF; ++u) {
+    const int f = lane + 64 * u;
+    const float ts = tanhf(s[u]), tm = tanhf(mx[u]);
+    sfp[f] = ts;
+    sfp[F + f] = tm;
+    a.fp[(int64_t)m * 2 * F + f] = ts;
+    a.fp[(int64_t)m * 2 * F + F + f] = tm;
+  }
+  // task head: one coalesced row of Wh per output, wave reduction
+  for (int tc = 0; tc < TC; ++tc) {
+    float p = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2 * NF; ++u) p = fmaf(sfp[lane + 64 * u], a.Wh[(int64_t)tc * 2 * F + lane + 64 * u], p);
+    p = wave_sum(p);
+    if (lane == 0) slog[tc] = p + a.bh[tc];
+  }
+  for (int tc = lane; tc < TC; tc += 64) a.logits[(int64_t)m * TC + tc] = slog[tc];
+  const bool train = a.labels != nullptr;
+  float lsum = 0.f;
+  for (int t = lane; t < a.T; t += 64) {
+    if (a.mode == 0) {
+      const float* x = slog + t * a.C;
+      float mxl = -INFINITY;
+      for (int c = 0; c < a.C; ++c) mxl = fmaxf(mxl, x[c]);
+      float se = 0.f;
+      for (int c = 0; c < a.C; ++c) se += expf(x[c] - mxl);
+      const float lse = logf(se);
+      const float w = (train && a.weights) ? a.weights[(int64_t)m * a.T + t] : 1.f;
+      float ysum = 0.f, l = 0.f;
+      if (train)
+        for (int c = 0; c < a.C; ++c) ysum += a.labels[((int64_t)m * a.T + t) * a.C + c];
+      for (int c = 0; c < a.C; ++c) {
+        const float logp = x[c] - mxl - lse;
+        const float p = expf(logp);
+        if (a.probs) a.probs[((int64_t)m * a.T + t) * a.C + c] = p;
+        if (train) {
+          const float y = a.labels[((int64_t)m * a.T + t) * a.C + c];
+          l -= y * logp;
+          sdl[t * a.C + c] = m < a.n_rows ? w * (p * ysum - y) * a.inv_count : 0.f;
+        }
+      }
+      if (train && m < a.n_rows) lsum += w * l;
+    } else if (train) {
+      const float w = a.weights ? a.weights[(int64_t)m * a.T + t] : 1.f;
+      const float dlt = slog[t] - a.labels[(int64_t)m * a.T + t];
+      sdl[t] = m < a.n_rows ? 2.f * dlt * w * a.inv_count : 0.f;
+      if (m < a.n_rows) lsum += w * dlt * dlt;
+    }
+  }
+  if (!train) return;
+  lsum = wave_sum(lsum);
+  if (lane == 0 && lsum != 0.f) atomicAdd(a.loss_acc, (double)lsum);
+  for (int tc = lane; tc < TC; tc += 64) a.dlogits[(int64_t)m * TC + tc] = sdl[tc];
+  // d fingerprint = dlogits . Wh, through tanh
+  float gfp[2 * NF];
+#pragma unroll
+  for (int u = 0; u < 2 * NF; ++u) gfp[u] = 0.f;
+  for (int tc = 0; tc < TC; ++tc) {
+    const float d = sdl[tc];
+#pragma unroll
+    for (int u = 0; u < 2 * NF; ++u) gfp[u] = fmaf(d, a.Wh[(int64_t)tc * 2 * F + lane + 64 * u], gfp[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < 2 * NF; ++u) {
+    const float y = sfp[lane + 64 * u];
+    gfp[u] *= (1.f - y * y);
+    a.g2[(int64_t)m * 2 * F + lane + 64 * u] = gfp[u];
+  }
+#pragma unroll
+  for (int u = 0; u < NF; ++u) {
+    const int f = lane + 64 * u;
+    a.argrow[(int64_t)m * F + f] = arow[u];
+    if (a.bsum && n_m > 0) {
+      const float gs = gfp[u], gm = gfp[NF + u];
+      const float sum_xhat = bn[u].invstd * (raw[u] - (float)n_m * bn[u].mean);
+      const float xhat_arg = (rawarg[u] - bn[u].mean) * bn[u].invstd;
+      atomicAdd(a.bsum + f, (double)((float)n_m * gs + gm));
+      atomicAdd(a.bsum + F + f, (double)(gs * sum_xhat + gm * xhat_arg));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dense backward
+// One launch, three kinds of workgroups:
+//   [0, n_tiles)            16-row tiles: dx of the dense pre-activation (readout backward recomputed from the
+//                           per-molecule gradient, BatchNorm backward, ReLU mask) -> dP = dx . Wd  (N x K)
+//   [n_tiles, +n_slabs)     64-row slabs: dWd += dx^T . P, dbd += column sums of dx (float atomics, one per
+//                           output element and slab); slab 0 also writes the BatchNorm gradient
+//   [.., +head blocks)      dWh = dlogits^T . fp, dbh = column sums of dlogits (plain stores)
+struct DenseBwdArgs {
+  const float* dense;      // N x F (post-ReLU dense output = BatchNorm input)
+  const float* pool;       // N x K
+  const float* g2;         // B x 2F
+  const int32_t* argrow;   // B x F
+  BnArgs bn;               // mode 1 (batch statistics) or 0
+  const double* bsum;      // [sum dy | sum dy xhat]
+  const float* Wd;         // F x K
+  float* dpool;            // N x K
+  float* dWd;              // F x K   (accumulated)
+  float* dbd;              // F       (accumulated)
+  float* dgamma;           // F       (written)
+  float* dbeta;            // F
+  const float* dlogits;    // B x TC
+  const float* fp;         // B x 2F
+  float* dWh;              // TC x 2F (written)
+  float* dbh;              // TC
+  int F, K, TC, n_slabs, n_head_blocks;
+};
+
+// dx of `rows` consecutive rows starting at row0 into LDS tile sDx[rows][pitch]
+__device__ __forceinline__ void dense_dx_to_lds(const SmallGraph& g, const DenseBwdArgs& a, int row0, int nrows,
+                                                int tile_rows, const float* sA, const float* sB, const float* sC,
+                                                float* sDx, int pitch) {
+  const int F = a.F, q4 = F / 4;
+  for (int idx = threadIdx.x; idx < tile_rows * q4; idx += kSBlock) {
+    const int r = idx / q4, q = idx - r * q4;
+    float4 dx = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < nrows) {
+      const int row = row0 + r;
+      const int m = g.membership[row];
+      const float4 gs = ld4(a.g2 + (int64_t)m * 2 * F + 4 * q);
+      const float4 gm = ld4(a.g2 + (int64_t)m * 2 * F + F + 4 * q);
+      const int4 ar = *reinterpret_cast<const int4*>(a.argrow + (int64_t)m * F + 4 * q);
+      const float4 x = ld4(a.dense + (int64_t)row * F + 4 * q);
+      const float4 cA = ld4(sA + 4 * q), cB = ld4(sB + 4 * q), cC = ld4(sC + 4 * q);
+      const float dy0 = gs.x + (ar.x == row ? gm.x : 0.f), dy1 = gs.y + (ar.y == row ? gm.y : 0.f),
+                  dy2 = gs.z + (ar.z == row ? gm.z : 0.f), dy3 = gs.w + (ar.w == row ? gm.w : 0.f);
+      // dx = A dy + B x + C  (BatchNorm backward folded per column), masked by the ReLU in front
+      dx.x = x.x > 0.f ? fmaf(cA.x, dy0, fmaf(cB.x, x.x, cC.x)) : 0.f;
+      dx.y = x.y > 0.f ? fmaf(cA.y, dy1, fmaf(cB.y, x.y, cC.y)) : 0.f;
+      dx.z = x.z > 0.f ? fmaf(cA.z, dy2, fmaf(cB.z, x.z, cC.z)) : 0.f;
+      dx.w = x.w > 0.f ? fmaf(cA.w, dy3, fmaf(cB.w, x.w, cC.w)) : 0.f;
+    }
+    st4(sDx + r * pitch + 4 * q, dx);
+  }
+}
+
+// BatchNorm backward as dx = A dy + B x + C per column:
+//   xhat = (x - mean) invstd;  dx = gamma invstd (dy - S1/N - xhat S2/N),  S1 = sum dy, S2 = sum dy xhat
+//   => A = gamma invstd,  B = -A invstd S2/N,  C = -A S1/N - B mean.   Without BatchNorm: A = 1, B = C = 0.
+__device__ __forceinline__ void bn_bwd_coeffs_to_lds(const BnArgs& bn, const double* bsum, int F, float* sA, float* sB,
+                                                     float* sC, float* dgamma, float* dbeta) {
+  for (int c = threadIdx.x; c < F; c += kSBlock) {
+    if (bn.mode == 0) {
+      sA[c] = 1.f;
+      sB[c] = 0.f;
+      sC[c] = 0.f;
+      continue;
+    }
+    const BnCol b = bn_col(bn, F, c);
+    const double inv_n = 1.0 / (double)bn.n_rows;
+    const double S1 = bsum[c], S2 = bsum[F + c];
+    const double A = (double)bn.gamma[c] * (double)b.invstd;
+    const double B = -A * (double)b.invstd * S2 * inv_n;
+    const double C = -A * S1 * inv_n - B * (double)b.mean;
+    sA[c] = (float)A;
+    sB[c] = (float)B;
+    sC[c] = (float)C;
+    if (dgamma) {
+      dgamma[c] = (float)S2;
+      dbeta[c] = (float)S1;
+    }
+  }
+}
+
+template <int NKT>  // K = 64 * NKT columns of dP per row
+__global__ void __launch_bounds__(kSBlock)
+small_dense_bwd_kernel(SmallGraph g, DenseBwdArgs a) {
+  extern __shared__ float smem[];
+  const int F = a.F, K = a.K;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lr = lane & 15, kq = lane >> 4;
+  int b = blockIdx.x;
+  if (b < g.n_tiles) {
+    const Tile tl = tile_of(g, b);
+    const int FP = pitch_a(F);
+    float* sA = smem;
+    float* sB = smem + F;
+    float* sC = smem + 2 * F;
+    float* sDx = smem + 3 * F;  // [16][FP]
+    bn_bwd_coeffs_to_lds(a.bn, a.bsum, F, sA, sB, sC, nullptr, nullptr);
+    __syncthreads();
+    dense_dx_to_lds(g, a, tl.row0, tl.nrows, kTileRows, sA, sB, sC, sDx, FP);
+    __syncthreads();
+    f4v c[NKT];
+#pragma unroll
+    for (int i = 0; i < NKT; ++i) c[i] = (f4v){0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < F / 4; ++ks) {
+      const int o = 4 * ks + kq;
+      const float av = sDx[lr * FP + o];
+#pragma unroll
+      for (int i = 0; i < NKT; ++i) c[i] = mfma16(av, a.Wd[(int64_t)o * K + 16 * (wave + 4 * i) + lr], c[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NKT; ++i) {
+      const int col = 16 * (wave + 4 * i) + lr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * kq + j;
+        if (r < tl.nrows) a.dpool[(int64_t)(tl.row0 + r) * K + col] = c[i][j];
+      }
+    }
+    return;
+  }
+  b -= g.n_tiles;
+  if (b < a.n_slabs) {
+    // dWd[o][k] += sum_r dx[r][o] P[r][k] over the slab's 64 rows
+    const int row0 = b * kSlabRows;
+    const int nrows = min(kSlabRows, g.n_atoms - row0);
+    const int FT = pitch_t(F), KT = pitch_t(K);
+    float* sA = smem;
+    float* sB = smem + F;
+    float* sC = smem + 2 * F;
+    float* sDx = smem + 3 * F;            // [64][FT]
+    float* sP = sDx + kSlabRows * FT;     // [64][KT]
+    bn_bwd_coeffs_to_lds(a.bn, a.bsum, F, sA, sB, sC, b == 0 ? a.dgamma : nullptr, a.dbeta);
+    __syncthreads();
+    dense_dx_to_lds(g, a, row0, nrows, kSlabRows, sA, sB, sC, sDx, FT);
+    for (int idx = threadIdx.x; idx < kSlabRows * (K / 4); idx += kSBlock) {
+      const int r = idx / (K / 4), q = idx - r * (K / 4);
+      st4(sP + r * KT + 4 * q, r < nrows ? ld4(a.pool + (int64_t)(row0 + r) * K + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+    __syncthreads();
+    const int n_ot = F / 16, n_kt = K / 16;
+    for (int ot = wave; ot < n_ot; ot += 4) {
+      for (int kt0 = 0; kt0 < n_kt; kt0 += 4) {
+        f4v c[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[i] = (f4v){0.f, 0.f, 0.f, 0.f};
+        for (int rs = 0; rs < kSlabRows / 4; ++rs) {
+          const int r = 4 * rs + kq;
+          const float av = sDx[r * FT + 16 * ot + lr];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (kt0 + i < n_kt) c[i] = mfma16(av, sP[r * KT + 16 * (kt0 + i) + lr], c[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (kt0 + i >= n_kt) continue;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int o = 16 * ot + 4 * kq + j, k = 16 * (kt0 + i) + lr;
+            atomicAdd(a.dWd + (int64_t)o * K + k, c[i][j]);
+          }
+        }
+      }
+    }
+    for (int o = threadIdx.x; o < F; o += kSBlock) {
+      float s = 0.f;
+      for (int r = 0; r < nrows; ++r) s += sDx[r * FT + o];
+      atomicAdd(a.dbd + o, s);
+    }
+    return;
+  }
+  b -= a.n_slabs;
+  // head weight gradient: one thread per (tc, f')
+  const int64_t gid = (int64_t)b * kSBlock + threadIdx.x;
+  const int F2 = 2 * F;
+  if (gid < (int64_t)a.TC * F2) {
+    const int tc = (int)(gid / F2), f = (int)(gid - (int64_t)tc * F2);
+    float s = 0.f, sb = 0.f;
+    for (int m = 0; m < g.n_mols; ++m) {
+      const float d = a.dlogits[(int64_t)m * a.TC + tc];
+      s = fmaf(d, a.fp[(int64_t)m * F2 + f], s);
+      sb += d;
+    }
+    a.dWh[(int64_t)tc * F2 + f] = s;
+    if (f == 0) a.dbh[tc] = sb;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ pool backward
+// dA[k] = [arg[k] == self] dP[k] + sum_j [arg[nb_j] == slot of k in nb_j's list + 1] dP[nb_j]   (a gather: every
+// bond is listed from both ends, rev_pos names the slot), i.e. the gradient w.r.t. the BatchNorm OUTPUT of the
+// layer; its column sums with and without xhat are the BatchNorm gradient (dbeta, dgamma; float atomics).
+__global__ void __launch_bounds__(kSBlock)
+small_pool_bwd_kernel(SmallGraph g, const float* __restrict__ dpool, const uint8_t* __restrict__ arg,
+                      const float* __restrict__ gc, int W, BnArgs bn, float* __restrict__ dA,
+                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  extern __shared__ float smem[];
+  const int t = blockIdx.x;
+  if (t >= g.n_tiles) return;
+  const Tile tl = tile_of(g, t);
+  const int q4 = W / 4;
+  float* sMean = smem;
+  float* sInv = smem + W;
+  float* red = smem + 2 * W;  // [16][2W] partial sums per row of the tile
+  for (int c = threadIdx.x; c < W; c += kSBlock) {
+    const BnCol b = bn_col(bn, W, c);
+    sMean[c] = b.mean;
+    sInv[c] = b.invstd;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < kTileRows * q4; idx += kSBlock) {
+    const int r = idx / q4, q = idx - r * q4;
+    float4 d = make_float4(0.f, 0.f, 0.f, 0.f), dx = d;
+    if (r < tl.nrows) {
+      const int row = tl.row0 + r;
+      const uint32_t a = *reinterpret_cast<const uint32_t*>(arg + (int64_t)row * W + 4 * q);
+      const float4 v = ld4(dpool + (int64_t)row * W + 4 * q);
+      d.x = (a & 0xff) == 0 ? v.x : 0.f;
+      d.y = ((a >> 8) & 0xff) == 0 ? v.y : 0.f;
+      d.z = ((a >> 16) & 0xff) == 0 ? v.z : 0.f;
+      d.w = (a >> 24) == 0 ? v.w : 0.f;
+      const int e = tl.e0 + r * tl.d;
+      for (int j = 0; j < tl.d; ++j) {
+        const int nb = g.col_idx[e + j];
+        const uint32_t want = (uint32_t)g.rev_pos[e + j] + 1u;
+        const uint32_t an = *reinterpret_cast<const uint32_t*>(arg + (int64_t)nb * W + 4 * q);
+        const float4 vn = ld4(dpool + (int64_t)nb * W + 4 * q);
+        d.x += (an & 0xff) == want ? vn.x : 0.f;
+        d.y += ((an >> 8) & 0xff) == want ? vn.y : 0.f;
+        d.z += ((an >> 16) & 0xff) == want ? vn.z : 0.f;
+        d.w += (an >> 24) == want ? vn.w : 0.f;
+      }
+      if (dA) st4(dA + (int64_t)row * W + 4 * q, d);
+      const float4 x = ld4(gc + (int64_t)row * W + 4 * q);
+      const float4 mu = ld4(sMean + 4 * q), iv = ld4(sInv + 4 * q);
+      dx.x = d.x * (x.x - mu.x) * iv.x;
+      dx.y = d.y * (x.y - mu.y) * iv.y;
+      dx.z = d.z * (x.z - mu.z) * iv.z;
+      dx.w = d.w * (x.w - mu.w) * iv.w;
+    }
+    st4(red + r * 2 * W + 4 * q, d);
+    st4(red + r * 2 * W + W + 4 * q, dx);
+  }
+  __syncthreads();
+  if (bn.mode == 0 || dgamma == nullptr) return;
+  for (int c = threadIdx.x; c < 2 * W; c += kSBlock) {
+    float s = 0.f;
+    for (int r = 0; r < tl.nrows; ++r) s += red[r * 2 * W + c];
+    if (c < W)
+      atomicAdd(dbeta + c, s);
+    else
+      atomicAdd(dgamma + c - W, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ conv backward (full mode)
+// Gradient through BatchNorm + ReLU of a GraphConv layer, then
+//   tiles:  dS = dg . W_rel[d]^T (N x K), dXs = dg . W_self[d]^T (N x K)       (layer > 0 only)
+//   slabs:  dW_rel[d] += S^T dg, dW_self[d] += X^T dg, db_rel[d] += colsum dg, db_self[d] += colsum dg
+// with S recomputed by the neighbour gather.  dA = gradient w.r.t. the BatchNorm output (from pool backward),
+// dgamma/dbeta = its column sums (already complete: previous launch).
+struct ConvBwdArgs {
+  const float* dA;       // N x W
+  const float* gc;       // N x W post-ReLU conv output (BatchNorm input)
+  BnArgs bn;
+  const float* dgamma;   // sum dA xhat
+  const float* dbeta;    // sum dA
+  const float* x;        // N x ldx layer input
+  int ldx, K, W;
+  const float* Wl;       // 21 x K x W
+  float* dWl;            // accumulated
+  float* dbl;            // 21 x W accumulated
+  float* dS;             // N x K4 (layer > 0) or NULL
+  float* dXs;            // N x K4
+  int n_slabs;
+  int32_t slab_start[GCMI_MAX_DEG + 2];  // 64-row slabs per degree block, prefix
+};
+
+__device__ __forceinline__ void conv_dg_to_lds(const ConvBwdArgs& a, int row0, int nrows, int tile_rows,
+                                               const float* sA, const float* sB, const float* sC, float* sG,
+                                               int pitch) {
+  const int W = a.W, q4 = W / 4;
+  for (int idx = threadIdx.x; idx < tile_rows * q4; idx += kSBlock) {
+    const int r = idx / q4, q = idx - r * q4;
+    float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < nrows) {
+      const float4 dy = ld4(a.dA + (int64_t)(row0 + r) * W + 4 * q);
+      const float4 x = ld4(a.gc + (int64_t)(row0 + r) * W + 4 * q);
+      const float4 cA = ld4(sA + 4 * q), cB = ld4(sB + 4 * q), cC = ld4(sC + 4 * q);
+      dg.x = x.x > 0.f ? fmaf(cA.x, dy.x, fmaf(cB.x, x.x, cC.x)) : 0.f;
+      dg.y = x.y > 0.f ? fmaf(cA.y, dy.y, fmaf(cB.y, x.y, cC.y)) : 0.f;
+      dg.z = x.z > 0.f ? fmaf(cA.z, dy.z, fmaf(cB.z, x.z, cC.z)) : 0.f;
+      dg.w = x.w > 0.f ? fmaf(cA.w, dy.w, fmaf(cB.w, x.w, cC.w)) : 0.f;
+    }
+    st4(sG + r * pitch + 4 * q, dg);
+  }
+}
+
+__device__ __forceinline__ void conv_bwd_coeffs(const ConvBwdArgs& a, float* sA, float* sB, float* sC) {
+  for (int c = threadIdx.x; c < a.W; c += kSBlock) {
+    if (a.bn.mode == 0) {
+      sA[c] = 1.f;
+      sB[c] = 0.f;
+      sC[c] = 0.f;
+      continue;
+    }
+    const BnCol b = bn_col(a.bn, a.W, c);
+    const double inv_n = 1.0 / (double)a.bn.n_rows;
+    const double A = (double)a.bn.gamma[c] * (double)b.invstd;
+    const double B = -A * (double)b.invstd * (double)a.dgamma[c] * inv_n;
+    const double C = -A * (double)a.dbeta[c] * inv_n - B * (double)b.mean;
+    sA[c] = (float)A;
+    sB[c] = (float)B;
+    sC[c] = (float)C;
+  }
+}
+
+__global__ void __launch_bounds__(kSBlock)
+small_conv_bwd_kernel(SmallGraph g, ConvBwdArgs a) {
+  extern __shared__ float smem[];
+  const int W = a.W, K = a.K, K4 = (K + 3) & ~3;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lr = lane & 15, kq = lane >> 4;
+  const int64_t blk = (int64_t)K * W;
+  float* sA = smem;
+  float* sB = smem + W;
+  float* sC = smem + 2 * W;
+  int b = blockIdx.x;
+  const int n_dgrad = a.dS ? g.n_tiles : 0;
+  if (b < n_dgrad) {
+    const Tile tl = tile_of(g, b);
+    const int WP = pitch_a(W);
+    float* sG = smem + 3 * W;  // [16][WP]
+    conv_bwd_coeffs(a, sA, sB, sC);
+    __syncthreads();
+    conv_dg_to_lds(a, tl.row0, tl.nrows, kTileRows, sA, sB, sC, sG, WP);
+    __syncthreads();
+    const float* Wself = a.Wl + (tl.d == 0 ? (int64_t)(2 * g.max_deg) * blk : (int64_t)(2 * (tl.d - 1) + 1) * blk);
+    const float* Wrel = tl.d == 0 ? nullptr : a.Wl + (int64_t)(2 * (tl.d - 1)) * blk;
+    // out[r][k] = sum_c dg[r][c] W[k][c]: B fragment = W[k = col][c = 4 ks + kq]
+    for (int kt = wave; kt < K4 / 16 + ((K4 % 16) ? 1 : 0); kt += 4) {
+      const int k = 16 * kt + lr;
+      const int kc = k < K ? k : K - 1;
+      f4v cs = (f4v){0.f, 0.f, 0.f, 0.f}, cx = cs;
+      for (int ks = 0; ks < W / 4; ++ks) {
+        const int c = 4 * ks + kq;
+        const float av = sG[lr * WP + c];
+        cx = mfma16(av, Wself[(int64_t)kc * W + c], cx);
+        if (Wrel) cs = mfma16(av, Wrel[(int64_t)kc * W + c], cs);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * kq + j;
+        if (r < tl.nrows && k < K4) {
+          a.dXs[(int64_t)(tl.row0 + r) * K4 + k] = k < K ? cx[j] : 0.f;
+          a.dS[(int64_t)(tl.row0 + r) * K4 + k] = k < K ? cs[j] : 0.f;
+        }
+      }
+    }
+    return;
+  }
+  b -= n_dgrad;
+  if (b >= a.n_slabs) return;
+  // weight-gradient slab: 64 rows of one degree
+  int d = 0;
+#pragma unroll
+  for (int k = 1; k <= GCMI_MAX_DEG; ++k) d += (k <= g.max_deg && b >= a.slab_start[k]) ? 1 : 0;
+  const int row0 = g.deg_start[d] + (b - a.slab_start[d]) * kSlabRows;
+  const int nrows = min(kSlabRows, g.deg_start[d + 1] - row0);
+  const int e0 = g.edge_start[d] + (row0 - g.deg_start[d]) * d;
+  const int WT = pitch_t(W), KT = pitch_t(K4);
+  float* sG = smem + 3 * W;             // [64][WT]
+  float* sX = sG + kSlabRows * WT;      // [64][KT] own rows
+  float* sS = sX + kSlabRows * KT;      // [64][KT] neighbour sums
+  conv_bwd_coeffs(a, sA, sB, sC);
+  __syncthreads();
+  conv_dg_to_lds(a, row0, nrows, kSlabRows, sA, sB, sC, sG, WT);
+  const int q4 = K4 / 4;
+  for (int idx = threadIdx.x; idx < kSlabRows * q4; idx += kSBlock) {
+    const int r = idx / q4, q = idx - r * q4;
+    float4 self = make_float4(0.f, 0.f, 0.f, 0.f), s = self;
+    if (r < nrows) {
+      self = ld4(a.x + (int64_t)(row0 + r) * a.ldx + 4 * q);
+      const int32_t* nb = g.col_idx + e0 + r * d;
+      for (int j = 0; j < d; ++j) {
+        const float4 v = ld4(a.x + (int64_t)nb[j] * a.ldx + 4 * q);
+        s.x += v.x;
+        s.y += v.y;
+        s.z += v.z;
+        s.w += v.w;
+      }
+    }
+    st4(sX + r * KT + 4 * q, self);
+    st4(sS + r * KT + 4 * q, s);
+  }
+  __syncthreads();
+  float* dWself = a.dWl + (d == 0 ? (int64_t)(2 * g.max_deg) * blk : (int64_t)(2 * (d - 1) + 1) * blk);
+  float* dWrel = d == 0 ? nullptr : a.dWl + (int64_t)(2 * (d - 1)) * blk;
+  // dW[k][c] = sum_r X[r][k] dg[r][c]: A fragment = X^T (m = k), B fragment = dg (n = c)
+  const int n_kt = (K4 + 15) / 16, n_ct = W / 16;
+  for (int kt = wave; kt < n_kt; kt += 4) {
+    const int k = 16 * kt + lr;
+    for (int ct0 = 0; ct0 < n_ct; ct0 += 4) {
+      f4v cx[4], cs[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cx[i] = cs[i] = (f4v){0.f, 0.f, 0.f, 0.f};
+      for (int rs = 0; rs < kSlabRows / 4; ++rs) {
+        const int r = 4 * rs + kq;
+        const float ax = k < K4 ? sX[r * KT + k] : 0.f;
+        const float as = k < K4 ? sS[r * KT + k] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (ct0 + i >= n_ct) continue;
+          const float bv = sG[r * WT + 16 * (ct0 + i) + lr];
+          cx[i] = mfma16(ax, bv, cx[i]);
+          if (dWrel) cs[i] = mfma16(as, bv, cs[i]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (ct0 + i >= n_ct) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int kk = 16 * kt + 4 * kq + j, c = 16 * (ct0 + i) + lr;
+          if (kk < K) {
+            atomicAdd(dWself + (int64_t)kk * W + c, cx[i][j]);
+            if (dWrel) atomicAdd(dWrel + (int64_t)kk * W + c, cs[i][j]);
+          }
+        }
+      }
+    }
+  }
+  for (int c = threadIdx.x; c < W; c += kSBlock) {
+    float s = 0.f;
+    for (int r = 0; r < nrows; ++r) s += sG[r * WT + c];
+    if (d == 0) {
+      atomicAdd(a.dbl + (int64_t)(2 * g.max_deg) * W + c, s);
+    } else {
+      atomicAdd(a.dbl + (int64_t)(2 * (d - 1)) * W + c, s);
+      atomicAdd(a.dbl + (int64_t)(2 * (d - 1) + 1) * W + c, s);
+    }
+  }
+}
+
+// dP[k] = dXs[k] + sum_j dS[nb_j(k)]: the transposed neighbour sum over a symmetric adjacency is a gather
+__global__ void __launch_bounds__(kSBlock)
+small_gather_add_kernel(SmallGraph g, const float* __restrict__ dXs, const float* __restrict__ dS, int W,
+                        float* __restrict__ dP) {
+  const int t = blockIdx.x;
+  if (t >= g.n_tiles) return;
+  const Tile tl = tile_of(g, t);
+  const int q4 = W / 4;
+  for (int idx = threadIdx.x; idx < tl.nrows * q4; idx += kSBlock) {
+    const int r = idx / q4, q = idx - r * q4;
+    const int row = tl.row0 + r;
+    float4 s = ld4(dXs + (int64_t)row * W + 4 * q);
+    const int32_t* nb = g.col_idx + tl.e0 + r * tl.d;
+    for (int j = 0; j < tl.d; ++j) {
+      const float4 v = ld4(dS + (int64_t)nb[j] * W + 4 * q);
+      s.x += v.x;
+      s.y += v.y;
+      s.z += v.z;
+      s.w += v.w;
+    }
+    st4(dP + (int64_t)row * W + 4 * q, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ adam + bookkeeping
+struct StepEnd {
+  float* p;
+  float* grad;
+  float* m;
+  float* v;
+  int64_t lo, hi;          // trained range of the flat arenas
+  float one_minus_b1, b2, one_minus_b2, step_size, inv_bc2_sqrt, eps;
+  double* loss_acc;
+  float* loss_out;         // this step's loss
+  float inv_count;
+  int n_bn;                // BatchNorm layers with batch statistics to fold into the running ones
+  int n_rows;
+  float momentum;
+  double* acc[kMaxL + 1];  // [sum | sumsq] per layer
+  int width[kMaxL + 1];
+  float* rm[kMaxL + 1];
+  float* rv[kMaxL + 1];
+  int64_t* tracked[kMaxL + 1];
+  double* zero_from;       // accumulator region to clear for the next step
+  int64_t zero_doubles;
+};
+
+__global__ void __launch_bounds__(kSBlock)
+small_step_end_kernel(StepEnd s) {
+  // torch.optim.Adam (optimizers.py:231-241): exp_avg.lerp_, exp_avg_sq.mul_.addcmul_, addcdiv_
+  const int64_t n4 = (s.hi - s.lo) / 4;
+  for (int64_t i = (int64_t)blockIdx.x * kSBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kSBlock) {
+    const int64_t o = s.lo + 4 * i;
+    float4 g = ld4(s.grad + o), m = ld4(s.m + o), v = ld4(s.v + o), p = ld4(s.p + o);
+    float* gf = reinterpret_cast<float*>(&g);
+    float* mf = reinterpret_cast<float*>(&m);
+    float* vf = reinterpret_cast<float*>(&v);
+    float* pf = reinterpret_cast<float*>(&p);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      mf[c] = mf[c] + (gf[c] - mf[c]) * s.one_minus_b1;
+      vf[c] = vf[c] * s.b2 + gf[c] * gf[c] * s.one_minus_b2;
+      const float denom = sqrtf(vf[c]) * s.inv_bc2_sqrt + s.eps;
+      pf[c] -= s.step_size * (mf[c] / denom);
+    }
+    st4(s.m + o, m);
+    st4(s.v + o, v);
+    st4(s.p + o, p);
+    st4(s.grad + o, make_float4(0.f, 0.f, 0.f, 0.f));  // the next step accumulates into a clean arena
+  }
+  if (blockIdx.x != 0) return;
+  if (threadIdx.x == 0 && s.loss_out) *s.loss_out = (float)(*s.loss_acc * (double)s.inv_count);
+  // running statistics: running = (1 - momentum) running + momentum batch; unbiased variance (nn.BatchNorm1d)
+  for (int l = 0; l < s.n_bn; ++l) {
+    const int W = s.width[l];
+    for (int c = threadIdx.x; c < W; c += kSBlock) {
+      const double inv_n = 1.0 / (double)s.n_rows;
+      const double mean = s.acc[l][c] * inv_n;
+      double var = s.acc[l][W + c] * inv_n - mean * mean;
+      var = var > 0.0 ? var : 0.0;
+      const double unbiased = s.n_rows > 1 ? var * (double)s.n_rows / (double)(s.n_rows - 1) : var;
+      s.rm[l][c] = (1.f - s.momentum) * s.rm[l][c] + s.momentum * (float)mean;
+      s.rv[l][c] = (1.f - s.momentum) * s.rv[l][c] + s.momentum * (float)unbiased;
+    }
+    if (threadIdx.x == 0 && s.tracked[l]) *s.tracked[l] += 1;
+  }
+  __syncthreads();
+  for (int64_t i = threadIdx.x; i < s.zero_doubles; i += kSBlock) s.zero_from[i] = 0.0;
+}
+
+}  // namespace gcmi
+
+// ================================================================================================ host side
+namespace gcmi {
+
+static inline int64_t up4s(int64_t n) { return (n + 3) / 4 * 4; }
+
+struct SmallWs {  // offsets in floats into the workspace
+  int64_t gc[kMaxL], pool[kMaxL], arg[kMaxL], dA[kMaxL];
+  int64_t dense, fp, logits, dlogits, g2, argrow, dpool, dS, dXs;
+  int64_t acc0;                 // start of the fp64 accumulator region
+  int64_t acc[kMaxL + 1];       // doubles, relative to acc0: [sum | sumsq] per BatchNorm layer
+  int64_t bsum, loss;           // doubles, relative to acc0
+  int64_t acc_doubles;
+  int64_t total;
+};
+
+static SmallWs small_carve(const gcmi_model_desc* m, int64_t N, int64_t B) {
+  SmallWs w;
+  memset(&w, 0, sizeof(w));
+  int64_t off = 0;
+  auto take = [&](int64_t n) {
+    int64_t o = off;
+    off += up4s(n);
+    return o;
+  };
+  const int L = m->n_layers;
+  int64_t wmax = 0;
+  for (int l = 0; l < L; ++l) {
+    const int64_t W = m->conv_width[l];
+    w.gc[l] = take(N * W);
+    w.pool[l] = take(N * W);
+    w.arg[l] = take((N * W + 3) / 4);
+    w.dA[l] = take(N * W);
+    if (W > wmax) wmax = W;
+  }
+  const int64_t F = m->dense_width, TC = (int64_t)m->n_tasks * m->n_classes;
+  w.dense = take(N * F);
+  w.fp = take(B * 2 * F);
+  w.logits = take(B * TC);
+  w.dlogits = take(B * TC);
+  w.g2 = take(B * 2 * F);
+  w.argrow = take(B * F);
+  w.dpool = take(N * wmax);
+  w.dS = take(N * wmax);
+  w.dXs = take(N * wmax);
+  off = (off + 3) / 4 * 4;
+  w.acc0 = off;
+  int64_t d = 0;
+  for (int l = 0; l < L; ++l) {
+    w.acc[l] = d;
+    d += 2 * m->conv_width[l];
+  }
+  w.acc[L] = d;
+  d += 2 * F;
+  w.bsum = d;
+  d += 2 * F;
+  w.loss = d;
+  d += 2;
+  w.acc_doubles = d;
+  off += 2 * d;
+  w.total = off;
+  return w;
+}
+
+static int small_check(const gcmi_model_desc* m) {
+  GCMI_CHECK_ARG(m != nullptr, "small: model desc is NULL");
+  GCMI_CHECK_ARG(m->n_layers >= 1 && m->n_layers <= kMaxL, "small: n_layers %d outside [1,%d]", m->n_layers, kMaxL);
+  GCMI_CHECK_ARG(m->max_deg >= 0 && m->max_deg <= GCMI_MAX_DEG, "small: bad max_deg");
+  GCMI_CHECK_ARG(m->n_feat_in > 0 && m->n_tasks > 0 && m->n_classes > 0, "small: bad widths");
+  GCMI_CHECK_ARG(m->mode == 0 || (m->mode == 1 && m->n_classes == 1), "small: bad mode / n_classes");
+  for (int l = 0; l < m->n_layers; ++l)
+    if (m->conv_width[l] <= 0 || m->conv_width[l] % 64 || m->conv_width[l] > 256) {
+      set_error("small: GraphConv width %d is not a multiple of 64 in [64, 256]", m->conv_width[l]);
+      return GCMI_ERR_UNSUPPORTED;
+    }
+  if (m->dense_width <= 0 || m->dense_width % 64 || m->dense_width > 256) {
+    set_error("small: dense width %d is not a multiple of 64 in [64, 256]", m->dense_width);
+    return GCMI_ERR_UNSUPPORTED;
+  }
+  return GCMI_OK;
+}
+
+static int make_small_graph(const gcmi_graph* g, bool need_rev, SmallGraph* out) {
+  int rc = check_graph(g, true);
+  if (rc) return rc;
+  GCMI_CHECK_ARG(g->n_mols > 1, "graph_gather requires batches larger than 1");
+  GCMI_CHECK_ARG(g->d_membership && g->d_mol_runs, "small: the graph lacks membership / mol_runs");
+  if (need_rev && g->n_edges > 0 && !g->d_rev_pos) {
+    set_error("small: the training step needs d_rev_pos (every bond listed from both ends)");
+    return GCMI_ERR_UNSUPPORTED;
+  }
+  SmallGraph s;
+  memset(&s, 0, sizeof(s));
+  s.n_atoms = g->n_atoms;
+  s.n_mols = g->n_mols;
+  s.max_deg = g->max_deg;
+  int t = 0;
+  for (int d = 0; d < GCMI_MAX_DEG + 2; ++d) {
+    const int dd = d < g->max_deg + 1 ? d : g->max_deg + 1;
+    s.deg_start[d] = g->deg_start[dd];
+    s.edge_start[d] = g->edge_start[dd];
+    s.tile_start[d] = t;
+    if (d <= g->max_deg) t += (g->deg_start[d + 1] - g->deg_start[d] + kTileRows - 1) / kTileRows;
+  }
+  s.n_tiles = t;
+  s.col_idx = g->d_col_idx;
+  s.membership = g->d_membership;
+  s.mol_runs = g->d_mol_runs;
+  s.rev_pos = g->d_rev_pos;
+  *out = s;
+  return GCMI_OK;
+}
+
+template <typename Kern>
+static int ensure_lds(Kern kern, size_t bytes) {
+  if (bytes > 64 * 1024) {
+    if (bytes > 160 * 1024) {
+      set_error("small: a tile needs %zu bytes of LDS (> 160 KB)", bytes);
+      return GCMI_ERR_UNSUPPORTED;
+    }
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes) != hipSuccess) {
+      set_error("small: hipFuncSetAttribute(max dynamic LDS = %zu) failed", bytes);
+      return GCMI_ERR_LAUNCH;
+    }
+  }
+  return GCMI_OK;
+}
+
+#define SRUN(call)          \
+  do {                      \
+    int rc__ = (call);      \
+    if (rc__) return rc__;  \
+  } while (0)
+
+struct SmallCtx {
+  const gcmi_model_desc* m;
+  const float* params;
+  const gcmi_model_io* io;
+  SmallWs w;
+  float* ws;
+  double* accs;
+  hipStream_t st;
+  bool training;
+};
+
+static BnArgs bn_args(const SmallCtx& c, int layer, int n_rows) {
+  BnArgs b;
+  memset(&b, 0, sizeof(b));
+  const gcmi_model_desc* m = c.m;
+  if (!m->batch_norm) return b;
+  b.mode = c.training ? 1 : 2;
+  b.acc = c.accs + c.w.acc[layer];
+  b.rm = c.io->d_bn_running_mean[layer];
+  b.rv = c.io->d_bn_running_var[layer];
+  b.gamma = c.params + m->off_bn_gamma[layer];
+  b.beta = c.params + m->off_bn_beta[layer];
+  b.eps = m->bn_eps;
+  b.n_rows = n_rows;
+  return b;
+}
+
+static int launch_conv_fwd(const SmallGraph& g, const float* x, int ldx, int K, const float* Wl, const float* bl,
+                           int W, float* out, double* acc, hipStream_t st) {
+  const int K4 = (K + 3) & ~3;
+  const size_t lds = sizeof(float) * 2 * kTileRows * pitch_a(K4);
+  const dim3 grid(g.n_tiles), block(kSBlock);
+  switch (W / 64) {
+    case 1: hipLaunchKernelGGL(small_conv_fwd_kernel<1>, grid, block, lds, st, g, x, ldx, K, Wl, bl, out, acc); break;
+    case 2: hipLaunchKernelGGL(small_conv_fwd_kernel<2>, grid, block, lds, st, g, x, ldx, K, Wl, bl, out, acc); break;
+    case 3: hipLaunchKernelGGL(small_conv_fwd_kernel<3>, grid, block, lds, st, g, x, ldx, K, Wl, bl, out, acc); break;
+    default: hipLaunchKernelGGL(small_conv_fwd_kernel<4>, grid, block, lds, st, g, x, ldx, K, Wl, bl, out, acc); break;
+  }
+  GCMI_CHECK_LAUNCH("small_conv_fwd");
+  return GCMI_OK;
+}
+
+// conv / pool stack + dense; leaves the dense output in the workspace
+static int small_forward_body(const SmallCtx& c, const SmallGraph& g, const float* x, int64_t ldx) {
+  const gcmi_model_desc* m = c.m;
+  const int L = m->n_layers;
+  const int N = g.n_atoms;
+  int K = m->n_feat_in;
+  if (g.n_tiles == 0) return GCMI_OK;
+  GCMI_CHECK_ARG(ldx % 4 == 0 && ldx >= ((K + 3) & ~3) && aligned16(x),
+                 "small: atom features must be 16-byte aligned rows (ld %lld for %d columns)", (long long)ldx, K);
+  for (int l = 0; l < L; ++l) {
+    const int W = m->conv_width[l];
+    double* acc = (m->batch_norm && c.training) ? c.accs + c.w.acc[l] : nullptr;
+    SRUN(launch_conv_fwd(g, x, (int)ldx, K, c.params + m->off_conv_w[l], c.params + m->off_conv_b[l], W,
+                         c.ws + c.w.gc[l], acc, c.st));
+    if (l < L - 1) {
+      hipLaunchKernelGGL(small_pool_fwd_kernel, dim3(g.n_tiles), dim3(kSBlock), sizeof(float) * 2 * W, c.st, g,
+                         c.ws + c.w.gc[l], W, bn_args(c, l, N), c.ws + c.w.pool[l],
+                         c.training ? reinterpret_cast<uint8_t*>(c.ws + c.w.arg[l]) : nullptr);
+      GCMI_CHECK_LAUNCH("small_pool_fwd");
+      x = c.ws + c.w.pool[l];
+      ldx = W;
+      K = W;
+    }
+  }
+  const int Wl = m->conv_width[L - 1], F = m->dense_width;
+  double* accD = (m->batch_norm && c.training) ? c.accs + c.w.acc[L] : nullptr;
+  const size_t lds = sizeof(float) * (2 * Wl + kTileRows * pitch_a(Wl));
+  uint8_t* arg = c.training ? reinterpret_cast<uint8_t*>(c.ws + c.w.arg[L - 1]) : nullptr;
+  const float* Wd = c.params + m->off_dense_w;
+  const float* bd = c.params + m->off_dense_b;
+  const dim3 grid(g.n_tiles), block(kSBlock);
+#define PD(NT)                                                                                                      \
+  hipLaunchKernelGGL(small_pool_dense_fwd_kernel<NT>, grid, block, lds, c.st, g, c.ws + c.w.gc[L - 1], Wl,           \
+                     bn_args(c, L - 1, N), c.ws + c.w.pool[L - 1], arg, Wd, bd, c.ws + c.w.dense, accD)
+  switch (F / 64) {
+    case 1: PD(1); break;
+    case 2: PD(2); break;
+    case 3: PD(3); break;
+    default: PD(4); break;
+  }
+#undef PD
+  GCMI_CHECK_LAUNCH("small_pool_dense_fwd");
+  return GCMI_OK;
+}
+
+static int launch_readout(const SmallCtx& c, const SmallGraph& g, ReadoutArgs& a) {
+  const gcmi_model_desc* m = c.m;
+  const int F = m->dense_width, TC = m->n_tasks * m->n_classes;
+  a.dense = c.ws + c.w.dense;
+  a.bn = bn_args(c, m->n_layers, g.n_atoms);
+  if (g.n_atoms == 0) a.bn.mode = 0;  // no rows: every molecule is empty, nothing is normalised
+  a.Wh = c.params + m->off_head_w;
+  a.bh = c.params + m->off_head_b;
+  a.F = F;
+  a.T = m->n_tasks;
+  a.C = m->n_classes;
+  a.mode = m->mode;
+  const size_t lds = sizeof(float) * 4 * (2 * F + 2 * TC);
+  const dim3 grid((g.n_mols + 3) / 4), block(kSBlock);
+  switch (F / 64) {
+    case 1:
+      SRUN(ensure_lds(small_readout_kernel<1>, lds));
+      hipLaunchKernelGGL(small_readout_kernel<1>, grid, block, lds, c.st, g, a);
+      break;
+    case 2:
+      SRUN(ensure_lds(small_readout_kernel<2>, lds));
+      hipLaunchKernelGGL(small_readout_kernel<2>, grid, block, lds, c.st, g, a);
+      break;
+    case 3:
+      SRUN(ensure_lds(small_readout_kernel<3>, lds));
+      hipLaunchKernelGGL(small_readout_kernel<3>, grid, block, lds, c.st, g, a);
+      break;
+    default:
+      SRUN(ensure_lds(small_readout_kernel<4>, lds));
+      hipLaunchKernelGGL(small_readout_kernel<4>, grid, block, lds, c.st, g, a);
+      break;
+  }
+  GCMI_CHECK_LAUNCH("small_readout");
+  return GCMI_OK;
+}
+
+static int small_backward(const SmallCtx& c, const SmallGraph& g, const gcmi_small_batch* b, float* grads) {
+  const gcmi_model_desc* m = c.m;
+  const int L = m->n_layers, N = g.n_atoms;
+  const int F = m->dense_width, TC = m->n_tasks * m->n_classes, Kd = m->conv_width[L - 1];
+  const bool full = m->grad_mode == 1;
+  const bool need_dpool = full || m->batch_norm;
+  DenseBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.dense = c.ws + c.w.dense;
+  a.pool = c.ws + c.w.pool[L - 1];
+  a.g2 = c.ws + c.w.g2;
+  a.argrow = reinterpret_cast<const int32_t*>(c.ws + c.w.argrow);
+  a.bn = bn_args(c, L, N);
+  a.bsum = c.accs + c.w.bsum;
+  a.Wd = c.params + m->off_dense_w;
+  a.dpool = need_dpool ? c.ws + c.w.dpool : nullptr;
+  a.dWd = grads + m->off_dense_w;
+  a.dbd = grads + m->off_dense_b;
+  a.dgamma = m->batch_norm ? grads + m->off_bn_gamma[L] : nullptr;
+  a.dbeta = m->batch_norm ? grads + m->off_bn_beta[L] : nullptr;
+  a.dlogits = c.ws + c.w.dlogits;
+  a.fp = c.ws + c.w.fp;
+  a.dWh = grads + m->off_head_w;
+  a.dbh = grads + m->off_head_b;
+  a.F = F;
+  a.K = Kd;
+  a.TC = TC;
+  a.n_slabs = (N + kSlabRows - 1) / kSlabRows;
+  a.n_head_blocks = (int)(((int64_t)TC * 2 * F + kSBlock - 1) / kSBlock);
+  SmallGraph gd = g;
+  if (!need_dpool) gd.n_tiles = 0;  // nothing in front of the dense layer trains: no dgrad tiles
+  {
+    const size_t lds_tile = sizeof(float) * (3 * F + kTileRows * pitch_a(F));
+    const size_t lds_slab = sizeof(float) * (3 * F + kSlabRows * (pitch_t(F) + pitch_t(Kd)));
+    const size_t lds = lds_tile > lds_slab ? lds_tile : lds_slab;
+    const dim3 grid(gd.n_tiles + a.n_slabs + a.n_head_blocks), block(kSBlock);
+    switch (Kd / 64) {
+      case 1:
+        SRUN(ensure_lds(small_dense_bwd_kernel<1>, lds));
+        hipLaunchKernelGGL(small_dense_bwd_kernel<1>, grid, block, lds, c.st, gd, a);
+        break;
+      case 2:
+        SRUN(ensure_lds(small_dense_bwd_kernel<2>, lds));
+        hipLaunchKernelGGL(small_dense_bwd_kernel<2>, grid, block, lds, c.st, gd, a);
+        break;
+      case 3:
+        SRUN(ensure_lds(small_dense_bwd_kernel<3>, lds));
+        hipLaunchKernelGGL(small_dense_bwd_kernel<3>, grid, block, lds, c.st, gd, a);
+        break;
+      default:
+        SRUN(ensure_lds(small_dense_bwd_kernel<4>, lds));
+        hipLaunchKernelGGL(small_dense_bwd_kernel<4>, grid, block, lds, c.st, gd, a);
+        break;
+    }
+    GCMI_CHECK_LAUNCH("small_dense_bwd");
+  }
+  if (!need_dpool || g.n_tiles == 0) return GCMI_OK;
+  const float* dpool = c.ws + c.w.dpool;
+  for (int l = L - 1; l >= 0; --l) {
+    const int W = m->conv_width[l];
+    const int K = l == 0 ? m->n_feat_in : m->conv_width[l - 1];
+    float* dA = full ? c.ws + c.w.dA[l] : nullptr;
+    hipLaunchKernelGGL(small_pool_bwd_kernel, dim3(g.n_tiles), dim3(kSBlock), sizeof(float) * (2 * W + kTileRows * 2 * W),
+                       c.st, g, dpool, reinterpret_cast<const uint8_t*>(c.ws + c.w.arg[l]), c.ws + c.w.gc[l], W,
+                       bn_args(c, l, N), dA, m->batch_norm ? grads + m->off_bn_gamma[l] : nullptr,
+                       m->batch_norm ? grads + m->off_bn_beta[l] : nullptr);
+    GCMI_CHECK_LAUNCH("small_pool_bwd");
+    if (!full) break;  // reference semantics: nothing in front of a GraphConv output trains
+    ConvBwdArgs cb;
+    memset(&cb, 0, sizeof(cb));
+    cb.dA = dA;
+    cb.gc = c.ws + c.w.gc[l];
+    cb.bn = bn_args(c, l, N);
+    cb.dgamma = m->batch_norm ? grads + m->off_bn_gamma[l] : nullptr;
+    cb.dbeta = m->batch_norm ? grads + m->off_bn_beta[l] : nullptr;
+    cb.x = l == 0 ? b->d_atom_features : c.ws + c.w.pool[l - 1];
+    cb.ldx = l == 0 ? (int)b->ld_features : m->conv_width[l - 1];
+    cb.K = K;
+    cb.W = W;
+    cb.Wl = c.params + m->off_conv_w[l];
+    cb.dWl = grads + m->off_conv_w[l];
+    cb.dbl = grads + m->off_conv_b[l];
+    cb.dS = l > 0 ? c.ws + c.w.dS : nullptr;
+    cb.dXs = l > 0 ? c.ws + c.w.dXs : nullptr;
+    int s = 0;
+    for (int d = 0; d < GCMI_MAX_DEG + 2; ++d) {
+      cb.slab_start[d] = s;
+      if (d <= g.max_deg) s += (g.deg_start[d + 1] - g.deg_start[d] + kSlabRows - 1) / kSlabRows;
+    }
+    cb.n_slabs = s;
+    const int K4 = (K + 3) & ~3;
+    const size_t lds_tile = sizeof(float) * (3 * W + kTileRows * pitch_a(W));
+    const size_t lds_slab = sizeof(float) * (3 * W + kSlabRows * (pitch_t(W) + 2 * pitch_t(K4)));
+    const size_t lds = lds_tile > lds_slab ? lds_tile : lds_slab;
+    SRUN(ensure_lds(small_conv_bwd_kernel, lds));
+    hipLaunchKernelGGL(small_conv_bwd_kernel, dim3((l > 0 ? g.n_tiles : 0) + cb.n_slabs), dim3(kSBlock), lds, c.st, g,
+                       cb);
+    GCMI_CHECK_LAUNCH("small_conv_bwd");
+    if (l == 0) break;
+    hipLaunchKernelGGL(small_gather_add_kernel, dim3(g.n_tiles), dim3(kSBlock), 0, c.st, g, c.ws + c.w.dXs,
+                       c.ws + c.w.dS, K4, c.ws + c.w.dpool);
+    GCMI_CHECK_LAUNCH("small_gather_add");
+    dpool = c.ws + c.w.dpool;
+  }
+  return GCMI_OK;
+}
+
+}  // namespace gcmi
+
+using namespace gcmi;
+
+extern "C" {
+
+int64_t gcmi_small_workspace_floats(const gcmi_model_desc* m, int64_t max_atoms, int64_t max_mols) {
+  if (small_check(m) != GCMI_OK || max_atoms < 0 || max_mols < 0) return -1;
+  return small_carve(m, max_atoms, max_mols).total;
+}
+
+int gcmi_small_fit(const gcmi_model_desc* m, float* d_params, float* d_grads, float* d_adam_m, float* d_adam_v,
+                   const gcmi_model_io* io, const gcmi_small_batch* batches, int64_t n_batches, int64_t ws_atoms,
+                   int64_t ws_mols, float lr, float beta1, float beta2, float eps, int64_t first_step,
+                   float* d_losses, int64_t* grad_lo, int64_t* grad_hi, void* stream) {
+  SRUN(small_check(m));
+  GCMI_CHECK_ARG(d_params && d_grads && d_adam_m && d_adam_v && io && io->d_workspace && (batches || n_batches == 0),
+                 "small_fit: NULL buffer");
+  GCMI_CHECK_ARG(n_batches >= 0 && first_step >= 1, "small_fit: bad n_batches / first_step");
+  const int L = m->n_layers;
+  const bool full = m->grad_mode == 1;
+  const int64_t lo = full ? 0 : (m->batch_norm ? m->off_bn_gamma[L - 1] : m->off_dense_w);
+  const int64_t hi = m->n_params;
+  GCMI_CHECK_ARG(lo % 4 == 0 && hi % 4 == 0 && lo < hi, "small_fit: parameter blocks must be 16-byte aligned");
+  if (grad_lo) *grad_lo = lo;
+  if (grad_hi) *grad_hi = hi;
+  if (n_batches == 0) return GCMI_OK;
+  SmallCtx c;
+  c.m = m;
+  c.params = d_params;
+  c.io = io;
+  c.w = small_carve(m, ws_atoms, ws_mols);
+  c.ws = io->d_workspace;
+  c.accs = reinterpret_cast<double*>(c.ws + c.w.acc0);
+  c.st = (hipStream_t)stream;
+  c.training = true;
+  if (m->batch_norm)
+    for (int l = 0; l <= L; ++l)
+      GCMI_CHECK_ARG(io->d_bn_running_mean[l] && io->d_bn_running_var[l], "small_fit: NULL running statistics");
+  // clean accumulators and a clean gradient range at entry; every step leaves them clean for the next
+  if (hipMemsetAsync(c.accs, 0, sizeof(double) * (size_t)c.w.acc_doubles, c.st) != hipSuccess ||
+      hipMemsetAsync(d_grads + lo, 0, sizeof(float) * (size_t)(hi - lo), c.st) != hipSuccess) {
+    set_error("small_fit: memset failed");
+    return GCMI_ERR_LAUNCH;
+  }
+  for (int64_t i = 0; i < n_batches; ++i) {
+    const gcmi_small_batch* b = batches + i;
+    GCMI_CHECK_ARG(b->graph.n_atoms <= ws_atoms && b->graph.n_mols <= ws_mols,
+                   "small_fit: batch %lld (%d atoms, %d molecules) exceeds the workspace (%lld, %lld)", (long long)i,
+                   b->graph.n_atoms, b->graph.n_mols, (long long)ws_atoms, (long long)ws_mols);
+    GCMI_CHECK_ARG(b->d_labels && b->n_rows > 0 && b->n_rows <= b->graph.n_mols, "small_fit: batch %lld: bad labels / n_rows",
+                   (long long)i);
+    GCMI_CHECK_ARG(b->graph.n_atoms == 0 || b->d_atom_features, "small_fit: NULL atom features");
+    GCMI_CHECK_ARG(b->graph.max_deg == m->max_deg, "small_fit: graph max_deg %d != model max_deg %d", b->graph.max_deg,
+                   m->max_deg);
+    SmallGraph g;
+    SRUN(make_small_graph(&b->graph, true, &g));
+    SRUN(small_forward_body(c, g, b->d_atom_features, b->ld_features));
+    ReadoutArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    ra.fp = c.ws + c.w.fp;
+    ra.logits = c.ws + c.w.logits;
+    ra.probs = nullptr;
+    ra.labels = b->d_labels;
+    ra.weights = b->d_weights;
+    ra.n_rows = (int)b->n_rows;
+    ra.inv_count = 1.f / (float)(b->n_rows * m->n_tasks);
+    ra.dlogits = c.ws + c.w.dlogits;
+    ra.g2 = c.ws + c.w.g2;
+    ra.argrow = reinterpret_cast<int32_t*>(c.ws + c.w.argrow);
+    ra.loss_acc = c.accs + c.w.loss;
+    ra.bsum = m->batch_norm ? c.accs + c.w.bsum : nullptr;
+    SRUN(launch_readout(c, g, ra));
+    SRUN(small_backward(c, g, b, d_grads));
+    // Adam over the trained range, loss, running statistics, counters, zeroing
+    StepEnd se;
+    memset(&se, 0, sizeof(se));
+    const int64_t step = first_step + i;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    se.p = d_params;
+    se.grad = d_grads;
+    se.m = d_adam_m;
+    se.v = d_adam_v;
+    se.lo = lo;
+    se.hi = hi;
+    se.one_minus_b1 = 1.f - beta1;
+    se.b2 = beta2;
+    se.one_minus_b2 = 1.f - beta2;
+    se.step_size = (float)((double)lr / bc1);
+    se.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    se.eps = eps;
+    se.loss_acc = c.accs + c.w.loss;
+    se.loss_out = d_losses ? d_losses + i : nullptr;
+    se.inv_count = ra.inv_count;
+    se.n_bn = (m->batch_norm && g.n_atoms > 0) ? L + 1 : 0;
+    se.n_rows = g.n_atoms;
+    se.momentum = m->bn_momentum;
+    for (int l = 0; l <= L; ++l) {
+      se.acc[l] = c.accs + c.w.acc[l];
+      se.width[l] = l < L ? m->conv_width[l] : m->dense_width;
+      se.rm[l] = io->d_bn_running_mean[l];
+      se.rv[l] = io->d_bn_running_var[l];
+      se.tracked[l] = io->d_bn_batches_tracked[l];
+    }
+    se.zero_from = c.accs;
+    se.zero_doubles = c.w.acc_doubles;
+    const int64_t n4 = (hi - lo) / 4;
+    int blocks = (int)((n4 + kSBlock - 1) / kSBlock);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(small_step_end_kernel, dim3(blocks), dim3(kSBlock), 0, c.st, se);
+    GCMI_CHECK_LAUNCH("small_step_end");
+  }
+  return GCMI_OK;
+}
+
+int gcmi_small_predict(const gcmi_model_desc* m, const float* d_params, const gcmi_model_io* io,
+                       const gcmi_small_batch* batches, int64_t n_batches, int64_t ws_atoms, int64_t ws_mols,
+                       void* stream) {
+  SRUN(small_check(m));
+  GCMI_CHECK_ARG(d_params && io && io->d_workspace && (batches || n_batches == 0), "small_predict: NULL buffer");
+  SmallCtx c;
+  c.m = m;
+  c.params = d_params;
+  c.io = io;
+  c.w = small_carve(m, ws_atoms, ws_mols);
+  c.ws = io->d_workspace;
+  c.accs = reinterpret_cast<double*>(c.ws + c.w.acc0);
+  c.st = (hipStream_t)stream;
+  c.training = false;
+  if (m->batch_norm)
+    for (int l = 0; l <= m->n_layers; ++l)
+      GCMI_CHECK_ARG(io->d_bn_running_mean[l] && io->d_bn_running_var[l], "small_predict: NULL running statistics");
+  for (int64_t i = 0; i < n_batches; ++i) {
+    const gcmi_small_batch* b = batches + i;
+    GCMI_CHECK_ARG(b->graph.n_atoms <= ws_atoms && b->graph.n_mols <= ws_mols,
+                   "small_predict: batch %lld exceeds the workspace", (long long)i);
+    GCMI_CHECK_ARG(b->d_logits && b->d_fingerprint, "small_predict: NULL output");
+    GCMI_CHECK_ARG(b->graph.n_atoms == 0 || b->d_atom_features, "small_predict: NULL atom features");
+    GCMI_CHECK_ARG(b->graph.max_deg == m->max_deg, "small_predict: graph max_deg != model max_deg");
+    SmallGraph g;
+    SRUN(make_small_graph(&b->graph, false, &g));
+    SRUN(small_forward_body(c, g, b->d_atom_features, b->ld_features));
+    ReadoutArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    ra.fp = b->d_fingerprint;
+    ra.logits = b->d_logits;
+    ra.probs = m->mode == 0 ? b->d_probs : nullptr;
+    SRUN(launch_readout(c, g, ra));
+  }
+  return GCMI_OK;
+}
+
+}  // extern "C"

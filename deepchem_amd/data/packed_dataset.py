@@ -66,6 +66,13 @@ class PackedDataset(Dataset):
     def ids(self):
         return self._ids
 
+    def get_task_names(self):
+        """Task indices, as NumpyDataset names them (data/datasets.py:793-797)."""
+        return np.array([0]) if self._y.ndim < 2 else np.arange(self._y.shape[1])
+
+    def get_shape(self):
+        return (len(self),), self._y.shape, self._w.shape, self._ids.shape
+
     def iter_index_batches(self, batch_size: int, epochs: int = 1, deterministic: bool = False,
                            pad_batches: bool = False) -> Iterator[Tuple[np.ndarray, int]]:
         """(molecule indices, number of real molecules) per batch; with ``pad_batches`` the

@@ -1,0 +1,125 @@
+"""SmallBatchEngine: many optimizer steps (or prediction batches) per C call.
+
+At the batch sizes the reference actually trains with (100 molecules by default,
+graphconvmodel.py:292; 64 in MolNet's presets) a step moves ~2 000 atom rows: the large-batch kernels
+leave the GPU almost empty and the Python loop of ``fit_generator`` (torch_model.py:423-445) costs more
+than the arithmetic.  ``gcmi_small_fit`` / ``gcmi_small_predict`` (include/gcmi.h, csrc/smallstep.hip)
+run the whole step -- forward, loss, backward, Adam, BatchNorm running statistics -- as 8-12 launches
+on 16-row degree tiles, for a whole list of collated batches per call.  This class owns the host side:
+the descriptor array, the workspace, and the hand-over of the optimizer state (the flat moment buffers
+of ``GcmiAdam``, so a checkpoint taken afterwards is indistinguishable from one written by the
+per-batch path).
+"""
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from deepchem_amd import _lib
+from deepchem_amd._lib import GcmiModelIO, GcmiSmallBatch
+from deepchem_amd.graph import _stream
+
+# batches up to this many atoms run on the small engine (beyond, the streaming kernels win)
+SMALL_MAX_ATOMS = 16384
+
+
+class SmallUnsupported(Exception):
+    pass
+
+
+class SmallBatchEngine:
+
+    def __init__(self, native):
+        """``native``: the model's ``deepchem_amd.native.NativeNet`` (flat parameter arena + description)."""
+        self.native = native
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_shape = (0, 0)
+        lib = _lib.load()
+        if lib.gcmi_small_workspace_floats(ctypes.byref(native.desc), 1, 2) < 0:
+            raise SmallUnsupported(lib.gcmi_last_error().decode())
+
+    # ------------------------------------------------------------------ buffers
+    def _workspace(self, max_atoms: int, max_mols: int) -> Tuple[torch.Tensor, int, int]:
+        a, b = self._ws_shape
+        if self._ws is None or max_atoms > a or max_mols > b or self._ws.device != self.native.flat.device:
+            a = max(int(max_atoms * 1.25) + 64, a)
+            b = max(int(max_mols * 1.25) + 2, b)
+            need = int(_lib.load().gcmi_small_workspace_floats(ctypes.byref(self.native.desc), a, b))
+            if need < 0:
+                raise SmallUnsupported("gcmi_small_workspace_floats rejected the model description")
+            self._ws = torch.empty(need + 16, dtype=torch.float32, device=self.native.flat.device)
+            self._ws_shape = (a, b)
+        return self._ws, self._ws_shape[0], self._ws_shape[1]
+
+    def _io(self, ws: torch.Tensor) -> GcmiModelIO:
+        io = GcmiModelIO()
+        io.d_workspace = ws.data_ptr()
+        d = self.native.desc
+        if d.batch_norm:
+            for i in range(self.native.n_layers + 1):
+                bn = self.native.module.batch_norms[i]
+                io.d_bn_running_mean[i] = bn.running_mean.data_ptr()
+                io.d_bn_running_var[i] = bn.running_var.data_ptr()
+                io.d_bn_batches_tracked[i] = bn.num_batches_tracked.data_ptr()
+        return io
+
+    @staticmethod
+    def describe(batch, labels=None, weights=None, n_rows: Optional[int] = None) -> GcmiSmallBatch:
+        """A ``DeviceBatch`` (+ device labels / weights) as the struct the C side reads."""
+        g = batch.graph
+        if g.mol_runs is None:
+            raise ValueError("the batch has no readout plan (set_mols)")
+        sb = GcmiSmallBatch()
+        ctypes.memmove(ctypes.byref(sb.graph), ctypes.byref(g.c), ctypes.sizeof(g.c))
+        x = batch.atom_features
+        sb.d_atom_features = x.data_ptr() if x.numel() else None
+        sb.ld_features = int(x.stride(0)) if x.shape[0] > 1 else int(x.shape[1])
+        sb.d_labels = labels.data_ptr() if labels is not None else None
+        sb.d_weights = weights.data_ptr() if weights is not None else None
+        sb.n_rows = int(batch.n_samples if n_rows is None else n_rows)
+        return sb
+
+    # ------------------------------------------------------------------ calls
+    def fit(self, descs: Sequence[GcmiSmallBatch], optimizer, max_atoms: int, max_mols: int) -> torch.Tensor:
+        """One Adam step per descriptor, in order.  Returns the per-step losses (device, float32)."""
+        nat = self.native
+        n = len(descs)
+        losses = torch.empty(n, dtype=torch.float32, device=nat.flat.device)
+        if n == 0:
+            return losses
+        if optimizer._flat is None or optimizer._flat["p"].data_ptr() != nat.flat.data_ptr():
+            optimizer.attach_flat(nat.flat, nat.grad_flat, nat._slices)
+        d = nat.desc
+        L = nat.n_layers
+        lo = 0 if d.grad_mode == 1 else (d.off_bn_gamma[L - 1] if d.batch_norm else d.off_dense_w)
+        hi = d.n_params
+        f = optimizer._flat
+        if f.get("range") != (lo, hi):
+            optimizer._setup_flat_range(lo, hi)
+        group = optimizer.param_groups[0]
+        beta1, beta2 = group["betas"]
+        first_step = int(f["step_t"].item()) + 1
+        arr = (GcmiSmallBatch * n)(*descs)
+        ws, a, b = self._workspace(max_atoms, max_mols)
+        io = self._io(ws)
+        glo, ghi = ctypes.c_int64(0), ctypes.c_int64(0)
+        _lib.call("gcmi_small_fit", ctypes.byref(d), ctypes.c_void_p(nat.flat.data_ptr()),
+                  ctypes.c_void_p(nat.grad_flat.data_ptr()), ctypes.c_void_p(f["m"].data_ptr()),
+                  ctypes.c_void_p(f["v"].data_ptr()), ctypes.byref(io), ctypes.cast(arr, ctypes.c_void_p), n, a, b,
+                  float(group["lr"]), float(beta1), float(beta2), float(group["eps"]), first_step,
+                  ctypes.c_void_p(losses.data_ptr()), ctypes.byref(glo), ctypes.byref(ghi), _stream())
+        assert (glo.value, ghi.value) == (lo, hi)
+        f["step_t"] += n
+        nat.grad_range = (lo, hi)
+        return losses
+
+    def predict(self, descs: Sequence[GcmiSmallBatch], max_atoms: int, max_mols: int) -> None:
+        """Eval-mode forward of every descriptor into the output pointers it names."""
+        n = len(descs)
+        if n == 0:
+            return
+        arr = (GcmiSmallBatch * n)(*descs)
+        ws, a, b = self._workspace(max_atoms, max_mols)
+        io = self._io(ws)
+        _lib.call("gcmi_small_predict", ctypes.byref(self.native.desc), ctypes.c_void_p(self.native.flat.data_ptr()),
+                  ctypes.byref(io), ctypes.cast(arr, ctypes.c_void_p), n, a, b, _stream())

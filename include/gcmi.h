@@ -489,6 +489,47 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
                              const float* d_weights, int64_t n_rows, int64_t* grad_lo,
                              int64_t* grad_hi, void* stream);
 
+/* ---------------------------------------------------------------- small-batch engine
+ * The same model step for batches whose activations live in L2 (the reference's default batch of 100
+ * molecules, MolNet's 64: graphconvmodel.py:292, molnet/preset_hyper_parameters.py:49-56), over MANY batches
+ * per call: the loop of TorchModel.fit_generator (torch_model.py:423-445) -- forward, loss, backward, Adam,
+ * running statistics -- runs inside the library, 8 launches per step in reference gradient mode and 12 in
+ * full mode, on 16-row degree tiles (csrc/smallstep.hip).  Same arithmetic contract as gcmi_model_*: fp32
+ * operands and accumulation on v_mfma_f32_16x16x4_f32, BatchNorm statistics in fp64.
+ *
+ * gcmi_small_batch: one collated batch; every pointer is device memory.  graph needs d_col_idx, d_membership,
+ *   d_mol_runs, and for gcmi_small_fit d_rev_pos (GCMI_ERR_UNSUPPORTED without: use gcmi_model_*).  Atom
+ *   feature rows must be 16-byte aligned (ld_features % 4 == 0, >= n_feat_in rounded up to 4; pad columns 0).
+ * gcmi_small_fit: for i in [0, n_batches): one optimizer step on batches[i] (labels (B, T, C) one-hot for
+ *   classification / (B, T) for regression; weights (B, T) or NULL; loss over the first n_rows molecules,
+ *   _StandardLoss, torch_model.py:1275-1294); Adam step number first_step + i (1-based; torch.optim.Adam as
+ *   optimizers.py:231-241 configures it) on the trained range [*grad_lo, *grad_hi) of the flat arenas;
+ *   d_losses[i] = that step's loss; BatchNorm running statistics and counters updated per step.
+ *   d_grads: scratch arena of n_params floats (left zero on the trained range).  The workspace
+ *   (io->d_workspace) holds gcmi_small_workspace_floats(m, ws_atoms, ws_mols) floats; every batch must fit.
+ * gcmi_small_predict: eval-mode forward of every batch into its d_logits (B x T*C), d_probs (classification;
+ *   may be NULL) and d_fingerprint (B x 2*dense_width).
+ * Widths: GraphConv and dense widths multiples of 64 up to 256 (else GCMI_ERR_UNSUPPORTED).              */
+typedef struct gcmi_small_batch {
+  gcmi_graph graph;
+  const float* d_atom_features;
+  int64_t ld_features;
+  const float* d_labels;
+  const float* d_weights;
+  int64_t n_rows;
+  float* d_logits;
+  float* d_probs;
+  float* d_fingerprint;
+} gcmi_small_batch;
+int64_t gcmi_small_workspace_floats(const gcmi_model_desc* m, int64_t max_atoms, int64_t max_mols);
+int gcmi_small_fit(const gcmi_model_desc* m, float* d_params, float* d_grads, float* d_adam_m, float* d_adam_v,
+                   const gcmi_model_io* io, const gcmi_small_batch* batches, int64_t n_batches, int64_t ws_atoms,
+                   int64_t ws_mols, float lr, float beta1, float beta2, float eps, int64_t first_step,
+                   float* d_losses, int64_t* grad_lo, int64_t* grad_hi, void* stream);
+int gcmi_small_predict(const gcmi_model_desc* m, const float* d_params, const gcmi_model_io* io,
+                       const gcmi_small_batch* batches, int64_t n_batches, int64_t ws_atoms, int64_t ws_mols,
+                       void* stream);
+
 /* ---------------------------------------------------------------- measurement
  * Optional per-kernel timing with hipEvents recorded on `stream` around the
  * launches of one kernel family (bench.py roofline).  id: see GCMI_K_*.       */

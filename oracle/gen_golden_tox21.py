@@ -21,7 +21,8 @@ The data file ``tests/golden/tox21.csv.gz`` is a byte copy of the reference tree
 
 Written: for every run (batch 64 preset; batch 100 = the reference's default batch, lr 1e-3, 10
 epochs) the reference's valid-split probabilities after training, its per-task ROC-AUC on train and
-valid, the mean loss fit() returned, and its wall time on this container's cores.
+valid, the mean loss fit() returned, every per-step loss, the parameters and buffers that training
+changed, and its wall time on this container's cores.
 """
 import os
 import sys
@@ -92,9 +93,19 @@ def main():
                                learning_rate=lr)
         model.model.load_state_dict({k: v.clone() for k, v in state.items()}, strict=True)
         np.random.seed(seed)
+        step_losses = []
         t0 = time.time()
-        loss = model.fit(train, nb_epoch=epochs, checkpoint_interval=0)
+        loss = model.fit(train, nb_epoch=epochs, checkpoint_interval=0,
+                         callbacks=[lambda m, s, iteration_loss=None: step_losses.append(float(iteration_loss))])
         wall = time.time() - t0
+        # what training changed (dense layer, head, BatchNorm 1..2 and every running statistic; the GraphConv
+        # weights and BatchNorm 0's affine pair never train in the reference): the test loads these over
+        # init_state(123) to get the reference's trained model
+        for k, v in model.model.state_dict().items():
+            v = v.numpy()
+            if not np.array_equal(v, state[k].numpy()):
+                out["%s_trained__%s" % (name, k)] = v
+        out[name + "_step_losses"] = np.array(step_losses, np.float64)
         pv = np.asarray(model.predict(valid))
         pt = np.asarray(model.predict(train))
         auc_v = roc_auc_per_task(valid.y, pv, valid.w)
