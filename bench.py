@@ -203,6 +203,72 @@ def launch_ranks(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+TOX21_TASKS = ['NR-AR', 'NR-AR-LBD', 'NR-AhR', 'NR-Aromatase', 'NR-ER', 'NR-ER-LBD', 'NR-PPAR-gamma', 'SR-ARE',
+               'SR-ATAD5', 'SR-HSE', 'SR-MMP', 'SR-p53']
+
+
+def tox21_real(device, epochs=3):
+    """BASELINE.json config 2 on the real file (tests/golden/tox21.csv.gz, a copy of the reference tree's
+    datasets/tox21.csv.gz): MolNet recipe -- native featurizer, index split 80/10/10, BalancingTransformer -- and
+    fit() / predict() timed end to end (shuffle, collation, H2D, every optimizer step) at MolNet's preset batch 64
+    (molnet/preset_hyper_parameters.py:49-56) and the reference's default batch 100 (graphconvmodel.py:292)."""
+    import deepchem_amd as dc
+    from deepchem_amd.data.data_loader import convert_df_to_numpy, load_csv_files
+    path = os.path.join(ROOT, "tests", "golden", "tox21.csv.gz")
+    if not os.path.exists(path):
+        return None
+    t0 = time.perf_counter()
+    df = next(iter(load_csv_files([path], shard_size=8192)))
+    packed, keep = dc.feat.ConvMolFeaturizer().featurize_packed(df["smiles"].tolist())
+    y, w = convert_df_to_numpy(df, TOX21_TASKS)
+    y, w = y[keep], w[keep]
+    featurize_s = time.perf_counter() - t0
+    n = packed.n_mols
+    a, b = int(0.8 * n), int(0.9 * n)
+    train = dc.data.PackedDataset(packed.select(np.arange(a)), y[:a], w[:a])
+    _, _, w_bal, _ = dc.trans.BalancingTransformer(dataset=train).transform_array(None, train.y, train.w, None)
+    train = dc.data.PackedDataset(train.packed, train.y, w_bal)
+    valid = dc.data.PackedDataset(packed.select(np.arange(a, b)), y[a:b], w[a:b])
+    rec = {"molecules": n, "atoms": packed.n_atoms, "train_molecules": a, "load_and_featurize_s": round(featurize_s, 3),
+           "timed_epochs": epochs}
+    for B, lr in ((64, 5e-4), (100, 1e-3)):
+        for gm in ("reference", "full"):
+            for engine in (True, False):
+                if not engine and gm == "full":
+                    continue
+                model = dc.models.torch_models.GraphConvModel(12, number_input_features=[75, 64], batch_size=B,
+                                                              learning_rate=lr, grad_mode=gm, device=device,
+                                                              log_frequency=10**9)
+                model.small_batch_engine = engine
+                np.random.seed(123)
+                model.fit(train, nb_epoch=1, checkpoint_interval=0)  # warm-up: label upload, workspace, first launches
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                model.fit(train, nb_epoch=epochs, checkpoint_interval=0)
+                torch.cuda.synchronize()
+                wall = time.perf_counter() - t1
+                key = "fit_molecules_per_s_batch_%d_%s%s" % (B, gm, "" if engine else "_per_batch_path")
+                rec[key] = round(epochs * a / wall, 1)
+                if gm == "reference":
+                    model.predict(valid)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(5):
+                        model.predict(valid)
+                    rec["predict_molecules_per_s_batch_%d%s" % (B, "" if engine else "_per_batch_path")] = round(
+                        5 * len(valid) / (time.perf_counter() - t1), 1)
+    # the whole MolNet preset (40 epochs at batch 64), wall time next to examples/stable_results.csv:5 (165.2 s)
+    model = dc.models.torch_models.GraphConvModel(12, number_input_features=[75, 64], batch_size=64, learning_rate=5e-4,
+                                                  device=device, log_frequency=10**9)
+    np.random.seed(123)
+    t1 = time.perf_counter()
+    model.fit(train, nb_epoch=40, checkpoint_interval=0)
+    torch.cuda.synchronize()
+    rec["molnet_preset_40_epochs_wall_s"] = round(time.perf_counter() - t1, 3)
+    rec["reference_published_wall_s"] = 165.2
+    return rec
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -408,6 +474,10 @@ def main():
         out["config"]["fit_molecules_per_s_batch_%d_atom_codes" % args.batch] = round(
             fit_epochs * big.n_mols / (time.perf_counter() - t1), 1)
 
+    if rank == 0 and world == 1 and args.fit_pipeline:
+        real = tox21_real(device)
+        if real is not None:
+            out["config"]["tox21_real"] = real
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
     elif rank == 0:

@@ -166,6 +166,10 @@ _SIGNATURES = {
     "gcmi_lstm_cell": [_P, c_int64, c_int32, c_int64, _P, c_int64, _P, c_int64, _P],
     "gcmi_model_forward": [_MD, _G, _P, _MIO, c_int32, _P],
     "gcmi_model_loss_backward": [_MD, _G, _P, _P, _MIO, _P, _P, c_int64, _I64P, _I64P, _P],
+    "gcmi_collate_batches": [_P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int32, c_int64, c_int64, _P, _P, _P, _P, _P,
+                             c_int32],
+    "gcmi_small_bind": [_P, _P, _P, _P, c_int64, _P, _P, c_int64, c_int64, _P, _P, c_int64, _P, c_int64, _P, _P,
+                        c_int64, _P, c_int64],
     "gcmi_small_fit": [_MD, _P, _P, _P, _P, _MIO, _P, c_int64, c_int64, c_int64, c_float, c_float, c_float, c_float,
                        c_int64, _P, _I64P, _I64P, _P],
     "gcmi_small_predict": [_MD, _P, _MIO, _P, c_int64, c_int64, c_int64, _P],
@@ -180,7 +184,7 @@ _SIGNATURES = {
 }
 
 EXPORTS = ["gcmi_version", "gcmi_last_error", "gcmi_model_workspace_floats", "gcmi_small_workspace_floats",
-           "gcmi_smiles_check", "gcmi_collate_plan_words"] + sorted(_SIGNATURES)
+           "gcmi_smiles_check", "gcmi_collate_plan_words", "gcmi_collate_batches_layout"] + sorted(_SIGNATURES)
 
 _lib = None
 
@@ -215,6 +219,8 @@ def load():
     lib.gcmi_last_error.restype = c_char_p
     lib.gcmi_model_workspace_floats.restype = c_int64
     lib.gcmi_model_workspace_floats.argtypes = [_MD, c_int64, c_int64]
+    lib.gcmi_collate_batches_layout.restype = c_int64
+    lib.gcmi_collate_batches_layout.argtypes = [_P, _P, _P, _P, c_int64, c_int64, c_int32, c_int64, _P, _P]
     lib.gcmi_small_workspace_floats.restype = c_int64
     lib.gcmi_small_workspace_floats.argtypes = [_MD, c_int64, c_int64]
     lib.gcmi_smiles_check.restype = c_char_p

@@ -13,6 +13,7 @@
 // The result is identical for any thread count.
 #include <algorithm>
 #include <cstdlib>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -808,6 +809,154 @@ int gcmi_collate_rows_host(const void* features, int64_t n_feat, const int64_t* 
   for (int32_t i = 0; i < A.n_atoms; ++i) collate_atom(A, i);
   if (mol_runs)
     for (int64_t k = 0; k < (int64_t)A.n_sel * A.n_deg; ++k) collate_run(A, (int32_t)k);
+  return GCMI_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------- many batches per call
+// The host side of the small-batch engine (gcmi_small_fit / gcmi_small_predict): all batches of a chunk of an
+// epoch collated in ONE call into ONE arena (one H2D copy), worker threads taking whole batches.  Per batch the
+// output is exactly what gcmi_collate_plans writes (without LDS windows).
+namespace {
+inline int64_t up4w(int64_t n) { return (n + 3) / 4 * 4; }
+}  // namespace
+
+extern "C" {
+
+int64_t gcmi_collate_batches_layout(const int64_t* atom_ptr, const int64_t* adj_ptr, const int64_t* sel,
+                                    const int64_t* batch_ptr, int64_t n_batches, int64_t ld, int32_t max_deg,
+                                    int64_t mols_out, int64_t* out_parts, int64_t* out_counts) {
+  if (!(atom_ptr && adj_ptr && batch_ptr && out_parts && out_counts && (sel || n_batches == 0))) {
+    gcmi::set_error("collate_batches_layout: NULL argument");
+    return GCMI_ERR_ARG;
+  }
+  if (n_batches < 0 || ld <= 0 || max_deg < 0 || max_deg > GCMI_MAX_DEG) {
+    gcmi::set_error("collate_batches_layout: bad n_batches / ld / max_deg");
+    return GCMI_ERR_ARG;
+  }
+  const int n_deg = max_deg + 1;
+  // feature rows of all batches first, batch after batch (every batch padded to an even number of rows so that
+  // 8-byte code rows keep 16-byte alignment): ONE contiguous row array, so atom codes expand in one launch
+  int64_t rows = 0;
+  for (int64_t b = 0; b < n_batches; ++b) {
+    int64_t na = 0, ne = 0;
+    const int64_t n_sel = batch_ptr[b + 1] - batch_ptr[b];
+    if (n_sel < 0 || (mols_out > 0 && n_sel > mols_out)) {
+      gcmi::set_error("collate_batches_layout: batch %lld has %lld molecules (mols_out %lld)", (long long)b,
+                      (long long)n_sel, (long long)mols_out);
+      return GCMI_ERR_ARG;
+    }
+    const int rc = gcmi_collate_sizes(atom_ptr, adj_ptr, sel + batch_ptr[b], n_sel, &na, &ne);
+    if (rc != GCMI_OK) return rc;
+    out_counts[3 * b] = na;
+    out_counts[3 * b + 1] = ne;
+    out_counts[3 * b + 2] = rows;  // first feature row of the batch in the chunk-wide row array
+    rows += (na + 1) / 2 * 2;
+  }
+  int64_t off = up4w(rows * ld);
+  for (int64_t b = 0; b < n_batches; ++b) {
+    const int64_t na = out_counts[3 * b], ne = out_counts[3 * b + 1];
+    const int64_t n_sel = batch_ptr[b + 1] - batch_ptr[b];
+    const int64_t n_out = mols_out > 0 ? mols_out : n_sel;
+    int64_t* p = out_parts + 5 * b;
+    p[0] = out_counts[3 * b + 2] * ld;  // features
+    p[1] = off;                         // membership
+    off += up4w(na);
+    p[2] = off;  // col_idx
+    off += up4w(ne);
+    p[3] = off;  // mol_runs (n_out molecules)
+    off += up4w(n_out * n_deg * 2);
+    p[4] = off;  // rev_pos (bytes)
+    off += up4w((ne + 3) / 4);
+  }
+  return off > 4 ? off : 4;
+}
+
+int gcmi_collate_batches(const float* atom_features, int64_t n_feat, const int64_t* atom_ptr, const int64_t* adj_ptr,
+                         const int32_t* adj_idx, const int64_t* sel, const int64_t* batch_ptr, int64_t n_batches,
+                         int32_t max_deg, int64_t ld, int64_t mols_out, float* arena, const int64_t* parts,
+                         const int64_t* counts, gcmi_graph* graphs, int32_t* out_symmetric, int32_t n_threads) {
+  GCMI_CHECK_ARG(atom_features && atom_ptr && adj_ptr && batch_ptr && arena && parts && counts && graphs &&
+                     (sel || n_batches == 0),
+                 "collate_batches: NULL argument");
+  GCMI_CHECK_ARG(n_batches >= 0 && ld >= n_feat && n_feat > 0, "collate_batches: bad n_batches / ld");
+  const int n_deg = max_deg + 1;
+  const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+  int nt = n_threads > 0 ? n_threads : 16;
+  nt = std::max(1, std::min(std::min(nt, hw), (int)std::min<int64_t>(n_batches, 64)));
+  std::vector<int> status((size_t)nt, GCMI_OK);
+  std::vector<std::string> messages((size_t)nt);
+  int32_t* i32 = reinterpret_cast<int32_t*>(arena);
+  auto work = [&](int t) {
+    for (int64_t b = t; b < n_batches; b += nt) {
+      const int64_t n_sel = batch_ptr[b + 1] - batch_ptr[b];
+      const int64_t n_out = mols_out > 0 ? mols_out : n_sel;
+      const int64_t* p = parts + 5 * b;
+      int32_t sym = 1;
+      int32_t* runs = i32 + p[3];
+      const int rc = gcmi_collate_plans(atom_features, n_feat, atom_ptr, adj_ptr, adj_idx, sel + batch_ptr[b], n_sel,
+                                        max_deg, arena + p[0], ld, counts[3 * b], i32 + p[1], i32 + p[2],
+                                        counts[3 * b + 1], runs, reinterpret_cast<uint8_t*>(i32 + p[4]), &sym, 0,
+                                        nullptr, nullptr, graphs + b);
+      if (rc != GCMI_OK) {
+        status[(size_t)t] = rc;
+        messages[(size_t)t] = gcmi_last_error();
+        return;
+      }
+      // GraphGather emits mols_out rows whatever the batch holds (layers.py:6469-6479): the molecules beyond the
+      // selection are empty
+      for (int64_t k = n_sel * n_deg * 2; k < n_out * n_deg * 2; ++k) runs[k] = 0;
+      graphs[b].n_mols = (int32_t)n_out;
+      if (out_symmetric) out_symmetric[b] = sym;
+    }
+  };
+  if (nt == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back(work, t);
+    for (auto& x : th) x.join();
+  }
+  for (int t = 0; t < nt; ++t)
+    if (status[(size_t)t] != GCMI_OK) {
+      gcmi::set_error("collate_batches: %s", messages[(size_t)t].c_str());
+      return status[(size_t)t];
+    }
+  return GCMI_OK;
+}
+
+/* Fill the descriptor array gcmi_small_fit / gcmi_small_predict read from what gcmi_collate_batches produced, once
+ * the arena is on the device: d_arena = device copy of the arena; d_features = the chunk-wide feature row array
+ * (the arena itself for float rows, or the rows expanded from atom codes), feature_ld its leading dimension.
+ * Labels / weights (may be NULL): chunk-wide arrays with one row of label_stride / weight_stride floats per
+ * molecule SLOT (mols_out slots per batch); outputs likewise (predict). */
+int gcmi_small_bind(gcmi_small_batch* out, const gcmi_graph* graphs, const int64_t* parts, const int64_t* counts,
+                    int64_t n_batches, const float* d_arena, const float* d_features, int64_t feature_ld,
+                    int64_t mols_out, const int64_t* n_rows, const float* d_labels, int64_t label_stride,
+                    const float* d_weights, int64_t weight_stride, float* d_logits, float* d_probs,
+                    int64_t logit_stride, float* d_fingerprint, int64_t fp_stride) {
+  GCMI_CHECK_ARG(out && graphs && parts && counts && d_arena && d_features && n_rows, "small_bind: NULL argument");
+  const int32_t* i32 = reinterpret_cast<const int32_t*>(d_arena);
+  for (int64_t b = 0; b < n_batches; ++b) {
+    gcmi_small_batch& s = out[b];
+    memset(&s, 0, sizeof(s));
+    s.graph = graphs[b];
+    const int64_t* p = parts + 5 * b;
+    s.graph.d_membership = i32 + p[1];
+    s.graph.d_col_idx = i32 + p[2];
+    s.graph.d_mol_runs = i32 + p[3];
+    s.graph.d_rev_pos = reinterpret_cast<const uint8_t*>(i32 + p[4]);
+    s.d_atom_features = d_features + counts[3 * b + 2] * feature_ld;
+    s.ld_features = feature_ld;
+    s.n_rows = n_rows[b];
+    const int64_t slot0 = b * mols_out;
+    s.d_labels = d_labels ? d_labels + slot0 * label_stride : nullptr;
+    s.d_weights = d_weights ? d_weights + slot0 * weight_stride : nullptr;
+    s.d_logits = d_logits ? d_logits + slot0 * logit_stride : nullptr;
+    s.d_probs = d_probs ? d_probs + slot0 * logit_stride : nullptr;
+    s.d_fingerprint = d_fingerprint ? d_fingerprint + slot0 * fp_stride : nullptr;
+  }
   return GCMI_OK;
 }
 

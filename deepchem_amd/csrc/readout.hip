@@ -338,8 +338,9 @@ namespace gcmi {
 __global__ void __launch_bounds__(256)
 expand_codes_kernel(const uint8_t* __restrict__ codes, int64_t ldc, int64_t n_atoms, float* __restrict__ out,
                     int64_t ldo, int quads) {
-  const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= n_atoms * quads) return;
+  // grid-stride: grid_for caps the grid, a large batch has more quads than one sweep of it covers
+  for (int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; slot < n_atoms * quads;
+       slot += (int64_t)gridDim.x * blockDim.x) {
   const int64_t r = slot / quads;
   const int q = (int)(slot - r * quads);
   const uint2 w = *reinterpret_cast<const uint2*>(codes + r * ldc);
@@ -362,6 +363,7 @@ expand_codes_kernel(const uint8_t* __restrict__ codes, int64_t ldc, int64_t n_at
     v[e] = x;
   }
   *reinterpret_cast<float4*>(out + r * ldo + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
+  }
 }
 }  // namespace gcmi
 

@@ -32,7 +32,7 @@ namespace gcmi {
 typedef float f4v __attribute__((ext_vector_type(4)));
 
 constexpr int kTileRows = 16;
-constexpr int kSlabRows = 64;
+constexpr int kSlabRows = 32;
 constexpr int kSBlock = 256;
 constexpr int kMaxL = GCMI_MAX_CONV_LAYERS;
 
@@ -129,14 +129,60 @@ __device__ __forceinline__ BnCol bn_col(const BnArgs& a, int width, int c) {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+// ------------------------------------------------------------------------------------------------ pooled row chunk
+// One row of GraphPool over the folded BatchNorm of gc: max over {self} U neighbours, first maximum wins
+// (self, then neighbours in table order: layers.py:6353-6361; torch.max(dim) tie rule).  arg: 0 = self, j+1.
+__device__ __forceinline__ void pool_chunk(const SmallGraph& g, int row, int d, int e, const float* __restrict__ gc,
+                                           int W, int q, const float* sScale, const float* sShift, float4& best,
+                                           uint32_t& arg) {
+  const float4 sc = ld4(sScale + 4 * q), sh = ld4(sShift + 4 * q);
+  float4 v = ld4(gc + (int64_t)row * W + 4 * q);
+  best = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+  uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  const int32_t* nb = g.col_idx + e;
+  for (int j = 0; j < d; ++j) {
+    v = ld4(gc + (int64_t)nb[j] * W + 4 * q);
+    const float y0 = fmaf(v.x, sc.x, sh.x), y1 = fmaf(v.y, sc.y, sh.y), y2 = fmaf(v.z, sc.z, sh.z),
+                y3 = fmaf(v.w, sc.w, sh.w);
+    if (y0 > best.x) { best.x = y0; a0 = j + 1; }
+    if (y1 > best.y) { best.y = y1; a1 = j + 1; }
+    if (y2 > best.z) { best.z = y2; a2 = j + 1; }
+    if (y3 > best.w) { best.w = y3; a3 = j + 1; }
+  }
+  arg = a0 | (a1 << 8) | (a2 << 16) | (a3 << 24);
+}
+
+__device__ __forceinline__ int degree_of(const SmallGraph& g, int row) {
+  int d = 0;
+#pragma unroll
+  for (int k = 1; k <= GCMI_MAX_DEG; ++k) d += (k <= g.max_deg && row >= g.deg_start[k]) ? 1 : 0;
+  return d;
+}
+
+__device__ __forceinline__ void fold_bn_to_lds(const BnArgs& bn, int W, float* sScale, float* sShift) {
+  for (int c = threadIdx.x; c < W; c += kSBlock) {
+    const BnCol b = bn_col(bn, W, c);
+    sScale[c] = b.scale;
+    sShift[c] = b.shift;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ conv forward
 // out[rows of degree d] = relu(S . W_rel[d] + X . W_self[d] + b_rel[d] + b_self[d]),  S = sum of neighbour rows
 // (degree 0: X . W_self[0] + b_self[0]); optional column sums of out and out^2 into acc (fp64 atomics).
 // W_list order: rel_1, self_1, ..., rel_10, self_10, self_0 (layers.py:6189-6224).
-template <int NT>
+// POOL_IN: the layer input X is the GraphPool of the previous layer's output, computed HERE from gc_prev with
+// its folded BatchNorm -- own rows (written to pool_out / arg_out when given: the backward of "full" mode reads
+// them) and, recomputed, the rows of the neighbours -- so the pooled matrix needs no launch of its own.
+// The weight fragments of a wave (its 16 columns per pass) are fetched eight k-steps ahead into registers: one
+// load latency per eight steps instead of one per step.
+constexpr int kBChunk = 8;
+
+template <int NT, bool POOL_IN>
 __global__ void __launch_bounds__(kSBlock)
 small_conv_fwd_kernel(SmallGraph g, const float* __restrict__ x, int ldx, int K, const float* __restrict__ Wl,
-                      const float* __restrict__ bl, float* __restrict__ out, double* __restrict__ acc) {
+                      const float* __restrict__ bl, float* __restrict__ out, double* __restrict__ acc, BnArgs bn_in,
+                      float* __restrict__ pool_out, uint8_t* __restrict__ arg_out) {
   extern __shared__ float smem[];
   const int t = blockIdx.x;
   if (t >= g.n_tiles) return;
@@ -144,52 +190,102 @@ small_conv_fwd_kernel(SmallGraph g, const float* __restrict__ x, int ldx, int K,
   const int W = 64 * NT;
   const int K4 = (K + 3) & ~3;
   const int KP = pitch_a(K4);
-  float* sS = smem;                 // [16][KP] neighbour sums
+  float* sS = smem;                   // [16][KP] neighbour sums
   float* sX = smem + kTileRows * KP;  // [16][KP] own rows
+  float* sScale = sX + kTileRows * KP;
+  float* sShift = sScale + K4;
   const int q4 = K4 / 4;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lr = lane & 15, kq = lane >> 4;
+  const int64_t blk = (int64_t)K * W;
+  const float* Wself = Wl + (tl.d == 0 ? (int64_t)(2 * g.max_deg) * blk : (int64_t)(2 * (tl.d - 1) + 1) * blk);
+  const float* Wrel = tl.d == 0 ? nullptr : Wl + (int64_t)(2 * (tl.d - 1)) * blk;
+  float bx[kBChunk][NT], bs[kBChunk][NT];
+  auto load_b = [&](int ks0) {
+#pragma unroll
+    for (int u = 0; u < kBChunk; ++u) {
+      int k = 4 * (ks0 + u) + kq;
+      k = k < K ? k : K - 1;  // beyond K the A operand is zero (and beyond the loop nothing is used)
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int col = 16 * (wave + 4 * i) + lr;
+        bx[u][i] = Wself[(int64_t)k * W + col];
+        bs[u][i] = Wrel ? Wrel[(int64_t)k * W + col] : 0.f;
+      }
+    }
+  };
+  load_b(0);  // in flight while the operand tile is gathered
+  if (POOL_IN) {
+    fold_bn_to_lds(bn_in, K, sScale, sShift);
+    __syncthreads();
+  }
   for (int idx = threadIdx.x; idx < kTileRows * q4; idx += kSBlock) {
     const int r = idx / q4, q = idx - r * q4;
     float4 self = make_float4(0.f, 0.f, 0.f, 0.f), s = self;
     if (r < tl.nrows) {
       const int row = tl.row0 + r;
-      self = ld4(x + (int64_t)row * ldx + 4 * q);
       const int32_t* nb = g.col_idx + tl.e0 + r * tl.d;
-      for (int j = 0; j < tl.d; ++j) {
-        const float4 v = ld4(x + (int64_t)nb[j] * ldx + 4 * q);
-        s.x += v.x;
-        s.y += v.y;
-        s.z += v.z;
-        s.w += v.w;
-      }
-      if (4 * q + 3 >= K) {  // columns beyond K (alignment padding of the input) never count
-        float* sf = reinterpret_cast<float*>(&self);
-        float* ss = reinterpret_cast<float*>(&s);
-        for (int c = 0; c < 4; ++c)
-          if (4 * q + c >= K) sf[c] = ss[c] = 0.f;
+      if (POOL_IN) {
+        uint32_t a;
+        pool_chunk(g, row, tl.d, tl.e0 + r * tl.d, x, K, q, sScale, sShift, self, a);
+        if (pool_out) st4(pool_out + (int64_t)row * K + 4 * q, self);
+        if (arg_out) *reinterpret_cast<uint32_t*>(arg_out + (int64_t)row * K + 4 * q) = a;
+        for (int j = 0; j < tl.d; ++j) {
+          const int nr = nb[j];
+          const int dn = degree_of(g, nr);
+          float4 v;
+          pool_chunk(g, nr, dn, g.edge_start[dn] + (nr - g.deg_start[dn]) * dn, x, K, q, sScale, sShift, v, a);
+          s.x += v.x;
+          s.y += v.y;
+          s.z += v.z;
+          s.w += v.w;
+        }
+      } else {
+        self = ld4(x + (int64_t)row * ldx + 4 * q);
+        for (int j = 0; j < tl.d; ++j) {
+          const float4 v = ld4(x + (int64_t)nb[j] * ldx + 4 * q);
+          s.x += v.x;
+          s.y += v.y;
+          s.z += v.z;
+          s.w += v.w;
+        }
+        if (4 * q + 3 >= K) {  // columns beyond K (alignment padding of the input) never count
+          float* sf = reinterpret_cast<float*>(&self);
+          float* ss = reinterpret_cast<float*>(&s);
+          for (int c = 0; c < 4; ++c)
+            if (4 * q + c >= K) sf[c] = ss[c] = 0.f;
+        }
       }
     }
     st4(sX + r * KP + 4 * q, self);
     st4(sS + r * KP + 4 * q, s);
   }
   __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int lr = lane & 15, kq = lane >> 4;
-  const int64_t blk = (int64_t)K * W;
-  const float* Wself = Wl + (tl.d == 0 ? (int64_t)(2 * g.max_deg) * blk : (int64_t)(2 * (tl.d - 1) + 1) * blk);
-  const float* Wrel = tl.d == 0 ? nullptr : Wl + (int64_t)(2 * (tl.d - 1)) * blk;
   f4v c[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) c[i] = (f4v){0.f, 0.f, 0.f, 0.f};
-  for (int ks = 0; ks < q4; ++ks) {
-    const int k = 4 * ks + kq;
-    const int kc = k < K ? k : K - 1;  // A is zero there
-    const float ax = sX[lr * KP + k];
-    const float as = sS[lr * KP + k];
+  for (int ks0 = 0; ks0 < q4; ks0 += kBChunk) {
+    float cx[kBChunk][NT], cs[kBChunk][NT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int col = 16 * (wave + 4 * i) + lr;
-      c[i] = mfma16(ax, Wself[(int64_t)kc * W + col], c[i]);
-      if (Wrel) c[i] = mfma16(as, Wrel[(int64_t)kc * W + col], c[i]);
+    for (int u = 0; u < kBChunk; ++u)
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        cx[u][i] = bx[u][i];
+        cs[u][i] = bs[u][i];
+      }
+    if (ks0 + kBChunk < q4) load_b(ks0 + kBChunk);
+#pragma unroll
+    for (int u = 0; u < kBChunk; ++u) {
+      if (ks0 + u < q4) {
+        const int k = 4 * (ks0 + u) + kq;
+        const float ax = sX[lr * KP + k];
+        const float as = sS[lr * KP + k];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+          c[i] = mfma16(ax, cx[u][i], c[i]);
+          if (Wrel) c[i] = mfma16(as, cs[u][i], c[i]);
+        }
+      }
     }
   }
 #pragma unroll
@@ -221,60 +317,6 @@ small_conv_fwd_kernel(SmallGraph g, const float* __restrict__ x, int ldx, int K,
   }
 }
 
-// ------------------------------------------------------------------------------------------------ pool forward
-// One row of GraphPool over the folded BatchNorm of gc: max over {self} U neighbours, first maximum wins
-// (self, then neighbours in table order: layers.py:6353-6361; torch.max(dim) tie rule).  arg: 0 = self, j+1.
-__device__ __forceinline__ void pool_row_chunk(const SmallGraph& g, const Tile& tl, int r, const float* __restrict__ gc,
-                                               int W, int q, const float* sScale, const float* sShift, float4& best,
-                                               uint32_t& arg) {
-  const int row = tl.row0 + r;
-  const float4 sc = ld4(sScale + 4 * q), sh = ld4(sShift + 4 * q);
-  float4 v = ld4(gc + (int64_t)row * W + 4 * q);
-  best = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
-  uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-  const int32_t* nb = g.col_idx + tl.e0 + r * tl.d;
-  for (int j = 0; j < tl.d; ++j) {
-    v = ld4(gc + (int64_t)nb[j] * W + 4 * q);
-    const float y0 = fmaf(v.x, sc.x, sh.x), y1 = fmaf(v.y, sc.y, sh.y), y2 = fmaf(v.z, sc.z, sh.z),
-                y3 = fmaf(v.w, sc.w, sh.w);
-    if (y0 > best.x) { best.x = y0; a0 = j + 1; }
-    if (y1 > best.y) { best.y = y1; a1 = j + 1; }
-    if (y2 > best.z) { best.z = y2; a2 = j + 1; }
-    if (y3 > best.w) { best.w = y3; a3 = j + 1; }
-  }
-  arg = a0 | (a1 << 8) | (a2 << 16) | (a3 << 24);
-}
-
-__device__ __forceinline__ void fold_bn_to_lds(const BnArgs& bn, int W, float* sScale, float* sShift) {
-  for (int c = threadIdx.x; c < W; c += kSBlock) {
-    const BnCol b = bn_col(bn, W, c);
-    sScale[c] = b.scale;
-    sShift[c] = b.shift;
-  }
-}
-
-__global__ void __launch_bounds__(kSBlock)
-small_pool_fwd_kernel(SmallGraph g, const float* __restrict__ gc, int W, BnArgs bn, float* __restrict__ pool,
-                      uint8_t* __restrict__ arg) {
-  extern __shared__ float smem[];
-  const int t = blockIdx.x;
-  if (t >= g.n_tiles) return;
-  const Tile tl = tile_of(g, t);
-  float* sScale = smem;
-  float* sShift = smem + W;
-  fold_bn_to_lds(bn, W, sScale, sShift);
-  __syncthreads();
-  const int q4 = W / 4;
-  for (int idx = threadIdx.x; idx < tl.nrows * q4; idx += kSBlock) {
-    const int r = idx / q4, q = idx - r * q4;
-    float4 best;
-    uint32_t a;
-    pool_row_chunk(g, tl, r, gc, W, q, sScale, sShift, best, a);
-    st4(pool + (int64_t)(tl.row0 + r) * W + 4 * q, best);
-    if (arg) *reinterpret_cast<uint32_t*>(arg + (int64_t)(tl.row0 + r) * W + 4 * q) = a;
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ pool + dense forward
 // The last GraphPool fused with the atom-level nn.Linear(K -> D) + ReLU (graphconvmodel.py:222-223): the pooled
 // tile goes to LDS (and to HBM with its arg-max, for the backward) and straight into the product.
@@ -293,33 +335,51 @@ small_pool_dense_fwd_kernel(SmallGraph g, const float* __restrict__ gc, int K, B
   float* sScale = smem;
   float* sShift = smem + K;
   float* sP = smem + 2 * K;  // [16][KP]
+  const int q4 = K / 4;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int lr = lane & 15, kq = lane >> 4;
+  float bw[kBChunk][NT];
+  auto load_w = [&](int ks0) {
+#pragma unroll
+    for (int u = 0; u < kBChunk; ++u) {
+      int k = 4 * (ks0 + u) + kq;
+      k = k < K ? k : K - 1;
+#pragma unroll
+      for (int i = 0; i < NT; ++i) bw[u][i] = Wd[(int64_t)(16 * (wave + 4 * i) + lr) * K + k];
+    }
+  };
+  load_w(0);  // in flight while the pooled tile is gathered
   fold_bn_to_lds(bn, K, sScale, sShift);
   __syncthreads();
-  const int q4 = K / 4;
   for (int idx = threadIdx.x; idx < kTileRows * q4; idx += kSBlock) {
     const int r = idx / q4, q = idx - r * q4;
     float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < tl.nrows) {
       uint32_t a;
-      pool_row_chunk(g, tl, r, gc, K, q, sScale, sShift, best, a);
+      pool_chunk(g, tl.row0 + r, tl.d, tl.e0 + r * tl.d, gc, K, q, sScale, sShift, best, a);
       st4(pool + (int64_t)(tl.row0 + r) * K + 4 * q, best);
       if (arg) *reinterpret_cast<uint32_t*>(arg + (int64_t)(tl.row0 + r) * K + 4 * q) = a;
     }
     st4(sP + r * KP + 4 * q, best);
   }
   __syncthreads();
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int lr = lane & 15, kq = lane >> 4;
   f4v c[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) c[i] = (f4v){0.f, 0.f, 0.f, 0.f};
-  for (int ks = 0; ks < q4; ++ks) {
-    const int k = 4 * ks + kq;
-    const float a = sP[lr * KP + k];
+  for (int ks0 = 0; ks0 < q4; ks0 += kBChunk) {
+    float cw[kBChunk][NT];
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int col = 16 * (wave + 4 * i) + lr;
-      c[i] = mfma16(a, Wd[(int64_t)col * K + k], c[i]);
+    for (int u = 0; u < kBChunk; ++u)
+#pragma unroll
+      for (int i = 0; i < NT; ++i) cw[u][i] = bw[u][i];
+    if (ks0 + kBChunk < q4) load_w(ks0 + kBChunk);
+#pragma unroll
+    for (int u = 0; u < kBChunk; ++u) {
+      if (ks0 + u < q4) {
+        const float a = sP[lr * KP + 4 * (ks0 + u) + kq];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) c[i] = mfma16(a, cw[u][i], c[i]);
+      }
     }
   }
 #pragma unroll
@@ -384,65 +444,126 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-template <int NF>  // F = 64 * NF
+// Lanes along the feature axis in float4 pieces: LPR = F / 4 lanes cover one row, 64 / LPR rows are read per
+// wave instruction; the molecule's rows (<= 11 contiguous runs) are enumerated up front so that the row loads of
+// several iterations are independent and in flight together.
+template <int LPR>  // F = 4 * LPR in {64, 128, 256}
 __global__ void __launch_bounds__(kSBlock)
 small_readout_kernel(SmallGraph g, ReadoutArgs a) {
   extern __shared__ float smem[];
+  constexpr int F = 4 * LPR, RPW = 64 / LPR, F2 = 2 * F;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + wave;
-  const int F = 64 * NF, TC = a.T * a.C;
-  float* sfp = smem + wave * (2 * F + 2 * TC);  // [2F] fingerprint, [TC] logits, [TC] dlogits
-  float* slog = sfp + 2 * F;
-  float* sdl = slog + TC;
+  const int TC = a.T * a.C, TCp = (TC + 3) & ~3;
+  float* sfp = smem + wave * (2 * F2 + 2 * TCp);  // [2F] fingerprint, [TCp] logits, [TCp] dlogits, [2F] its gradient
+  float* slog = sfp + F2;
+  float* sdl = slog + TCp;
+  float* sgr = sdl + TCp;
   if (m >= g.n_mols) return;
-  BnCol bn[NF];
-  float s[NF], raw[NF], mx[NF], rawarg[NF];
-  int arow[NF];
+  const int fq = lane % LPR, grp = lane / LPR;  // this lane's 4 features, its row slot
+  BnCol bn[4];
 #pragma unroll
-  for (int u = 0; u < NF; ++u) {
-    bn[u] = bn_col(a.bn, F, lane + 64 * u);
-    s[u] = raw[u] = rawarg[u] = 0.f;
-    mx[u] = -INFINITY;
-    arow[u] = -1;
-  }
+  for (int e = 0; e < 4; ++e) bn[e] = bn_col(a.bn, F, 4 * fq + e);
+  // run bounds: lanes 0..21 hold them, then every lane derives the row of its list position
+  const int n_b = 2 * (g.max_deg + 1);
+  const int rb = lane < n_b ? g.mol_runs[(int64_t)m * n_b + lane] : 0;
   int n_m = 0;
-  const int32_t* runs = g.mol_runs + (int64_t)m * (g.max_deg + 1) * 2;
-  for (int dd = 0; dd <= g.max_deg; ++dd) {
-    const int b = runs[2 * dd], e = runs[2 * dd + 1];
-    n_m += e - b;
-    for (int r = b; r < e; ++r) {
+  for (int dd = 0; dd <= g.max_deg; ++dd) n_m += __shfl(rb, 2 * dd + 1) - __shfl(rb, 2 * dd);
+  float s[4] = {0.f, 0.f, 0.f, 0.f}, raw[4] = {0.f, 0.f, 0.f, 0.f}, rawarg[4] = {0.f, 0.f, 0.f, 0.f};
+  float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  int arow[4] = {-1, -1, -1, -1};
+  for (int base = 0; base < n_m; base += 64) {
+    // row of list position base + lane (the walk order of segment max: degree blocks ascending, rows ascending)
+    int myrow = -1, pos = 0;
+    for (int dd = 0; dd <= g.max_deg; ++dd) {
+      const int b0 = __shfl(rb, 2 * dd), len = __shfl(rb, 2 * dd + 1) - b0;
+      const int j = base + lane - pos;
+      if (j >= 0 && j < len) myrow = b0 + j;
+      pos += len;
+    }
+    const int cnt = min(64, n_m - base);
+    for (int p = 0; p < cnt; p += 4 * RPW) {  // four wave-loads of rows in flight
+      float4 v4[4];
+      int rr[4];
+      bool ok[4];
 #pragma unroll
-      for (int u = 0; u < NF; ++u) {
-        const float v = a.dense[(int64_t)r * F + lane + 64 * u];
-        const float y = fmaf(v, bn[u].scale, bn[u].shift);
-        raw[u] += v;
-        s[u] += y;
-        if (y > mx[u]) {
-          mx[u] = y;
-          arow[u] = r;
-          rawarg[u] = v;
+      for (int u = 0; u < 4; ++u) {
+        const int pp = p + u * RPW + grp;
+        rr[u] = __shfl(myrow, pp & 63);
+        ok[u] = pp < cnt;
+        v4[u] = ok[u] ? ld4(a.dense + (int64_t)rr[u] * F + 4 * fq) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!ok[u]) continue;
+        const float* v = reinterpret_cast<const float*>(&v4[u]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float y = fmaf(v[e], bn[e].scale, bn[e].shift);
+          raw[e] += v[e];
+          s[e] += y;
+          if (y > mx[e]) {
+            mx[e] = y;
+            arow[e] = rr[u];
+            rawarg[e] = v[e];
+          }
         }
       }
     }
   }
+  // combine the row slots: sums add; the maximum keeps the first row of the walk (= the lowest row index) on ties
 #pragma unroll
-  for (int u = 0; u < NF; ++u) {
-    const int f = lane + 64 * u;
-    const float ts = tanhf(s[u]), tm = tanhf(mx[u]);
-    sfp[f] = ts;
-    sfp[F + f] = tm;
-    a.fp[(int64_t)m * 2 * F + f] = ts;
-    a.fp[(int64_t)m * 2 * F + F + f] = tm;
-  }
-  // task head: one coalesced row of Wh per output, wave reduction
-  for (int tc = 0; tc < TC; ++tc) {
-    float p = 0.f;
+  for (int o = LPR; o < 64; o <<= 1) {
 #pragma unroll
-    for (int u = 0; u < 2 * NF; ++u) p = fmaf(sfp[lane + 64 * u], a.Wh[(int64_t)tc * 2 * F + lane + 64 * u], p);
-    p = wave_sum(p);
-    if (lane == 0) slog[tc] = p + a.bh[tc];
+    for (int e = 0; e < 4; ++e) {
+      s[e] += __shfl_xor(s[e], o);
+      raw[e] += __shfl_xor(raw[e], o);
+      const float omx = __shfl_xor(mx[e], o);
+      const int orow = __shfl_xor(arow[e], o);
+      const float oraw = __shfl_xor(rawarg[e], o);
+      if (omx > mx[e] || (omx == mx[e] && orow >= 0 && (arow[e] < 0 || orow < arow[e]))) {
+        mx[e] = omx;
+        arow[e] = orow;
+        rawarg[e] = oraw;
+      }
+    }
   }
-  for (int tc = lane; tc < TC; tc += 64) a.logits[(int64_t)m * TC + tc] = slog[tc];
+  if (grp == 0) {
+    float4 ts, tm;
+    ts.x = tanhf(s[0]); ts.y = tanhf(s[1]); ts.z = tanhf(s[2]); ts.w = tanhf(s[3]);
+    tm.x = tanhf(mx[0]); tm.y = tanhf(mx[1]); tm.z = tanhf(mx[2]); tm.w = tanhf(mx[3]);
+    st4(sfp + 4 * fq, ts);
+    st4(sfp + F + 4 * fq, tm);
+    st4(a.fp + (int64_t)m * F2 + 4 * fq, ts);
+    st4(a.fp + (int64_t)m * F2 + F + 4 * fq, tm);
+  }
+  // task head: lane = (output tc mod 32, half of the 2F inputs); every lane reads its own row of Wh in float4
+  // pieces (independent loads), the fingerprint comes from LDS as a broadcast
+  {
+    const int tcl = lane & 31, half = lane >> 5;
+    for (int tc0 = 0; tc0 < TC; tc0 += 32) {
+      const int tc = tc0 + tcl;
+      float p = 0.f;
+      if (tc < TC) {
+        const float* wrow = a.Wh + (int64_t)tc * F2 + half * F;
+        const float* frow = sfp + half * F;
+#pragma unroll 8
+        for (int f = 0; f < F; f += 4) {
+          const float4 w4 = ld4(wrow + f), x4 = ld4(frow + f);
+          p = fmaf(x4.x, w4.x, p);
+          p = fmaf(x4.y, w4.y, p);
+          p = fmaf(x4.z, w4.z, p);
+          p = fmaf(x4.w, w4.w, p);
+        }
+      }
+      p += __shfl_xor(p, 32);
+      if (half == 0 && tc < TC) {
+        const float v = p + a.bh[tc];
+        slog[tc] = v;
+        a.logits[(int64_t)m * TC + tc] = v;
+      }
+    }
+  }
   const bool train = a.labels != nullptr;
   float lsum = 0.f;
   for (int t = lane; t < a.T; t += 64) {
@@ -479,31 +600,41 @@ small_readout_kernel(SmallGraph g, ReadoutArgs a) {
   lsum = wave_sum(lsum);
   if (lane == 0 && lsum != 0.f) atomicAdd(a.loss_acc, (double)lsum);
   for (int tc = lane; tc < TC; tc += 64) a.dlogits[(int64_t)m * TC + tc] = sdl[tc];
-  // d fingerprint = dlogits . Wh, through tanh
-  float gfp[2 * NF];
-#pragma unroll
-  for (int u = 0; u < 2 * NF; ++u) gfp[u] = 0.f;
-  for (int tc = 0; tc < TC; ++tc) {
-    const float d = sdl[tc];
-#pragma unroll
-    for (int u = 0; u < 2 * NF; ++u) gfp[u] = fmaf(d, a.Wh[(int64_t)tc * 2 * F + lane + 64 * u], gfp[u]);
+  // d fingerprint = dlogits . Wh through tanh; lane = 4 consecutive inputs, coalesced rows of Wh
+  for (int f0 = 0; f0 < F2; f0 += 256) {
+    const int f = f0 + 4 * lane;
+    if (f >= F2) break;
+    float4 gacc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int tc = 0; tc < TC; ++tc) {
+      const float d = sdl[tc];
+      const float4 w4 = ld4(a.Wh + (int64_t)tc * F2 + f);
+      gacc.x = fmaf(d, w4.x, gacc.x);
+      gacc.y = fmaf(d, w4.y, gacc.y);
+      gacc.z = fmaf(d, w4.z, gacc.z);
+      gacc.w = fmaf(d, w4.w, gacc.w);
+    }
+    const float4 y4 = ld4(sfp + f);
+    gacc.x *= (1.f - y4.x * y4.x);
+    gacc.y *= (1.f - y4.y * y4.y);
+    gacc.z *= (1.f - y4.z * y4.z);
+    gacc.w *= (1.f - y4.w * y4.w);
+    st4(a.g2 + (int64_t)m * F2 + f, gacc);
+    st4(sgr + f, gacc);  // read back below by the lanes that own the features
   }
-#pragma unroll
-  for (int u = 0; u < 2 * NF; ++u) {
-    const float y = sfp[lane + 64 * u];
-    gfp[u] *= (1.f - y * y);
-    a.g2[(int64_t)m * 2 * F + lane + 64 * u] = gfp[u];
-  }
-#pragma unroll
-  for (int u = 0; u < NF; ++u) {
-    const int f = lane + 64 * u;
-    a.argrow[(int64_t)m * F + f] = arow[u];
+  if (grp == 0) {
+    *reinterpret_cast<int4*>(a.argrow + (int64_t)m * F + 4 * fq) = make_int4(arow[0], arow[1], arow[2], arow[3]);
     if (a.bsum && n_m > 0) {
-      const float gs = gfp[u], gm = gfp[NF + u];
-      const float sum_xhat = bn[u].invstd * (raw[u] - (float)n_m * bn[u].mean);
-      const float xhat_arg = (rawarg[u] - bn[u].mean) * bn[u].invstd;
-      atomicAdd(a.bsum + f, (double)((float)n_m * gs + gm));
-      atomicAdd(a.bsum + F + f, (double)(gs * sum_xhat + gm * xhat_arg));
+      const float4 gs4 = ld4(sgr + 4 * fq), gm4 = ld4(sgr + F + 4 * fq);
+      const float* gs = reinterpret_cast<const float*>(&gs4);
+      const float* gm = reinterpret_cast<const float*>(&gm4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float sum_xhat = bn[e].invstd * (raw[e] - (float)n_m * bn[e].mean);
+        const float xhat_arg = (rawarg[e] - bn[e].mean) * bn[e].invstd;
+        atomicAdd(a.bsum + 4 * fq + e, (double)((float)n_m * gs[e] + gm[e]));
+        atomicAdd(a.bsum + F + 4 * fq + e, (double)(gs[e] * sum_xhat + gm[e] * xhat_arg));
+      }
     }
   }
 }
@@ -606,6 +737,14 @@ small_dense_bwd_kernel(SmallGraph g, DenseBwdArgs a) {
     float* sB = smem + F;
     float* sC = smem + 2 * F;
     float* sDx = smem + 3 * F;  // [16][FP]
+    float bw[kBChunk][NKT];
+    auto load_w = [&](int ks0) {
+#pragma unroll
+      for (int u = 0; u < kBChunk; ++u)
+#pragma unroll
+        for (int i = 0; i < NKT; ++i) bw[u][i] = a.Wd[(int64_t)(4 * (ks0 + u) + kq) * K + 16 * (wave + 4 * i) + lr];
+    };
+    load_w(0);  // in flight while dx is formed
     bn_bwd_coeffs_to_lds(a.bn, a.bsum, F, sA, sB, sC, nullptr, nullptr);
     __syncthreads();
     dense_dx_to_lds(g, a, tl.row0, tl.nrows, kTileRows, sA, sB, sC, sDx, FP);
@@ -613,11 +752,19 @@ small_dense_bwd_kernel(SmallGraph g, DenseBwdArgs a) {
     f4v c[NKT];
 #pragma unroll
     for (int i = 0; i < NKT; ++i) c[i] = (f4v){0.f, 0.f, 0.f, 0.f};
-    for (int ks = 0; ks < F / 4; ++ks) {
-      const int o = 4 * ks + kq;
-      const float av = sDx[lr * FP + o];
+    for (int ks0 = 0; ks0 < F / 4; ks0 += kBChunk) {
+      float cw[kBChunk][NKT];
 #pragma unroll
-      for (int i = 0; i < NKT; ++i) c[i] = mfma16(av, a.Wd[(int64_t)o * K + 16 * (wave + 4 * i) + lr], c[i]);
+      for (int u = 0; u < kBChunk; ++u)
+#pragma unroll
+        for (int i = 0; i < NKT; ++i) cw[u][i] = bw[u][i];
+      if (ks0 + kBChunk < F / 4) load_w(ks0 + kBChunk);
+#pragma unroll
+      for (int u = 0; u < kBChunk; ++u) {
+        const float av = sDx[lr * FP + 4 * (ks0 + u) + kq];  // F / 4 is a multiple of the chunk
+#pragma unroll
+        for (int i = 0; i < NKT; ++i) c[i] = mfma16(av, cw[u][i], c[i]);
+      }
     }
 #pragma unroll
     for (int i = 0; i < NKT; ++i) {
@@ -681,20 +828,35 @@ small_dense_bwd_kernel(SmallGraph g, DenseBwdArgs a) {
     return;
   }
   b -= a.n_slabs;
-  // head weight gradient: one thread per (tc, f')
-  const int64_t gid = (int64_t)b * kSBlock + threadIdx.x;
+  // head weight gradient: one workgroup per output row tc; the molecules are split over the four waves, a lane
+  // owns 4 consecutive input columns (coalesced float4 rows of fp), partial sums meet in LDS
+  const int tc = b;
   const int F2 = 2 * F;
-  if (gid < (int64_t)a.TC * F2) {
-    const int tc = (int)(gid / F2), f = (int)(gid - (int64_t)tc * F2);
-    float s = 0.f, sb = 0.f;
-    for (int m = 0; m < g.n_mols; ++m) {
-      const float d = a.dlogits[(int64_t)m * a.TC + tc];
-      s = fmaf(d, a.fp[(int64_t)m * F2 + f], s);
-      sb += d;
+  float* red = smem;  // [4][F2]
+  const int mg = threadIdx.x >> 6, ln = threadIdx.x & 63;
+  float dsum = 0.f;
+  for (int f0 = 0; f0 < F2; f0 += 256) {
+    const int f = f0 + 4 * ln;
+    float4 acc4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f < F2) {
+#pragma unroll 8
+      for (int m = mg; m < g.n_mols; m += 4) {
+        const float d = a.dlogits[(int64_t)m * a.TC + tc];
+        const float4 x4 = ld4(a.fp + (int64_t)m * F2 + f);
+        acc4.x = fmaf(d, x4.x, acc4.x);
+        acc4.y = fmaf(d, x4.y, acc4.y);
+        acc4.z = fmaf(d, x4.z, acc4.z);
+        acc4.w = fmaf(d, x4.w, acc4.w);
+        if (f0 == 0 && ln == 0) dsum += d;
+      }
+      st4(red + mg * F2 + f, acc4);
     }
-    a.dWh[(int64_t)tc * F2 + f] = s;
-    if (f == 0) a.dbh[tc] = sb;
   }
+  if (ln == 0) red[4 * F2 + mg] = dsum;
+  __syncthreads();
+  for (int f = threadIdx.x; f < F2; f += kSBlock)
+    a.dWh[(int64_t)tc * F2 + f] = red[f] + red[F2 + f] + red[2 * F2 + f] + red[3 * F2 + f];
+  if (threadIdx.x == 0) a.dbh[tc] = red[4 * F2] + red[4 * F2 + 1] + red[4 * F2 + 2] + red[4 * F2 + 3];
 }
 
 // ------------------------------------------------------------------------------------------------ pool backward
@@ -1119,8 +1281,8 @@ static int small_check(const gcmi_model_desc* m) {
       set_error("small: GraphConv width %d is not a multiple of 64 in [64, 256]", m->conv_width[l]);
       return GCMI_ERR_UNSUPPORTED;
     }
-  if (m->dense_width <= 0 || m->dense_width % 64 || m->dense_width > 256) {
-    set_error("small: dense width %d is not a multiple of 64 in [64, 256]", m->dense_width);
+  if (m->dense_width != 64 && m->dense_width != 128 && m->dense_width != 256) {
+    set_error("small: dense width %d is not 64, 128 or 256", m->dense_width);
     return GCMI_ERR_UNSUPPORTED;
   }
   return GCMI_OK;
@@ -1207,16 +1369,30 @@ static BnArgs bn_args(const SmallCtx& c, int layer, int n_rows) {
 }
 
 static int launch_conv_fwd(const SmallGraph& g, const float* x, int ldx, int K, const float* Wl, const float* bl,
-                           int W, float* out, double* acc, hipStream_t st) {
+                           int W, float* out, double* acc, bool pool_in, const BnArgs& bn_in, float* pool_out,
+                           uint8_t* arg_out, hipStream_t st) {
   const int K4 = (K + 3) & ~3;
-  const size_t lds = sizeof(float) * 2 * kTileRows * pitch_a(K4);
+  const size_t lds = sizeof(float) * (2 * kTileRows * pitch_a(K4) + 2 * K4);
   const dim3 grid(g.n_tiles), block(kSBlock);
-  switch (W / 64) {
-    case 1: hipLaunchKernelGGL(small_conv_fwd_kernel<1>, grid, block, lds, st, g, x, ldx, K, Wl, bl, out, acc); break;
-    case 2: hipLaunchKernelGGL(small_conv_fwd_kernel<2>, grid, block, lds, st, g, x, ldx, K, Wl, bl, out, acc); break;
-    case 3: hipLaunchKernelGGL(small_conv_fwd_kernel<3>, grid, block, lds, st, g, x, ldx, K, Wl, bl, out, acc); break;
-    default: hipLaunchKernelGGL(small_conv_fwd_kernel<4>, grid, block, lds, st, g, x, ldx, K, Wl, bl, out, acc); break;
+#define CF(NT, PI)                                                                                              \
+  hipLaunchKernelGGL((small_conv_fwd_kernel<NT, PI>), grid, block, lds, st, g, x, ldx, K, Wl, bl, out, acc, bn_in, \
+                     pool_out, arg_out)
+  if (pool_in) {
+    switch (W / 64) {
+      case 1: CF(1, true); break;
+      case 2: CF(2, true); break;
+      case 3: CF(3, true); break;
+      default: CF(4, true); break;
+    }
+  } else {
+    switch (W / 64) {
+      case 1: CF(1, false); break;
+      case 2: CF(2, false); break;
+      case 3: CF(3, false); break;
+      default: CF(4, false); break;
+    }
   }
+#undef CF
   GCMI_CHECK_LAUNCH("small_conv_fwd");
   return GCMI_OK;
 }
@@ -1233,17 +1409,20 @@ static int small_forward_body(const SmallCtx& c, const SmallGraph& g, const floa
   for (int l = 0; l < L; ++l) {
     const int W = m->conv_width[l];
     double* acc = (m->batch_norm && c.training) ? c.accs + c.w.acc[l] : nullptr;
-    SRUN(launch_conv_fwd(g, x, (int)ldx, K, c.params + m->off_conv_w[l], c.params + m->off_conv_b[l], W,
-                         c.ws + c.w.gc[l], acc, c.st));
-    if (l < L - 1) {
-      hipLaunchKernelGGL(small_pool_fwd_kernel, dim3(g.n_tiles), dim3(kSBlock), sizeof(float) * 2 * W, c.st, g,
-                         c.ws + c.w.gc[l], W, bn_args(c, l, N), c.ws + c.w.pool[l],
-                         c.training ? reinterpret_cast<uint8_t*>(c.ws + c.w.arg[l]) : nullptr);
-      GCMI_CHECK_LAUNCH("small_pool_fwd");
-      x = c.ws + c.w.pool[l];
-      ldx = W;
-      K = W;
+    if (l == 0) {
+      BnArgs none;
+      memset(&none, 0, sizeof(none));
+      SRUN(launch_conv_fwd(g, x, (int)ldx, K, c.params + m->off_conv_w[l], c.params + m->off_conv_b[l], W,
+                           c.ws + c.w.gc[l], acc, false, none, nullptr, nullptr, c.st));
+    } else {
+      // the GraphPool between the layers is computed by the consumer's gather; its rows and arg-max are written
+      // only when a backward pass will read them ("full" gradient mode)
+      const bool keep = c.training && m->grad_mode == 1;
+      SRUN(launch_conv_fwd(g, c.ws + c.w.gc[l - 1], K, K, c.params + m->off_conv_w[l], c.params + m->off_conv_b[l], W,
+                           c.ws + c.w.gc[l], acc, true, bn_args(c, l - 1, N), keep ? c.ws + c.w.pool[l - 1] : nullptr,
+                           keep ? reinterpret_cast<uint8_t*>(c.ws + c.w.arg[l - 1]) : nullptr, c.st));
     }
+    K = W;
   }
   const int Wl = m->conv_width[L - 1], F = m->dense_width;
   double* accD = (m->batch_norm && c.training) ? c.accs + c.w.acc[L] : nullptr;
@@ -1278,24 +1457,22 @@ static int launch_readout(const SmallCtx& c, const SmallGraph& g, ReadoutArgs& a
   a.T = m->n_tasks;
   a.C = m->n_classes;
   a.mode = m->mode;
-  const size_t lds = sizeof(float) * 4 * (2 * F + 2 * TC);
+  // per wave: fingerprint [2F], logits [TCp], dlogits [TCp], fingerprint gradient [2F] (TCp: TC rounded up to 4)
+  const int TCp = (TC + 3) & ~3;
+  const size_t lds = sizeof(float) * 4 * (4 * F + 2 * TCp);
   const dim3 grid((g.n_mols + 3) / 4), block(kSBlock);
-  switch (F / 64) {
-    case 1:
-      SRUN(ensure_lds(small_readout_kernel<1>, lds));
-      hipLaunchKernelGGL(small_readout_kernel<1>, grid, block, lds, c.st, g, a);
+  switch (F) {
+    case 64:
+      SRUN(ensure_lds(small_readout_kernel<16>, lds));
+      hipLaunchKernelGGL(small_readout_kernel<16>, grid, block, lds, c.st, g, a);
       break;
-    case 2:
-      SRUN(ensure_lds(small_readout_kernel<2>, lds));
-      hipLaunchKernelGGL(small_readout_kernel<2>, grid, block, lds, c.st, g, a);
-      break;
-    case 3:
-      SRUN(ensure_lds(small_readout_kernel<3>, lds));
-      hipLaunchKernelGGL(small_readout_kernel<3>, grid, block, lds, c.st, g, a);
+    case 128:
+      SRUN(ensure_lds(small_readout_kernel<32>, lds));
+      hipLaunchKernelGGL(small_readout_kernel<32>, grid, block, lds, c.st, g, a);
       break;
     default:
-      SRUN(ensure_lds(small_readout_kernel<4>, lds));
-      hipLaunchKernelGGL(small_readout_kernel<4>, grid, block, lds, c.st, g, a);
+      SRUN(ensure_lds(small_readout_kernel<64>, lds));
+      hipLaunchKernelGGL(small_readout_kernel<64>, grid, block, lds, c.st, g, a);
       break;
   }
   GCMI_CHECK_LAUNCH("small_readout");
@@ -1330,13 +1507,14 @@ static int small_backward(const SmallCtx& c, const SmallGraph& g, const gcmi_sma
   a.K = Kd;
   a.TC = TC;
   a.n_slabs = (N + kSlabRows - 1) / kSlabRows;
-  a.n_head_blocks = (int)(((int64_t)TC * 2 * F + kSBlock - 1) / kSBlock);
+  a.n_head_blocks = TC;
   SmallGraph gd = g;
   if (!need_dpool) gd.n_tiles = 0;  // nothing in front of the dense layer trains: no dgrad tiles
   {
     const size_t lds_tile = sizeof(float) * (3 * F + kTileRows * pitch_a(F));
     const size_t lds_slab = sizeof(float) * (3 * F + kSlabRows * (pitch_t(F) + pitch_t(Kd)));
-    const size_t lds = lds_tile > lds_slab ? lds_tile : lds_slab;
+    const size_t lds_head = sizeof(float) * (4 * 2 * F + 4);
+    const size_t lds = std::max(lds_tile, std::max(lds_slab, lds_head));
     const dim3 grid(gd.n_tiles + a.n_slabs + a.n_head_blocks), block(kSBlock);
     switch (Kd / 64) {
       case 1:

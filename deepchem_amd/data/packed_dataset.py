@@ -191,6 +191,32 @@ def disk_index_batches(dataset, shard_offsets, batch_size, epochs, deterministic
             yield idx, n_real
 
 
+def resident_labels(packed, device, arr, fn, tag):
+    """float32 copy of the whole label (or weight) array on the device, after ``fn`` (the one-hot transform).
+    Successive fit() calls over the same set find it again: the copy is kept on the molecule set under a
+    fingerprint of the host array's bytes (a changed label array is converted and uploaded afresh)."""
+    a = np.ascontiguousarray(np.asarray(arr))
+    cache = key = mark = None
+    if tag is not None and a.dtype != object:
+        try:
+            import xxhash
+            digest = xxhash.xxh3_128_hexdigest(a.data)
+        except ImportError:
+            import hashlib
+            digest = hashlib.blake2b(a.data, digest_size=16).hexdigest()
+        cache = packed.__dict__.setdefault("_label_cache", {})
+        key = (str(torch.device(device)), tag)
+        mark = (digest, a.shape, a.dtype.str)
+        hit = cache.get(key)
+        if hit is not None and hit[0] == mark:
+            return hit[1]
+    conv = a if fn is None else fn(a)
+    t = torch.as_tensor(np.ascontiguousarray(conv, np.float32)).to(device)
+    if cache is not None:
+        cache[key] = (mark, t)
+    return t
+
+
 class DeviceBatchPipeline:
     """Iterate ``(DeviceBatch, labels, weights)`` with collation + H2D running ``depth`` batches
     ahead on a worker thread and its own stream."""
@@ -231,29 +257,7 @@ class DeviceBatchPipeline:
             self.w_dev = self._labels_in_hbm(w, None, ("w", None))
 
     def _labels_in_hbm(self, arr, fn, tag):
-        """float32 copy of the whole label (or weight) array on the device, after ``fn`` (the one-hot transform).
-        Successive fit() calls over the same set find it again: the copy is kept on the molecule set under a
-        fingerprint of the host array's bytes (a changed label array is converted and uploaded afresh)."""
-        a = np.ascontiguousarray(np.asarray(arr))
-        cache = key = mark = None
-        if tag is not None and a.dtype != object:
-            try:
-                import xxhash
-                digest = xxhash.xxh3_128_hexdigest(a.data)
-            except ImportError:
-                import hashlib
-                digest = hashlib.blake2b(a.data, digest_size=16).hexdigest()
-            cache = self.packed.__dict__.setdefault("_label_cache", {})
-            key = (str(torch.device(self.device)), tag)
-            mark = (digest, a.shape, a.dtype.str)
-            hit = cache.get(key)
-            if hit is not None and hit[0] == mark:
-                return hit[1]
-        conv = a if fn is None else fn(a)
-        t = torch.as_tensor(np.ascontiguousarray(conv, np.float32)).to(self.device)
-        if cache is not None:
-            cache[key] = (mark, t)
-        return t
+        return resident_labels(self.packed, self.device, arr, fn, tag)
 
     @property
     def resident(self):

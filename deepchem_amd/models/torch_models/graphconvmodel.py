@@ -241,6 +241,64 @@ class _GraphConvTorchModel(nn.Module):
         return outputs
 
 
+class _SmallPredictPlan:
+    """A prediction pass over small batches: ``run()`` yields the model's output list once per chunk of
+    batches (one C call each, deepchem_amd/small.py), predictions trimmed to the real molecules of every
+    batch, the embedding left at ``batch_size`` rows per batch as the reference leaves it
+    (graphconvmodel.py:234-236)."""
+
+    def __init__(self, owner, engine, packed, index_batches):
+        self.owner, self.engine, self.packed, self.index_batches = owner, engine, packed, index_batches
+
+    def __iter__(self):  # only _predict consumes this object
+        raise TypeError("a small-batch prediction plan is consumed by GraphConvModel._predict")
+
+    def run(self):
+        from deepchem_amd.small import ChunkCollator, HeldChunks
+        o = self.owner
+        B, T = o.batch_size, o.n_tasks
+        C = o.n_classes if o.mode == 'classification' else 1
+        TC, F2 = T * C, 2 * o.model.dense.out_features
+        dev = o.device
+        collator = o.__dict__.get("_small_collator")
+        if collator is None or collator.packed is not self.packed or collator.mols_out != B:
+            collator = ChunkCollator(self.packed, dev, B)
+            o.__dict__["_small_collator"] = collator
+        self.engine.native.refresh()
+        held = HeldChunks(dev)
+        buf_idx, buf_real = [], []
+
+        def flush():
+            ch = collator.collate(buf_idx, buf_real)
+            nb = ch.n_batches
+            logits = torch.empty((nb * B, TC), dtype=torch.float32, device=dev)
+            probs = torch.empty((nb * B, TC), dtype=torch.float32, device=dev) if o.mode == 'classification' else None
+            fp = torch.empty((nb * B, F2), dtype=torch.float32, device=dev)
+            collator.bind(ch, buf_real, logits=logits, probs=probs, logit_stride=TC, fp=fp, fp_stride=F2)
+            self.engine.predict(ch.descs, ch.max_atoms, B)
+            held.hold(ch)
+            if all(r == B for r in buf_real[:-1]):
+                rows = slice(0, (nb - 1) * B + buf_real[-1])
+                take = lambda t: t[rows]
+            else:
+                keep = torch.as_tensor(np.concatenate([np.arange(b * B, b * B + r) for b, r in enumerate(buf_real)]),
+                                       device=dev)
+                take = lambda t: t.index_select(0, keep)
+            del buf_idx[:], buf_real[:]
+            if o.mode == 'classification':
+                return [take(probs).view(-1, T, C), take(logits).view(-1, T, C), fp]
+            return [take(logits), fp]
+
+        for idx, n_real in self.index_batches:
+            buf_idx.append(idx)
+            buf_real.append(int(n_real))
+            if len(buf_idx) >= o.small_chunk_batches:
+                yield flush()
+        if buf_idx:
+            yield flush()
+        held.drain()
+
+
 class GraphConvModel(TorchModel):
     """Graph convolutional model with the ``dc.models.torch_models.GraphConvModel``
     interface (graphconvmodel.py:252-422).
@@ -327,6 +385,193 @@ class GraphConvModel(TorchModel):
         self._native_checked = False  # full parameter-view check on the first step of every fit
         return super(GraphConvModel, self).fit_generator(*args, **kwargs)
 
+    # ------------------------------------------------------------------ the small-batch engine
+    # set to False to keep fit()/predict() on the per-batch path whatever the batch size
+    small_batch_engine: bool = True
+    # batches of a chunk (one C call); chunks end early at checkpoint steps
+    small_chunk_batches: int = 256
+
+    def _packed_view(self, dataset, epochs, deterministic, pad_batches):
+        """(packed molecule set, y, w, iterator of (molecule indices, real molecules) per batch) for the dataset
+        kinds the native pipelines understand, else None.  The index batches reproduce ``iterbatches`` (order,
+        per-epoch shuffles drawn from np.random exactly as the reference draws them, shard walk, padding)."""
+        from deepchem_amd.data.datasets import DiskDataset, NumpyDataset
+        from deepchem_amd.data.packed_dataset import (PackedDataset, disk_index_batches, packed_from_convmols,
+                                                      packed_from_disk)
+        if type(dataset) is DiskDataset and len(dataset) > 0:
+            conv = packed_from_disk(dataset)
+            if conv is None:
+                return None
+            packed, y, w, shard_offsets = conv
+            return packed, y, w, disk_index_batches(dataset, shard_offsets, self.batch_size, epochs, deterministic,
+                                                    pad_batches)
+        if type(dataset) is PackedDataset:
+            packed, y, w = dataset.packed, dataset.y, dataset.w
+        elif type(dataset) is NumpyDataset and getattr(dataset.X, "dtype", None) == object and len(dataset) > 0 \
+                and hasattr(dataset.X[0], "get_atom_features"):
+            packed = dataset.__dict__.get("_gcmi_packed")
+            if packed is None:  # one conversion per dataset object
+                packed = packed_from_convmols(dataset.X)
+                dataset.__dict__["_gcmi_packed"] = packed
+            y, w = dataset.y, dataset.w
+        else:
+            return None
+        helper = PackedDataset(packed, y, w)
+        return packed, y, w, helper.iter_index_batches(self.batch_size, epochs, deterministic, pad_batches)
+
+    def _small_engine(self):
+        """The engine for this model and these batch sizes, or None (per-batch path)."""
+        from deepchem_amd.small import SMALL_MAX_ATOMS, SmallBatchEngine, SmallUnsupported
+        # (dropout layers do not matter: fit() and predict() never pass training=True, graphconvmodel.py:217/:226)
+        if not self.small_batch_engine or self.device.type != 'cuda' or self.uncertainty or self.batch_size < 2:
+            return None
+        native = self.model._native_net()
+        if native is None:
+            return None
+        eng = self.__dict__.get("_small")
+        if eng is None or eng.native is not native:
+            try:
+                eng = SmallBatchEngine(native)
+            except SmallUnsupported:
+                return None
+            self.__dict__["_small"] = eng
+        return eng
+
+    def _labels_for_small(self, packed, y, w, fit: bool):
+        """Whole-set labels (after the one-hot transform) and weights (one per task) in HBM, float32."""
+        from deepchem_amd.data.packed_dataset import resident_labels
+        n = packed.n_mols
+        T = self.n_tasks
+        y = np.asarray(y)
+        if self.mode == 'classification':
+            def one_hot(a):
+                return to_one_hot(a.flatten(), self.n_classes).reshape(-1, T, self.n_classes)
+            y_dev = resident_labels(packed, self.device, y, one_hot, ("y", ("one_hot", T, self.n_classes)))
+            label_stride = T * self.n_classes
+        else:
+            if y.size != n * T:
+                return None
+            y_dev = resident_labels(packed, self.device, y.reshape(n, T), None, ("y", None))
+            label_stride = T
+        w = np.asarray(w)
+        if w.size == n and T > 1:  # one weight per molecule: broadcast over the tasks (_StandardLoss)
+            w = np.repeat(w.reshape(n, 1), T, axis=1)
+        if w.size != n * T:
+            return None
+        w_dev = resident_labels(packed, self.device, w.reshape(n, T), None, ("w", None))
+        return y_dev.reshape(n, label_stride), label_stride, w_dev
+
+    def fit(self, dataset, nb_epoch: int = 10, max_checkpoints_to_keep: int = 5, checkpoint_interval: int = 1000,
+            deterministic: bool = False, restore: bool = False, variables=None, loss=None, callbacks=[],
+            all_losses=None) -> float:
+        """``TorchModel.fit`` (torch_model.py:289-343).  Batches small enough to live in L2 take the small-batch
+        engine: the whole loop of fit_generator runs inside libgcmi.so, ``small_chunk_batches`` optimizer steps
+        per call (same batches, same order, same losses, logging windows and checkpoint steps)."""
+        done = None
+        plain = (variables is None and loss is None and not callbacks and self.regularization_loss is None
+                 and self._grad_sync is None)
+        if plain:
+            done = self._fit_small(dataset, nb_epoch, max_checkpoints_to_keep, checkpoint_interval, deterministic,
+                                   restore, all_losses)
+        if done is not None:
+            return done
+        return super(GraphConvModel, self).fit(dataset, nb_epoch, max_checkpoints_to_keep, checkpoint_interval,
+                                               deterministic, restore, variables, loss, callbacks, all_losses)
+
+    def _fit_small(self, dataset, nb_epoch, max_keep, interval, deterministic, restore, all_losses):
+        from deepchem_amd.models.optimizers import GcmiAdam
+        from deepchem_amd.models.torch_models.torch_model import _LossWindow, _StandardLoss, logger
+        from deepchem_amd.small import SMALL_MAX_ATOMS, ChunkCollator, HeldChunks
+        if not isinstance(self._loss_fn, _StandardLoss) or self.device.type != 'cuda':
+            return None
+        self._ensure_built()
+        if self._lr_schedule is not None or not isinstance(self._pytorch_optimizer, GcmiAdam):
+            return None
+        engine = self._small_engine()
+        if engine is None:
+            return None
+        view = self._packed_view(dataset, nb_epoch, deterministic, True)
+        if view is None:
+            return None
+        packed, y, w, index_batches = view
+        if packed.n_mols == 0 or y is None or w is None:
+            return None
+        # the engine is for batches whose activations stay in L2: judge by the set's mean molecule size
+        if self.batch_size * (packed.n_atoms / max(packed.n_mols, 1)) > SMALL_MAX_ATOMS:
+            return None
+        from deepchem_amd.data.collate import _is_symmetric
+        if not _is_symmetric(packed):
+            return None
+        labels = self._labels_for_small(packed, y, w, True)
+        if labels is None:
+            return None
+        y_dev, label_stride, w_dev = labels
+        if restore:
+            self.restore()
+        self.model.train()
+        engine.native.refresh()
+        B = self.batch_size
+        T = self.n_tasks
+        collator = self.__dict__.get("_small_collator")
+        if collator is None or collator.packed is not packed or collator.mols_out != B:
+            collator = ChunkCollator(packed, self.device, B)
+            self.__dict__["_small_collator"] = collator
+        held = HeldChunks(self.device)
+        window = _LossWindow(all_losses)
+        pending = []  # (first step, device losses) not yet folded into the logging windows
+        import time as _time
+        started = _time.time()
+
+        def fold(final: bool):
+            # logging windows close at multiples of log_frequency; the host reads the losses chunk by chunk, late
+            while pending and (final or len(pending) > 3):
+                first, dev_losses = pending.pop(0)
+                for k, v in enumerate(dev_losses.cpu().tolist()):
+                    window.total += v
+                    window.count += 1
+                    if (first + k) % self.log_frequency == 0:
+                        window.close(first + k)
+
+        buf_idx, buf_real = [], []
+
+        def flush():
+            if not buf_idx:
+                return
+            ch = collator.collate(buf_idx, buf_real)
+            sel = torch.from_numpy(np.concatenate(buf_idx)).to(self.device, non_blocking=True)
+            y_t = y_dev.index_select(0, sel)
+            w_t = w_dev.index_select(0, sel)
+            for b, r in enumerate(buf_real):
+                if r < B:
+                    w_t[b * B + r:(b + 1) * B] = 0  # padding rows of a ragged last batch carry no weight
+            collator.bind(ch, [B] * ch.n_batches, labels=y_t, label_stride=label_stride, weights=w_t, weight_stride=T)
+            losses = engine.fit(ch.descs, self._pytorch_optimizer, ch.max_atoms, B)
+            held.hold(ch)
+            pending.append((self._global_step + 1, losses))
+            self._global_step += ch.n_batches
+            del buf_idx[:], buf_real[:]
+            fold(False)
+
+        for idx, n_real in index_batches:
+            if idx.shape[0] != B:
+                raise ValueError("the small-batch engine needs padded batches")
+            buf_idx.append(idx)
+            buf_real.append(int(n_real))
+            step_after = self._global_step + len(buf_idx)
+            at_checkpoint = interval > 0 and step_after % interval == interval - 1
+            if len(buf_idx) >= self.small_chunk_batches or at_checkpoint:
+                flush()
+                if at_checkpoint:
+                    self.save_checkpoint(max_keep)
+        flush()
+        fold(True)
+        window.close(self._global_step)
+        held.drain()
+        if interval > 0:
+            self.save_checkpoint(max_keep)
+        logger.info("TIMING: model fitting took %0.3f s" % (_time.time() - started))
+        return window.last_mean
+
     # set to False to force the reference's per-batch Python collation
     native_batches: bool = True
 
@@ -378,10 +623,39 @@ class GraphConvModel(TorchModel):
 
         return gen()
 
+    def _small_predict_plan(self, dataset, deterministic):
+        from deepchem_amd.small import SMALL_MAX_ATOMS
+        engine = self._small_engine()
+        if engine is None:
+            return None
+        view = self._packed_view(dataset, 1, deterministic, False)
+        if view is None:
+            return None
+        packed, _, _, index_batches = view
+        if packed.n_mols == 0 or self.batch_size * (packed.n_atoms / packed.n_mols) > SMALL_MAX_ATOMS:
+            return None
+        return _SmallPredictPlan(self, engine, packed, index_batches)
+
+    def _predict(self, generator, transformers, uncertainty, other_output_types):
+        if not isinstance(generator, _SmallPredictPlan):
+            return super(GraphConvModel, self)._predict(generator, transformers, uncertainty, other_output_types)
+        from deepchem_amd.models.torch_models.torch_model import _OutputSink
+        _OutputSink.check(self._roles, uncertainty, other_output_types)
+        sink = _OutputSink(self._roles, transformers, uncertainty, other_output_types)
+        self._ensure_built()
+        self.model.eval()
+        for outputs in generator.run():
+            sink.push(outputs)
+        return sink.result()
+
     def _batch_generator(self, dataset, epochs: int = 1, mode: str = 'fit',
                          deterministic: bool = True, pad_batches: bool = True):
         """What fit()/predict*() iterate: the native pipeline when the dataset allows it, else
         ``default_generator`` (which keeps the reference's exact contract for direct callers)."""
+        if mode == 'predict' and epochs == 1 and not pad_batches:
+            plan = self._small_predict_plan(dataset, deterministic)
+            if plan is not None:
+                return plan
         fast = self._fast_generator(dataset, epochs, mode, deterministic, pad_batches)
         if fast is not None:
             return fast

@@ -123,3 +123,124 @@ class SmallBatchEngine:
         io = self._io(ws)
         _lib.call("gcmi_small_predict", ctypes.byref(self.native.desc), ctypes.c_void_p(self.native.flat.data_ptr()),
                   ctypes.byref(io), ctypes.cast(arr, ctypes.c_void_p), n, a, b, _stream())
+
+
+# ---------------------------------------------------------------------------------------------- chunks of batches
+import collections  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+from deepchem_amd._lib import GcmiGraph  # noqa: E402
+
+
+class Chunk:
+    """The batches of one C call, collated into one device arena."""
+
+    def __init__(self):
+        self.n_batches = 0
+        self.max_atoms = 0
+        self.descs = None      # (GcmiSmallBatch * n)
+        self.keep = []         # device tensors the descriptors point into
+        self.symmetric = True
+        self.n_real: List[int] = []
+
+
+class ChunkCollator:
+    """index batches -> ``Chunk``: ``gcmi_collate_batches`` into a pinned arena (threads over batches), one
+    H2D copy, atom codes expanded by one launch, descriptors bound natively (``gcmi_small_bind``)."""
+
+    def __init__(self, packed, device: torch.device, mols_out: int, max_deg: int = 10):
+        from deepchem_amd.data.collate import PinnedRing
+        self.packed = packed
+        self.device = device
+        self.mols_out = int(mols_out)
+        self.max_deg = max_deg
+        self.coded = getattr(packed, "atom_codes", None) is not None
+        self.n_feat = 2 if self.coded else packed.n_feat
+        self.ld = 2 if self.coded else (self.n_feat + 3) // 4 * 4
+        self.feats = packed.atom_codes.view(np.float32) if self.coded else \
+            np.ascontiguousarray(packed.atom_features, np.float32)
+        self.atom_ptr = np.ascontiguousarray(packed.atom_ptr, np.int64)
+        self.adj_ptr = np.ascontiguousarray(packed.adj_ptr, np.int64)
+        self.adj_idx = np.ascontiguousarray(packed.adj_idx, np.int32)
+        self.ring = PinnedRing(3)
+
+    def collate(self, idx_batches: Sequence[np.ndarray], n_real: Sequence[int]) -> Chunk:
+        lib = _lib.load()
+        n = len(idx_batches)
+        sel = np.ascontiguousarray(np.concatenate(idx_batches), np.int64)
+        if sel.size and (sel.min() < 0 or sel.max() >= self.packed.n_mols):
+            raise IndexError("molecule index outside the set")
+        batch_ptr = np.zeros(n + 1, np.int64)
+        np.cumsum([len(i) for i in idx_batches], out=batch_ptr[1:])
+        parts = np.zeros((n, 5), np.int64)
+        counts = np.zeros((n, 3), np.int64)
+        words = int(lib.gcmi_collate_batches_layout(self.atom_ptr.ctypes.data, self.adj_ptr.ctypes.data, sel.ctypes.data,
+                                                    batch_ptr.ctypes.data, n, self.ld, self.max_deg, self.mols_out,
+                                                    parts.ctypes.data, counts.ctypes.data))
+        if words < 0:
+            _lib.check(words, "gcmi_collate_batches_layout")
+        arena = self.ring.get(words)[:words]
+        graphs = (GcmiGraph * n)()
+        sym = np.ones(n, np.int32)
+        _lib.call("gcmi_collate_batches", self.feats.ctypes.data, self.n_feat, self.atom_ptr.ctypes.data,
+                  self.adj_ptr.ctypes.data, self.adj_idx.ctypes.data, sel.ctypes.data, batch_ptr.ctypes.data, n,
+                  self.max_deg, self.ld, self.mols_out, arena.data_ptr(), parts.ctypes.data, counts.ctypes.data,
+                  ctypes.cast(graphs, ctypes.c_void_p), sym.ctypes.data, 0)
+        dev_arena = arena.to(self.device, non_blocking=True)
+        self.ring.mark()
+        ch = Chunk()
+        ch.n_batches = n
+        ch.max_atoms = int(counts[:, 0].max()) if n else 0
+        ch.symmetric = bool(sym.all())
+        ch.n_real = [int(r) for r in n_real]
+        rows = int(counts[-1, 2] + (counts[-1, 0] + 1) // 2 * 2) if n else 0
+        if self.coded:
+            from deepchem_amd import ops
+            feats = ops.expand_atom_codes(dev_arena[:rows * 2].view(torch.uint8).view(rows, 8), 76) if rows else \
+                torch.zeros((0, 76), dtype=torch.float32, device=self.device)
+            ld = 76
+        else:
+            feats, ld = dev_arena, self.ld
+        ch.keep = [dev_arena, feats]
+        ch._bind = (graphs, parts, counts, dev_arena, feats, ld)
+        return ch
+
+    def bind(self, ch: Chunk, n_rows: Sequence[int], labels=None, label_stride=0, weights=None, weight_stride=0,
+             logits=None, probs=None, logit_stride=0, fp=None, fp_stride=0) -> None:
+        graphs, parts, counts, dev_arena, feats, ld = ch._bind
+        n = ch.n_batches
+        ch.descs = (GcmiSmallBatch * n)()
+        nr = np.ascontiguousarray(n_rows, np.int64)
+
+        def ptr(t):
+            return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        _lib.call("gcmi_small_bind", ctypes.cast(ch.descs, ctypes.c_void_p), ctypes.cast(graphs, ctypes.c_void_p),
+                  parts.ctypes.data, counts.ctypes.data, n, ptr(dev_arena), ptr(feats), ld, self.mols_out,
+                  nr.ctypes.data, ptr(labels), label_stride, ptr(weights), weight_stride, ptr(logits), ptr(probs),
+                  logit_stride, ptr(fp), fp_stride)
+        ch.keep += [t for t in (labels, weights, logits, probs, fp) if t is not None]
+
+
+class HeldChunks:
+    """Chunks stay referenced until an event recorded after their last launch has passed (their device buffers
+    were filled on this stream and are read by kernels still queued on it)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.q = collections.deque()
+
+    def hold(self, ch: Chunk) -> None:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.q.append((ev, ch))
+        while len(self.q) > 2 and self.q[0][0].query():
+            self.q.popleft()
+        while len(self.q) > 6:  # bound the memory: wait for the oldest
+            self.q[0][0].synchronize()
+            self.q.popleft()
+
+    def drain(self) -> None:
+        if self.q:
+            self.q[-1][0].synchronize()
+        self.q.clear()

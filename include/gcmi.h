@@ -530,6 +530,32 @@ int gcmi_small_predict(const gcmi_model_desc* m, const float* d_params, const gc
                        const gcmi_small_batch* batches, int64_t n_batches, int64_t ws_atoms, int64_t ws_mols,
                        void* stream);
 
+/* Host side of the small-batch engine: every batch of a chunk of an epoch collated by ONE call into ONE arena
+ * (one H2D copy), worker threads taking whole batches; per batch the output is what gcmi_collate_plans writes
+ * (ConvMol.agglomerate_mols, feat/mol_graphs.py:256-349; no LDS windows).
+ *   sel [batch_ptr[n_batches]] molecule indices, batch b = sel[batch_ptr[b] : batch_ptr[b+1]] (repeats = pad_batch
+ *   tiling); mols_out > 0: every batch's graph says mols_out molecules, the ones beyond its selection empty
+ *   (GraphGather always emits batch_size rows, layers.py:6469-6479).
+ * gcmi_collate_batches_layout -> arena size in 4-byte words (negative: error); out_parts [n_batches x 5] word
+ *   offsets of features, membership, col_idx, mol_runs, rev_pos; out_counts [n_batches x 3] atoms, edges, first
+ *   feature row.  The feature rows of all batches form ONE contiguous [rows x ld] array at the start of the arena
+ *   (every batch padded to an even row count), so 8-byte atom codes (ld = 2) expand in one launch.
+ * gcmi_collate_batches fills the arena and graphs[n_batches] (device pointers NULL); out_symmetric[b] = 0 when a
+ *   bond of batch b is listed from one end only.
+ * gcmi_small_bind turns that into the gcmi_small_batch array once the arena is on the device.               */
+int64_t gcmi_collate_batches_layout(const int64_t* atom_ptr, const int64_t* adj_ptr, const int64_t* sel,
+                                    const int64_t* batch_ptr, int64_t n_batches, int64_t ld, int32_t max_deg,
+                                    int64_t mols_out, int64_t* out_parts, int64_t* out_counts);
+int gcmi_collate_batches(const float* atom_features, int64_t n_feat, const int64_t* atom_ptr, const int64_t* adj_ptr,
+                         const int32_t* adj_idx, const int64_t* sel, const int64_t* batch_ptr, int64_t n_batches,
+                         int32_t max_deg, int64_t ld, int64_t mols_out, float* arena, const int64_t* parts,
+                         const int64_t* counts, gcmi_graph* graphs, int32_t* out_symmetric, int32_t n_threads);
+int gcmi_small_bind(gcmi_small_batch* out, const gcmi_graph* graphs, const int64_t* parts, const int64_t* counts,
+                    int64_t n_batches, const float* d_arena, const float* d_features, int64_t feature_ld,
+                    int64_t mols_out, const int64_t* n_rows, const float* d_labels, int64_t label_stride,
+                    const float* d_weights, int64_t weight_stride, float* d_logits, float* d_probs,
+                    int64_t logit_stride, float* d_fingerprint, int64_t fp_stride);
+
 /* ---------------------------------------------------------------- measurement
  * Optional per-kernel timing with hipEvents recorded on `stream` around the
  * launches of one kernel family (bench.py roofline).  id: see GCMI_K_*.       */

@@ -102,6 +102,19 @@ def test_device_expansion_equals_host_rows():
 
 
 @pytest.mark.gpu
+def test_device_expansion_covers_every_row_of_a_large_batch():
+    """More quads than one sweep of the (capped) grid covers: 300 000 atoms x 19 quads.  (Round 1 expanded only the
+    first ~110 000 rows of such a batch and left the rest uninitialised.)"""
+    from deepchem_amd import ops
+    from deepchem_amd.feat.atom_codes import features_from_codes
+    rng = np.random.RandomState(0)
+    n = 300_000
+    codes = np.stack([rng.randint(0, hi, n) for hi in (44, 11, 7, 3, 2, 5, 2, 5)], axis=1).astype(np.uint8)
+    out = ops.expand_atom_codes(torch.from_numpy(codes).to("cuda:0"), 76).cpu().numpy()
+    want = features_from_codes(codes)
+    assert np.array_equal(out[:, :75], want) and not out[:, 75].any()
+
+
 def test_training_on_codes_equals_training_on_floats():
     from deepchem_amd.models.torch_models import GraphConvModel
     smiles = _sample_smiles()

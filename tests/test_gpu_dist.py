@@ -93,6 +93,7 @@ def test_two_ranks_of_the_real_model_average_to_the_global_batch_gradient(tmp_pa
                                                       batch_normalize=False, grad_mode=grad_mode,
                                                       device=torch.device("cuda:0"), learning_rate=1e-3)
         model.model.load_state_dict({k: v.clone() for k, v in r0["before"].items()})
+        model.small_batch_engine = False  # the per-batch path leaves the step's gradients in the arena
         model.fit(dc.data.PackedDataset(packed, y, w), nb_epoch=1, deterministic=True, checkpoint_interval=0)
     finally:
         dc.set_gemm_mode("fast")
