@@ -39,6 +39,7 @@ constexpr int kMaxL = GCMI_MAX_CONV_LAYERS;
 // A collated batch as the kernels see it (by value in the kernarg segment).
 struct SmallGraph {
   int32_t n_atoms, n_mols, max_deg, n_tiles;
+  int32_t diag;  // GCMI_SMALL_DIAG: parts of the kernels switched off for timing experiments (results are wrong then)
   int32_t deg_start[GCMI_MAX_DEG + 2];
   int32_t edge_start[GCMI_MAX_DEG + 2];
   int32_t tile_start[GCMI_MAX_DEG + 2];  // 16-row tiles per degree block, prefix
@@ -79,16 +80,15 @@ __host__ __device__ inline int pitch_t(int n) { return ((n + 63) / 64) * 64 + 16
 struct BnCol {
   float mean, invstd, scale, shift;
 };
-__device__ __forceinline__ BnCol bn_col_train(const double* __restrict__ acc, int width, int c, int n_rows,
+__device__ __forceinline__ BnCol bn_col_train(const double* __restrict__ acc, int width, int c, double inv_n,
                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                               float eps) {
-  const double inv_n = 1.0 / (double)n_rows;
+  // sums in fp64 (E[x^2] - mean^2 cancels), everything after the subtraction in fp32: no fp64 divide or root
   const double mean = acc[c] * inv_n;
-  double var = acc[width + c] * inv_n - mean * mean;
-  var = var > 0.0 ? var : 0.0;
+  const float var = fmaxf((float)(acc[width + c] * inv_n - mean * mean), 0.f);
   BnCol b;
   b.mean = (float)mean;
-  b.invstd = (float)(1.0 / sqrt(var + (double)eps));
+  b.invstd = 1.0f / sqrtf(var + eps);
   b.scale = gamma[c] * b.invstd;
   b.shift = beta[c] - b.mean * b.scale;
   return b;
@@ -98,7 +98,7 @@ __device__ __forceinline__ BnCol bn_col_eval(const float* __restrict__ rm, const
                                              float eps) {
   BnCol b;
   b.mean = rm[c];
-  b.invstd = (float)(1.0 / sqrt((double)rv[c] + (double)eps));
+  b.invstd = 1.0f / sqrtf(rv[c] + eps);
   b.scale = gamma[c] * b.invstd;
   b.shift = beta[c] - b.mean * b.scale;
   return b;
@@ -113,10 +113,11 @@ struct BnArgs {          // how a kernel obtains the folded BatchNorm of its inp
   const float* beta;
   float eps;
   int n_rows;
+  double inv_n;          // 1 / n_rows
 };
 
 __device__ __forceinline__ BnCol bn_col(const BnArgs& a, int width, int c) {
-  if (a.mode == 1) return bn_col_train(a.acc, width, c, a.n_rows, a.gamma, a.beta, a.eps);
+  if (a.mode == 1) return bn_col_train(a.acc, width, c, a.inv_n, a.gamma, a.beta, a.eps);
   if (a.mode == 2) return bn_col_eval(a.rm, a.rv, c, a.gamma, a.beta, a.eps);
   BnCol b;
   b.mean = 0.f;
@@ -132,24 +133,87 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 // ------------------------------------------------------------------------------------------------ pooled row chunk
 // One row of GraphPool over the folded BatchNorm of gc: max over {self} U neighbours, first maximum wins
 // (self, then neighbours in table order: layers.py:6353-6361; torch.max(dim) tie rule).  arg: 0 = self, j+1.
+// Folded BatchNorm of the four columns of quad q, in registers: every thread derives the coefficients of ITS
+// columns from the accumulated sums itself (the loads go out together with the thread's first gather loads; a
+// fold through LDS would put a barrier and one more memory round trip in front of them).
+struct BnQuad {
+  float4 mean, invstd, scale, shift;
+};
+__device__ __forceinline__ BnQuad bn_quad(const BnArgs& bn, int W, int q) {
+  BnQuad o;
+  float* m = reinterpret_cast<float*>(&o.mean);
+  float* iv = reinterpret_cast<float*>(&o.invstd);
+  float* sc = reinterpret_cast<float*>(&o.scale);
+  float* sh = reinterpret_cast<float*>(&o.shift);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const BnCol b = bn_col(bn, W, 4 * q + e);
+    m[e] = b.mean;
+    iv[e] = b.invstd;
+    sc[e] = b.scale;
+    sh[e] = b.shift;
+  }
+  return o;
+}
+
+// A dependent global load costs about a microsecond here (the operands were written by the previous launch on
+// other XCDs, so they come from the Infinity Cache / HBM, not the local L2): gathers therefore issue their index
+// loads together, then their row loads together, four neighbours per round, instead of one neighbour per trip.
 __device__ __forceinline__ void pool_chunk(const SmallGraph& g, int row, int d, int e, const float* __restrict__ gc,
-                                           int W, int q, const float* sScale, const float* sShift, float4& best,
+                                           int W, int q, const float4& sc, const float4& sh, float4& best,
                                            uint32_t& arg) {
-  const float4 sc = ld4(sScale + 4 * q), sh = ld4(sShift + 4 * q);
   float4 v = ld4(gc + (int64_t)row * W + 4 * q);
-  best = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
-  uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
   const int32_t* nb = g.col_idx + e;
-  for (int j = 0; j < d; ++j) {
-    v = ld4(gc + (int64_t)nb[j] * W + 4 * q);
-    const float y0 = fmaf(v.x, sc.x, sh.x), y1 = fmaf(v.y, sc.y, sh.y), y2 = fmaf(v.z, sc.z, sh.z),
-                y3 = fmaf(v.w, sc.w, sh.w);
-    if (y0 > best.x) { best.x = y0; a0 = j + 1; }
-    if (y1 > best.y) { best.y = y1; a1 = j + 1; }
-    if (y2 > best.z) { best.z = y2; a2 = j + 1; }
-    if (y3 > best.w) { best.w = y3; a3 = j + 1; }
+  uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  bool first = true;
+  for (int j0 = 0; j0 < d || first; j0 += 4) {
+    int id[4];
+    float4 u[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) id[t] = j0 + t < d ? nb[j0 + t] : row;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) u[t] = ld4(gc + (int64_t)id[t] * W + 4 * q);
+    if (first) {
+      best = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+      first = false;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (j0 + t < d) {
+        const float y0 = fmaf(u[t].x, sc.x, sh.x), y1 = fmaf(u[t].y, sc.y, sh.y), y2 = fmaf(u[t].z, sc.z, sh.z),
+                    y3 = fmaf(u[t].w, sc.w, sh.w);
+        const uint32_t j = j0 + t + 1;
+        if (y0 > best.x) { best.x = y0; a0 = j; }
+        if (y1 > best.y) { best.y = y1; a1 = j; }
+        if (y2 > best.z) { best.z = y2; a2 = j; }
+        if (y3 > best.w) { best.w = y3; a3 = j; }
+      }
+    }
   }
   arg = a0 | (a1 << 8) | (a2 << 16) | (a3 << 24);
+}
+
+// sum of the d neighbour rows (quad q), four rows in flight per round
+__device__ __forceinline__ float4 gather_sum_quad(const float* __restrict__ x, int64_t ld, const int32_t* nb, int d,
+                                                  int self_row, int q) {
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int j0 = 0; j0 < d; j0 += 4) {
+    int id[4];
+    float4 u[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) id[t] = j0 + t < d ? nb[j0 + t] : self_row;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) u[t] = ld4(x + (int64_t)id[t] * ld + 4 * q);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (j0 + t < d) {
+        s.x += u[t].x;
+        s.y += u[t].y;
+        s.z += u[t].z;
+        s.w += u[t].w;
+      }
+  }
+  return s;
 }
 
 __device__ __forceinline__ int degree_of(const SmallGraph& g, int row) {
@@ -159,12 +223,74 @@ __device__ __forceinline__ int degree_of(const SmallGraph& g, int row) {
   return d;
 }
 
-__device__ __forceinline__ void fold_bn_to_lds(const BnArgs& bn, int W, float* sScale, float* sShift) {
-  for (int c = threadIdx.x; c < W; c += kSBlock) {
-    const BnCol b = bn_col(bn, W, c);
-    sScale[c] = b.scale;
-    sShift[c] = b.shift;
+// Own pooled row and the sum of the neighbours' pooled rows (quad q) for an atom of degree d <= 4 whose neighbours
+// have degree <= 4 (every atom of an organic molecule but a handful): three rounds of loads -- own neighbour ids |
+// neighbour rows + their neighbour ids | second-neighbour rows -- each issued as one batch.  Returns false when a
+// neighbour has more than four neighbours (the caller then takes the general path).
+__device__ __forceinline__ bool pool_two_hop(const SmallGraph& g, int row, int d, int e, const float* __restrict__ gc,
+                                             int W, int q, const float4& sc, const float4& sh, float4& self,
+                                             uint32_t& arg, float4& nsum) {
+  const int32_t* nb = g.col_idx + e;
+  int id[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) id[t] = t < d ? nb[t] : row;
+  const float4 own = ld4(gc + (int64_t)row * W + 4 * q);
+  int dn[4];
+  const int32_t* nn[4];
+  bool ok = true;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    dn[t] = t < d ? degree_of(g, id[t]) : 0;
+    nn[t] = g.col_idx + g.edge_start[dn[t]] + (id[t] - g.deg_start[dn[t]]) * dn[t];
+    ok = ok && dn[t] <= 4;
   }
+  if (!ok) return false;
+  float4 r1[4];
+  int id2[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    r1[t] = ld4(gc + (int64_t)id[t] * W + 4 * q);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) id2[t][k] = (t < d && k < dn[t]) ? nn[t][k] : row;
+  }
+  float4 r2[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r2[t][k] = ld4(gc + (int64_t)id2[t][k] * W + 4 * q);
+  auto bnq = [&](const float4& v) {
+    return make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+  };
+  self = bnq(own);
+  uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  nsum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    if (t < d) {
+      const float4 y = bnq(r1[t]);
+      if (y.x > self.x) { self.x = y.x; a0 = t + 1; }
+      if (y.y > self.y) { self.y = y.y; a1 = t + 1; }
+      if (y.z > self.z) { self.z = y.z; a2 = t + 1; }
+      if (y.w > self.w) { self.w = y.w; a3 = t + 1; }
+      float4 p = y;  // pooled row of neighbour t: its own row, then its neighbours
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (k < dn[t]) {
+          const float4 z = bnq(r2[t][k]);
+          p.x = fmaxf(p.x, z.x);
+          p.y = fmaxf(p.y, z.y);
+          p.z = fmaxf(p.z, z.z);
+          p.w = fmaxf(p.w, z.w);
+        }
+      }
+      nsum.x += p.x;
+      nsum.y += p.y;
+      nsum.z += p.z;
+      nsum.w += p.w;
+    }
+  }
+  arg = a0 | (a1 << 8) | (a2 << 16) | (a3 << 24);
+  return true;
 }
 
 // ------------------------------------------------------------------------------------------------ conv forward
@@ -174,36 +300,42 @@ __device__ __forceinline__ void fold_bn_to_lds(const BnArgs& bn, int W, float* s
 // POOL_IN: the layer input X is the GraphPool of the previous layer's output, computed HERE from gc_prev with
 // its folded BatchNorm -- own rows (written to pool_out / arg_out when given: the backward of "full" mode reads
 // them) and, recomputed, the rows of the neighbours -- so the pooled matrix needs no launch of its own.
-// The weight fragments of a wave (its 16 columns per pass) are fetched eight k-steps ahead into registers: one
-// load latency per eight steps instead of one per step.
+// The weight fragments of a wave (its 16 columns per pass) are fetched a chunk of k-steps ahead into registers --
+// the whole K for the default widths -- and the bias with them: they are in flight while the operand tile is
+// gathered, so the product starts without a memory round trip of its own.
 constexpr int kBChunk = 8;
+template <int NT>
+struct ConvChunk {
+  static constexpr int value = NT == 1 ? 20 : (NT == 2 ? 10 : 5);
+};
 
 template <int NT, bool POOL_IN>
 __global__ void __launch_bounds__(kSBlock)
 small_conv_fwd_kernel(SmallGraph g, const float* __restrict__ x, int ldx, int K, const float* __restrict__ Wl,
                       const float* __restrict__ bl, float* __restrict__ out, double* __restrict__ acc, BnArgs bn_in,
                       float* __restrict__ pool_out, uint8_t* __restrict__ arg_out) {
+  if (g.diag & 1024) return;
   extern __shared__ float smem[];
   const int t = blockIdx.x;
   if (t >= g.n_tiles) return;
-  const Tile tl = tile_of(g, t);
+  Tile tl = tile_of(g, t);
+  if (g.diag & 16) tl.d = 0;
   const int W = 64 * NT;
   const int K4 = (K + 3) & ~3;
   const int KP = pitch_a(K4);
   float* sS = smem;                   // [16][KP] neighbour sums
   float* sX = smem + kTileRows * KP;  // [16][KP] own rows
-  float* sScale = sX + kTileRows * KP;
-  float* sShift = sScale + K4;
   const int q4 = K4 / 4;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lr = lane & 15, kq = lane >> 4;
   const int64_t blk = (int64_t)K * W;
   const float* Wself = Wl + (tl.d == 0 ? (int64_t)(2 * g.max_deg) * blk : (int64_t)(2 * (tl.d - 1) + 1) * blk);
   const float* Wrel = tl.d == 0 ? nullptr : Wl + (int64_t)(2 * (tl.d - 1)) * blk;
-  float bx[kBChunk][NT], bs[kBChunk][NT];
+  constexpr int CH = ConvChunk<NT>::value;
+  float bx[CH][NT], bs[CH][NT], bias[NT];
   auto load_b = [&](int ks0) {
 #pragma unroll
-    for (int u = 0; u < kBChunk; ++u) {
+    for (int u = 0; u < CH; ++u) {
       int k = 4 * (ks0 + u) + kq;
       k = k < K ? k : K - 1;  // beyond K the A operand is zero (and beyond the loop nothing is used)
 #pragma unroll
@@ -214,10 +346,12 @@ small_conv_fwd_kernel(SmallGraph g, const float* __restrict__ x, int ldx, int K,
       }
     }
   };
-  load_b(0);  // in flight while the operand tile is gathered
-  if (POOL_IN) {
-    fold_bn_to_lds(bn_in, K, sScale, sShift);
-    __syncthreads();
+  load_b(0);
+#pragma unroll
+  for (int i = 0; i < NT; ++i) {
+    const int col = 16 * (wave + 4 * i) + lr;
+    bias[i] = tl.d == 0 ? bl[(int64_t)(2 * g.max_deg) * W + col]
+                        : bl[(int64_t)(2 * (tl.d - 1)) * W + col] + bl[(int64_t)(2 * (tl.d - 1) + 1) * W + col];
   }
   for (int idx = threadIdx.x; idx < kTileRows * q4; idx += kSBlock) {
     const int r = idx / q4, q = idx - r * q4;
@@ -227,28 +361,28 @@ small_conv_fwd_kernel(SmallGraph g, const float* __restrict__ x, int ldx, int K,
       const int32_t* nb = g.col_idx + tl.e0 + r * tl.d;
       if (POOL_IN) {
         uint32_t a;
-        pool_chunk(g, row, tl.d, tl.e0 + r * tl.d, x, K, q, sScale, sShift, self, a);
+        const BnQuad bq = bn_quad(bn_in, K, q);
+        const int e = tl.e0 + r * tl.d;
+        if (!(tl.d <= 4 && pool_two_hop(g, row, tl.d, e, x, K, q, bq.scale, bq.shift, self, a, s))) {
+          pool_chunk(g, row, tl.d, e, x, K, q, bq.scale, bq.shift, self, a);
+          s = make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int j = 0; j < tl.d; ++j) {
+            const int nr = nb[j];
+            const int dn = degree_of(g, nr);
+            float4 v;
+            uint32_t an;
+            pool_chunk(g, nr, dn, g.edge_start[dn] + (nr - g.deg_start[dn]) * dn, x, K, q, bq.scale, bq.shift, v, an);
+            s.x += v.x;
+            s.y += v.y;
+            s.z += v.z;
+            s.w += v.w;
+          }
+        }
         if (pool_out) st4(pool_out + (int64_t)row * K + 4 * q, self);
         if (arg_out) *reinterpret_cast<uint32_t*>(arg_out + (int64_t)row * K + 4 * q) = a;
-        for (int j = 0; j < tl.d; ++j) {
-          const int nr = nb[j];
-          const int dn = degree_of(g, nr);
-          float4 v;
-          pool_chunk(g, nr, dn, g.edge_start[dn] + (nr - g.deg_start[dn]) * dn, x, K, q, sScale, sShift, v, a);
-          s.x += v.x;
-          s.y += v.y;
-          s.z += v.z;
-          s.w += v.w;
-        }
       } else {
         self = ld4(x + (int64_t)row * ldx + 4 * q);
-        for (int j = 0; j < tl.d; ++j) {
-          const float4 v = ld4(x + (int64_t)nb[j] * ldx + 4 * q);
-          s.x += v.x;
-          s.y += v.y;
-          s.z += v.z;
-          s.w += v.w;
-        }
+        s = gather_sum_quad(x, ldx, nb, tl.d, row, q);
         if (4 * q + 3 >= K) {  // columns beyond K (alignment padding of the input) never count
           float* sf = reinterpret_cast<float*>(&self);
           float* ss = reinterpret_cast<float*>(&s);
@@ -264,18 +398,18 @@ small_conv_fwd_kernel(SmallGraph g, const float* __restrict__ x, int ldx, int K,
   f4v c[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) c[i] = (f4v){0.f, 0.f, 0.f, 0.f};
-  for (int ks0 = 0; ks0 < q4; ks0 += kBChunk) {
-    float cx[kBChunk][NT], cs[kBChunk][NT];
+  for (int ks0 = 0; ks0 < q4 && !(g.diag & 8); ks0 += CH) {
+    float cx[CH][NT], cs[CH][NT];
 #pragma unroll
-    for (int u = 0; u < kBChunk; ++u)
+    for (int u = 0; u < CH; ++u)
 #pragma unroll
       for (int i = 0; i < NT; ++i) {
         cx[u][i] = bx[u][i];
         cs[u][i] = bs[u][i];
       }
-    if (ks0 + kBChunk < q4) load_b(ks0 + kBChunk);
+    if (ks0 + CH < q4) load_b(ks0 + CH);
 #pragma unroll
-    for (int u = 0; u < kBChunk; ++u) {
+    for (int u = 0; u < CH; ++u) {
       if (ks0 + u < q4) {
         const int k = 4 * (ks0 + u) + kq;
         const float ax = sX[lr * KP + k];
@@ -291,20 +425,18 @@ small_conv_fwd_kernel(SmallGraph g, const float* __restrict__ x, int ldx, int K,
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
     const int col = 16 * (wave + 4 * i) + lr;
-    float bias = tl.d == 0 ? bl[(int64_t)(2 * g.max_deg) * W + col]
-                           : bl[(int64_t)(2 * (tl.d - 1)) * W + col] + bl[(int64_t)(2 * (tl.d - 1) + 1) * W + col];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int r = 4 * kq + j;
       if (r < tl.nrows) {
-        const float v = fmaxf(c[i][j] + bias, 0.f);
+        const float v = fmaxf(c[i][j] + bias[i], 0.f);
         out[(int64_t)(tl.row0 + r) * W + col] = v;
         s1 += v;
         s2 += v * v;
       }
     }
-    if (acc) {
+    if (acc && !(g.diag & 1)) {
       s1 += __shfl_xor(s1, 16);
       s2 += __shfl_xor(s2, 16);
       s1 += __shfl_xor(s1, 32);
@@ -326,22 +458,23 @@ __global__ void __launch_bounds__(kSBlock)
 small_pool_dense_fwd_kernel(SmallGraph g, const float* __restrict__ gc, int K, BnArgs bn, float* __restrict__ pool,
                             uint8_t* __restrict__ arg, const float* __restrict__ Wd, const float* __restrict__ bd,
                             float* __restrict__ dense, double* __restrict__ acc) {
+  if (g.diag & 1024) return;
   extern __shared__ float smem[];
   const int t = blockIdx.x;
   if (t >= g.n_tiles) return;
-  const Tile tl = tile_of(g, t);
+  Tile tl = tile_of(g, t);
+  if (g.diag & 16) tl.d = 0;
   const int D = 64 * NT;
   const int KP = pitch_a(K);
-  float* sScale = smem;
-  float* sShift = smem + K;
-  float* sP = smem + 2 * K;  // [16][KP]
+  float* sP = smem;  // [16][KP]
   const int q4 = K / 4;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lr = lane & 15, kq = lane >> 4;
-  float bw[kBChunk][NT];
+  constexpr int CH = NT <= 2 ? 16 : 8;
+  float bw[CH][NT];
   auto load_w = [&](int ks0) {
 #pragma unroll
-    for (int u = 0; u < kBChunk; ++u) {
+    for (int u = 0; u < CH; ++u) {
       int k = 4 * (ks0 + u) + kq;
       k = k < K ? k : K - 1;
 #pragma unroll
@@ -349,14 +482,16 @@ small_pool_dense_fwd_kernel(SmallGraph g, const float* __restrict__ gc, int K, B
     }
   };
   load_w(0);  // in flight while the pooled tile is gathered
-  fold_bn_to_lds(bn, K, sScale, sShift);
-  __syncthreads();
+  float biasd[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) biasd[i] = bd[16 * (wave + 4 * i) + lr];
   for (int idx = threadIdx.x; idx < kTileRows * q4; idx += kSBlock) {
     const int r = idx / q4, q = idx - r * q4;
     float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < tl.nrows) {
       uint32_t a;
-      pool_chunk(g, tl.row0 + r, tl.d, tl.e0 + r * tl.d, gc, K, q, sScale, sShift, best, a);
+      const BnQuad bq = bn_quad(bn, K, q);
+      pool_chunk(g, tl.row0 + r, tl.d, tl.e0 + r * tl.d, gc, K, q, bq.scale, bq.shift, best, a);
       st4(pool + (int64_t)(tl.row0 + r) * K + 4 * q, best);
       if (arg) *reinterpret_cast<uint32_t*>(arg + (int64_t)(tl.row0 + r) * K + 4 * q) = a;
     }
@@ -366,15 +501,15 @@ small_pool_dense_fwd_kernel(SmallGraph g, const float* __restrict__ gc, int K, B
   f4v c[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) c[i] = (f4v){0.f, 0.f, 0.f, 0.f};
-  for (int ks0 = 0; ks0 < q4; ks0 += kBChunk) {
-    float cw[kBChunk][NT];
+  for (int ks0 = 0; ks0 < q4 && !(g.diag & 8); ks0 += CH) {
+    float cw[CH][NT];
 #pragma unroll
-    for (int u = 0; u < kBChunk; ++u)
+    for (int u = 0; u < CH; ++u)
 #pragma unroll
       for (int i = 0; i < NT; ++i) cw[u][i] = bw[u][i];
-    if (ks0 + kBChunk < q4) load_w(ks0 + kBChunk);
+    if (ks0 + CH < q4) load_w(ks0 + CH);
 #pragma unroll
-    for (int u = 0; u < kBChunk; ++u) {
+    for (int u = 0; u < CH; ++u) {
       if (ks0 + u < q4) {
         const float a = sP[lr * KP + 4 * (ks0 + u) + kq];
 #pragma unroll
@@ -385,7 +520,7 @@ small_pool_dense_fwd_kernel(SmallGraph g, const float* __restrict__ gc, int K, B
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
     const int col = 16 * (wave + 4 * i) + lr;
-    const float bias = bd[col];
+    const float bias = biasd[i];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -397,7 +532,7 @@ small_pool_dense_fwd_kernel(SmallGraph g, const float* __restrict__ gc, int K, B
         s2 += v * v;
       }
     }
-    if (acc) {
+    if (acc && !(g.diag & 1)) {
       s1 += __shfl_xor(s1, 16);
       s2 += __shfl_xor(s2, 16);
       s1 += __shfl_xor(s1, 32);
@@ -436,6 +571,7 @@ struct ReadoutArgs {
   double* loss_acc;     // 1
   double* bsum;         // [sum dy (F) | sum dy*xhat (F)]
   int F, T, C, mode;    // mode 0 classification, 1 regression
+  int wh_in_lds;        // the head matrix fits into LDS beside the per-wave scratch: staged once per workgroup
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -450,6 +586,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 template <int LPR>  // F = 4 * LPR in {64, 128, 256}
 __global__ void __launch_bounds__(kSBlock)
 small_readout_kernel(SmallGraph g, ReadoutArgs a) {
+  if (g.diag & 1024) return;
   extern __shared__ float smem[];
   constexpr int F = 4 * LPR, RPW = 64 / LPR, F2 = 2 * F;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -459,7 +596,36 @@ small_readout_kernel(SmallGraph g, ReadoutArgs a) {
   float* slog = sfp + F2;
   float* sdl = slog + TCp;
   float* sgr = sdl + TCp;
+  // the head matrix, shared by the four molecules of the workgroup: all its loads go out at once, up front
+  const int WP = F2 + 4;
+  const float* whp = a.Wh;
+  int wh_ld = F2;
+  if (a.wh_in_lds) {
+    float* sWh = smem + 4 * (2 * F2 + 2 * TCp);
+    for (int idx = threadIdx.x; idx < TC * (F2 / 4); idx += kSBlock) {
+      const int tc = idx / (F2 / 4), q = idx - tc * (F2 / 4);
+      st4(sWh + tc * WP + 4 * q, ld4(a.Wh + (int64_t)tc * F2 + 4 * q));
+    }
+    __syncthreads();
+    whp = sWh;
+    wh_ld = WP;
+  }
   if (m >= g.n_mols) return;
+  // what the tail of the kernel needs from memory, requested now: bias of this lane's first output, label pair and
+  // weight of this lane's first task
+  const bool train = a.labels != nullptr;
+  const float bh0 = (lane & 31) < TC ? a.bh[lane & 31] : 0.f;
+  float y_pre[2] = {0.f, 0.f}, w_pre = 1.f;
+  const bool pre = train && lane < a.T && (a.mode == 1 || a.C <= 2);
+  if (pre) {
+    if (a.mode == 0) {
+      y_pre[0] = a.labels[((int64_t)m * a.T + lane) * a.C];
+      if (a.C > 1) y_pre[1] = a.labels[((int64_t)m * a.T + lane) * a.C + 1];
+    } else {
+      y_pre[0] = a.labels[(int64_t)m * a.T + lane];
+    }
+    if (a.weights) w_pre = a.weights[(int64_t)m * a.T + lane];
+  }
   const int fq = lane % LPR, grp = lane / LPR;  // this lane's 4 features, its row slot
   BnCol bn[4];
 #pragma unroll
@@ -472,7 +638,7 @@ small_readout_kernel(SmallGraph g, ReadoutArgs a) {
   float s[4] = {0.f, 0.f, 0.f, 0.f}, raw[4] = {0.f, 0.f, 0.f, 0.f}, rawarg[4] = {0.f, 0.f, 0.f, 0.f};
   float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
   int arow[4] = {-1, -1, -1, -1};
-  for (int base = 0; base < n_m; base += 64) {
+  for (int base = 0; base < n_m && !(g.diag & 32); base += 64) {
     // row of list position base + lane (the walk order of segment max: degree blocks ascending, rows ascending)
     int myrow = -1, pos = 0;
     for (int dd = 0; dd <= g.max_deg; ++dd) {
@@ -482,19 +648,19 @@ small_readout_kernel(SmallGraph g, ReadoutArgs a) {
       pos += len;
     }
     const int cnt = min(64, n_m - base);
-    for (int p = 0; p < cnt; p += 4 * RPW) {  // four wave-loads of rows in flight
-      float4 v4[4];
-      int rr[4];
-      bool ok[4];
+    for (int p = 0; p < cnt; p += 8 * RPW) {  // eight wave-loads of rows in flight
+      float4 v4[8];
+      int rr[8];
+      bool ok[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         const int pp = p + u * RPW + grp;
         rr[u] = __shfl(myrow, pp & 63);
         ok[u] = pp < cnt;
         v4[u] = ok[u] ? ld4(a.dense + (int64_t)rr[u] * F + 4 * fq) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         if (!ok[u]) continue;
         const float* v = reinterpret_cast<const float*>(&v4[u]);
 #pragma unroll
@@ -537,6 +703,7 @@ small_readout_kernel(SmallGraph g, ReadoutArgs a) {
     st4(a.fp + (int64_t)m * F2 + 4 * fq, ts);
     st4(a.fp + (int64_t)m * F2 + F + 4 * fq, tm);
   }
+  if (g.diag & 64) return;
   // task head: lane = (output tc mod 32, half of the 2F inputs); every lane reads its own row of Wh in float4
   // pieces (independent loads), the fingerprint comes from LDS as a broadcast
   {
@@ -545,7 +712,7 @@ small_readout_kernel(SmallGraph g, ReadoutArgs a) {
       const int tc = tc0 + tcl;
       float p = 0.f;
       if (tc < TC) {
-        const float* wrow = a.Wh + (int64_t)tc * F2 + half * F;
+        const float* wrow = whp + (int64_t)tc * wh_ld + half * F;
         const float* frow = sfp + half * F;
 #pragma unroll 8
         for (int f = 0; f < F; f += 4) {
@@ -558,15 +725,15 @@ small_readout_kernel(SmallGraph g, ReadoutArgs a) {
       }
       p += __shfl_xor(p, 32);
       if (half == 0 && tc < TC) {
-        const float v = p + a.bh[tc];
+        const float v = p + (tc0 == 0 ? bh0 : a.bh[tc]);
         slog[tc] = v;
         a.logits[(int64_t)m * TC + tc] = v;
       }
     }
   }
-  const bool train = a.labels != nullptr;
   float lsum = 0.f;
   for (int t = lane; t < a.T; t += 64) {
+    const bool use_pre = pre && t == lane;
     if (a.mode == 0) {
       const float* x = slog + t * a.C;
       float mxl = -INFINITY;
@@ -574,31 +741,31 @@ small_readout_kernel(SmallGraph g, ReadoutArgs a) {
       float se = 0.f;
       for (int c = 0; c < a.C; ++c) se += expf(x[c] - mxl);
       const float lse = logf(se);
-      const float w = (train && a.weights) ? a.weights[(int64_t)m * a.T + t] : 1.f;
+      const float w = use_pre ? w_pre : ((train && a.weights) ? a.weights[(int64_t)m * a.T + t] : 1.f);
       float ysum = 0.f, l = 0.f;
       if (train)
-        for (int c = 0; c < a.C; ++c) ysum += a.labels[((int64_t)m * a.T + t) * a.C + c];
+        for (int c = 0; c < a.C; ++c) ysum += use_pre ? y_pre[c] : a.labels[((int64_t)m * a.T + t) * a.C + c];
       for (int c = 0; c < a.C; ++c) {
         const float logp = x[c] - mxl - lse;
         const float p = expf(logp);
         if (a.probs) a.probs[((int64_t)m * a.T + t) * a.C + c] = p;
         if (train) {
-          const float y = a.labels[((int64_t)m * a.T + t) * a.C + c];
+          const float y = use_pre ? y_pre[c] : a.labels[((int64_t)m * a.T + t) * a.C + c];
           l -= y * logp;
           sdl[t * a.C + c] = m < a.n_rows ? w * (p * ysum - y) * a.inv_count : 0.f;
         }
       }
       if (train && m < a.n_rows) lsum += w * l;
     } else if (train) {
-      const float w = a.weights ? a.weights[(int64_t)m * a.T + t] : 1.f;
-      const float dlt = slog[t] - a.labels[(int64_t)m * a.T + t];
+      const float w = use_pre ? w_pre : (a.weights ? a.weights[(int64_t)m * a.T + t] : 1.f);
+      const float dlt = slog[t] - (use_pre ? y_pre[0] : a.labels[(int64_t)m * a.T + t]);
       sdl[t] = m < a.n_rows ? 2.f * dlt * w * a.inv_count : 0.f;
       if (m < a.n_rows) lsum += w * dlt * dlt;
     }
   }
   if (!train) return;
   lsum = wave_sum(lsum);
-  if (lane == 0 && lsum != 0.f) atomicAdd(a.loss_acc, (double)lsum);
+  if (lane == 0 && lsum != 0.f && !(g.diag & 2)) atomicAdd(a.loss_acc, (double)lsum);
   for (int tc = lane; tc < TC; tc += 64) a.dlogits[(int64_t)m * TC + tc] = sdl[tc];
   // d fingerprint = dlogits . Wh through tanh; lane = 4 consecutive inputs, coalesced rows of Wh
   for (int f0 = 0; f0 < F2; f0 += 256) {
@@ -608,7 +775,7 @@ small_readout_kernel(SmallGraph g, ReadoutArgs a) {
 #pragma unroll 8
     for (int tc = 0; tc < TC; ++tc) {
       const float d = sdl[tc];
-      const float4 w4 = ld4(a.Wh + (int64_t)tc * F2 + f);
+      const float4 w4 = ld4(whp + (int64_t)tc * wh_ld + f);
       gacc.x = fmaf(d, w4.x, gacc.x);
       gacc.y = fmaf(d, w4.y, gacc.y);
       gacc.z = fmaf(d, w4.z, gacc.z);
@@ -624,7 +791,7 @@ small_readout_kernel(SmallGraph g, ReadoutArgs a) {
   }
   if (grp == 0) {
     *reinterpret_cast<int4*>(a.argrow + (int64_t)m * F + 4 * fq) = make_int4(arow[0], arow[1], arow[2], arow[3]);
-    if (a.bsum && n_m > 0) {
+    if (a.bsum && n_m > 0 && !(g.diag & 2)) {
       const float4 gs4 = ld4(sgr + 4 * fq), gm4 = ld4(sgr + F + 4 * fq);
       const float* gs = reinterpret_cast<const float*>(&gs4);
       const float* gm = reinterpret_cast<const float*>(&gm4);
@@ -666,58 +833,82 @@ struct DenseBwdArgs {
   int F, K, TC, n_slabs, n_head_blocks;
 };
 
-// dx of `rows` consecutive rows starting at row0 into LDS tile sDx[rows][pitch]
-__device__ __forceinline__ void dense_dx_to_lds(const SmallGraph& g, const DenseBwdArgs& a, int row0, int nrows,
-                                                int tile_rows, const float* sA, const float* sB, const float* sC,
-                                                float* sDx, int pitch) {
-  const int F = a.F, q4 = F / 4;
-  for (int idx = threadIdx.x; idx < tile_rows * q4; idx += kSBlock) {
-    const int r = idx / q4, q = idx - r * q4;
-    float4 dx = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < nrows) {
-      const int row = row0 + r;
-      const int m = g.membership[row];
-      const float4 gs = ld4(a.g2 + (int64_t)m * 2 * F + 4 * q);
-      const float4 gm = ld4(a.g2 + (int64_t)m * 2 * F + F + 4 * q);
-      const int4 ar = *reinterpret_cast<const int4*>(a.argrow + (int64_t)m * F + 4 * q);
-      const float4 x = ld4(a.dense + (int64_t)row * F + 4 * q);
-      const float4 cA = ld4(sA + 4 * q), cB = ld4(sB + 4 * q), cC = ld4(sC + 4 * q);
-      const float dy0 = gs.x + (ar.x == row ? gm.x : 0.f), dy1 = gs.y + (ar.y == row ? gm.y : 0.f),
-                  dy2 = gs.z + (ar.z == row ? gm.z : 0.f), dy3 = gs.w + (ar.w == row ? gm.w : 0.f);
-      // dx = A dy + B x + C  (BatchNorm backward folded per column), masked by the ReLU in front
-      dx.x = x.x > 0.f ? fmaf(cA.x, dy0, fmaf(cB.x, x.x, cC.x)) : 0.f;
-      dx.y = x.y > 0.f ? fmaf(cA.y, dy1, fmaf(cB.y, x.y, cC.y)) : 0.f;
-      dx.z = x.z > 0.f ? fmaf(cA.z, dy2, fmaf(cB.z, x.z, cC.z)) : 0.f;
-      dx.w = x.w > 0.f ? fmaf(cA.w, dy3, fmaf(cB.w, x.w, cC.w)) : 0.f;
-    }
-    st4(sDx + r * pitch + 4 * q, dx);
-  }
-}
-
 // BatchNorm backward as dx = A dy + B x + C per column:
 //   xhat = (x - mean) invstd;  dx = gamma invstd (dy - S1/N - xhat S2/N),  S1 = sum dy, S2 = sum dy xhat
 //   => A = gamma invstd,  B = -A invstd S2/N,  C = -A S1/N - B mean.   Without BatchNorm: A = 1, B = C = 0.
-__device__ __forceinline__ void bn_bwd_coeffs_to_lds(const BnArgs& bn, const double* bsum, int F, float* sA, float* sB,
-                                                     float* sC, float* dgamma, float* dbeta) {
-  for (int c = threadIdx.x; c < F; c += kSBlock) {
+// (s1, s2: fp64 sums for the dense layer, the float gradient entries dbeta / dgamma for a GraphConv layer.)
+struct BwdQuad {
+  float4 A, B, C;
+};
+template <typename T>
+__device__ __forceinline__ BwdQuad bn_bwd_quad(const BnArgs& bn, const T* s1, const T* s2, int F, int q) {
+  BwdQuad o;
+  float* pA = reinterpret_cast<float*>(&o.A);
+  float* pB = reinterpret_cast<float*>(&o.B);
+  float* pC = reinterpret_cast<float*>(&o.C);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = 4 * q + e;
     if (bn.mode == 0) {
-      sA[c] = 1.f;
-      sB[c] = 0.f;
-      sC[c] = 0.f;
+      pA[e] = 1.f;
+      pB[e] = 0.f;
+      pC[e] = 0.f;
       continue;
     }
     const BnCol b = bn_col(bn, F, c);
-    const double inv_n = 1.0 / (double)bn.n_rows;
-    const double S1 = bsum[c], S2 = bsum[F + c];
-    const double A = (double)bn.gamma[c] * (double)b.invstd;
-    const double B = -A * (double)b.invstd * S2 * inv_n;
-    const double C = -A * S1 * inv_n - B * (double)b.mean;
-    sA[c] = (float)A;
-    sB[c] = (float)B;
-    sC[c] = (float)C;
-    if (dgamma) {
-      dgamma[c] = (float)S2;
-      dbeta[c] = (float)S1;
+    const float A = bn.gamma[c] * b.invstd;
+    const float B = -A * b.invstd * (float)((double)s2[c] * bn.inv_n);
+    const float C = -A * (float)((double)s1[c] * bn.inv_n) - B * b.mean;
+    pA[e] = A;
+    pB[e] = B;
+    pC[e] = C;
+  }
+  return o;
+}
+
+// dx of `rows` consecutive rows starting at row0 into LDS tile sDx[rows][pitch].  F / 4 divides the block size, so
+// a thread keeps ONE column quad over all its rows: coefficients once, then its rows four at a time -- the four
+// membership loads together, then the sixteen loads that depend on them together.
+__device__ __forceinline__ void dense_dx_to_lds(const SmallGraph& g, const DenseBwdArgs& a, int row0, int nrows,
+                                                int tile_rows, float* sDx, int pitch) {
+  const int F = a.F, q4 = F / 4;
+  const int q = threadIdx.x % q4, r_first = threadIdx.x / q4, r_step = kSBlock / q4;
+  const BwdQuad cq = bn_bwd_quad(a.bn, a.bsum, a.bsum + F, F, q);
+  const float4 cA = cq.A, cB = cq.B, cC = cq.C;
+  for (int r0 = r_first; r0 < tile_rows; r0 += 4 * r_step) {
+    int m[4];
+    float4 x[4], gs[4], gm[4];
+    int4 ar[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = r0 + t * r_step;
+      m[t] = r < nrows ? g.membership[row0 + r] : 0;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = r0 + t * r_step;
+      const int row = r < nrows ? row0 + r : row0;
+      x[t] = ld4(a.dense + (int64_t)row * F + 4 * q);
+      gs[t] = ld4(a.g2 + (int64_t)m[t] * 2 * F + 4 * q);
+      gm[t] = ld4(a.g2 + (int64_t)m[t] * 2 * F + F + 4 * q);
+      ar[t] = *reinterpret_cast<const int4*>(a.argrow + (int64_t)m[t] * F + 4 * q);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = r0 + t * r_step;
+      if (r >= tile_rows) continue;
+      float4 dx = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < nrows) {
+        const int row = row0 + r;
+        const float dy0 = gs[t].x + (ar[t].x == row ? gm[t].x : 0.f), dy1 = gs[t].y + (ar[t].y == row ? gm[t].y : 0.f),
+                    dy2 = gs[t].z + (ar[t].z == row ? gm[t].z : 0.f), dy3 = gs[t].w + (ar[t].w == row ? gm[t].w : 0.f);
+        // dx = A dy + B x + C  (BatchNorm backward folded per column), masked by the ReLU in front
+        dx.x = x[t].x > 0.f ? fmaf(cA.x, dy0, fmaf(cB.x, x[t].x, cC.x)) : 0.f;
+        dx.y = x[t].y > 0.f ? fmaf(cA.y, dy1, fmaf(cB.y, x[t].y, cC.y)) : 0.f;
+        dx.z = x[t].z > 0.f ? fmaf(cA.z, dy2, fmaf(cB.z, x[t].z, cC.z)) : 0.f;
+        dx.w = x[t].w > 0.f ? fmaf(cA.w, dy3, fmaf(cB.w, x[t].w, cC.w)) : 0.f;
+      }
+      st4(sDx + r * pitch + 4 * q, dx);
     }
   }
 }
@@ -725,18 +916,17 @@ __device__ __forceinline__ void bn_bwd_coeffs_to_lds(const BnArgs& bn, const dou
 template <int NKT>  // K = 64 * NKT columns of dP per row
 __global__ void __launch_bounds__(kSBlock)
 small_dense_bwd_kernel(SmallGraph g, DenseBwdArgs a) {
+  if (g.diag & 1024) return;
   extern __shared__ float smem[];
   const int F = a.F, K = a.K;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lr = lane & 15, kq = lane >> 4;
   int b = blockIdx.x;
   if (b < g.n_tiles) {
+    if (g.diag & 512) return;
     const Tile tl = tile_of(g, b);
     const int FP = pitch_a(F);
-    float* sA = smem;
-    float* sB = smem + F;
-    float* sC = smem + 2 * F;
-    float* sDx = smem + 3 * F;  // [16][FP]
+    float* sDx = smem;  // [16][FP]
     float bw[kBChunk][NKT];
     auto load_w = [&](int ks0) {
 #pragma unroll
@@ -745,14 +935,12 @@ small_dense_bwd_kernel(SmallGraph g, DenseBwdArgs a) {
         for (int i = 0; i < NKT; ++i) bw[u][i] = a.Wd[(int64_t)(4 * (ks0 + u) + kq) * K + 16 * (wave + 4 * i) + lr];
     };
     load_w(0);  // in flight while dx is formed
-    bn_bwd_coeffs_to_lds(a.bn, a.bsum, F, sA, sB, sC, nullptr, nullptr);
-    __syncthreads();
-    dense_dx_to_lds(g, a, tl.row0, tl.nrows, kTileRows, sA, sB, sC, sDx, FP);
+    dense_dx_to_lds(g, a, tl.row0, tl.nrows, kTileRows, sDx, FP);
     __syncthreads();
     f4v c[NKT];
 #pragma unroll
     for (int i = 0; i < NKT; ++i) c[i] = (f4v){0.f, 0.f, 0.f, 0.f};
-    for (int ks0 = 0; ks0 < F / 4; ks0 += kBChunk) {
+    for (int ks0 = 0; ks0 < F / 4 && !(g.diag & 8); ks0 += kBChunk) {
       float cw[kBChunk][NKT];
 #pragma unroll
       for (int u = 0; u < kBChunk; ++u)
@@ -779,25 +967,27 @@ small_dense_bwd_kernel(SmallGraph g, DenseBwdArgs a) {
   }
   b -= g.n_tiles;
   if (b < a.n_slabs) {
-    // dWd[o][k] += sum_r dx[r][o] P[r][k] over the slab's 64 rows
+    if (g.diag & 128) return;
+    // dWd[o][k] += sum_r dx[r][o] P[r][k] over the slab's rows
     const int row0 = b * kSlabRows;
     const int nrows = min(kSlabRows, g.n_atoms - row0);
     const int FT = pitch_t(F), KT = pitch_t(K);
-    float* sA = smem;
-    float* sB = smem + F;
-    float* sC = smem + 2 * F;
-    float* sDx = smem + 3 * F;            // [64][FT]
-    float* sP = sDx + kSlabRows * FT;     // [64][KT]
-    bn_bwd_coeffs_to_lds(a.bn, a.bsum, F, sA, sB, sC, b == 0 ? a.dgamma : nullptr, a.dbeta);
-    __syncthreads();
-    dense_dx_to_lds(g, a, row0, nrows, kSlabRows, sA, sB, sC, sDx, FT);
+    float* sDx = smem;                    // [slab][FT]
+    float* sP = sDx + kSlabRows * FT;     // [slab][KT]
+    if (b == 0 && a.bn.mode != 0)         // the BatchNorm gradient is the pair of sums itself
+      for (int c = threadIdx.x; c < F; c += kSBlock) {
+        a.dgamma[c] = (float)a.bsum[F + c];
+        a.dbeta[c] = (float)a.bsum[c];
+      }
+    dense_dx_to_lds(g, a, row0, nrows, kSlabRows, sDx, FT);
+#pragma unroll 4
     for (int idx = threadIdx.x; idx < kSlabRows * (K / 4); idx += kSBlock) {
       const int r = idx / (K / 4), q = idx - r * (K / 4);
       st4(sP + r * KT + 4 * q, r < nrows ? ld4(a.pool + (int64_t)(row0 + r) * K + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f));
     }
     __syncthreads();
     const int n_ot = F / 16, n_kt = K / 16;
-    for (int ot = wave; ot < n_ot; ot += 4) {
+    for (int ot = wave; ot < n_ot && !(g.diag & 8); ot += 4) {
       for (int kt0 = 0; kt0 < n_kt; kt0 += 4) {
         f4v c[4];
 #pragma unroll
@@ -815,7 +1005,7 @@ small_dense_bwd_kernel(SmallGraph g, DenseBwdArgs a) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int o = 16 * ot + 4 * kq + j, k = 16 * (kt0 + i) + lr;
-            atomicAdd(a.dWd + (int64_t)o * K + k, c[i][j]);
+            if (!(g.diag & 4)) atomicAdd(a.dWd + (int64_t)o * K + k, c[i][j]);
           }
         }
       }
@@ -830,6 +1020,7 @@ small_dense_bwd_kernel(SmallGraph g, DenseBwdArgs a) {
   b -= a.n_slabs;
   // head weight gradient: one workgroup per output row tc; the molecules are split over the four waves, a lane
   // owns 4 consecutive input columns (coalesced float4 rows of fp), partial sums meet in LDS
+  if (g.diag & 256) return;
   const int tc = b;
   const int F2 = 2 * F;
   float* red = smem;  // [4][F2]
@@ -867,20 +1058,13 @@ __global__ void __launch_bounds__(kSBlock)
 small_pool_bwd_kernel(SmallGraph g, const float* __restrict__ dpool, const uint8_t* __restrict__ arg,
                       const float* __restrict__ gc, int W, BnArgs bn, float* __restrict__ dA,
                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  if (g.diag & 1024) return;
   extern __shared__ float smem[];
   const int t = blockIdx.x;
   if (t >= g.n_tiles) return;
   const Tile tl = tile_of(g, t);
   const int q4 = W / 4;
-  float* sMean = smem;
-  float* sInv = smem + W;
-  float* red = smem + 2 * W;  // [16][2W] partial sums per row of the tile
-  for (int c = threadIdx.x; c < W; c += kSBlock) {
-    const BnCol b = bn_col(bn, W, c);
-    sMean[c] = b.mean;
-    sInv[c] = b.invstd;
-  }
-  __syncthreads();
+  float* red = smem;  // [16][2W] partial sums per row of the tile
   for (int idx = threadIdx.x; idx < kTileRows * q4; idx += kSBlock) {
     const int r = idx / q4, q = idx - r * q4;
     float4 d = make_float4(0.f, 0.f, 0.f, 0.f), dx = d;
@@ -893,19 +1077,33 @@ small_pool_bwd_kernel(SmallGraph g, const float* __restrict__ dpool, const uint8
       d.z = ((a >> 16) & 0xff) == 0 ? v.z : 0.f;
       d.w = (a >> 24) == 0 ? v.w : 0.f;
       const int e = tl.e0 + r * tl.d;
-      for (int j = 0; j < tl.d; ++j) {
-        const int nb = g.col_idx[e + j];
-        const uint32_t want = (uint32_t)g.rev_pos[e + j] + 1u;
-        const uint32_t an = *reinterpret_cast<const uint32_t*>(arg + (int64_t)nb * W + 4 * q);
-        const float4 vn = ld4(dpool + (int64_t)nb * W + 4 * q);
-        d.x += (an & 0xff) == want ? vn.x : 0.f;
-        d.y += ((an >> 8) & 0xff) == want ? vn.y : 0.f;
-        d.z += ((an >> 16) & 0xff) == want ? vn.z : 0.f;
-        d.w += (an >> 24) == want ? vn.w : 0.f;
+      for (int j0 = 0; j0 < tl.d; j0 += 4) {  // four neighbours per round: ids together, then their rows together
+        int nb[4];
+        uint32_t want[4], an[4];
+        float4 vn[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const bool in = j0 + t < tl.d;
+          nb[t] = in ? g.col_idx[e + j0 + t] : row;
+          want[t] = in ? (uint32_t)g.rev_pos[e + j0 + t] + 1u : 0xffffu;  // 0xffff matches no arg byte
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          an[t] = *reinterpret_cast<const uint32_t*>(arg + (int64_t)nb[t] * W + 4 * q);
+          vn[t] = ld4(dpool + (int64_t)nb[t] * W + 4 * q);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          d.x += (an[t] & 0xff) == want[t] ? vn[t].x : 0.f;
+          d.y += ((an[t] >> 8) & 0xff) == want[t] ? vn[t].y : 0.f;
+          d.z += ((an[t] >> 16) & 0xff) == want[t] ? vn[t].z : 0.f;
+          d.w += (an[t] >> 24) == want[t] ? vn[t].w : 0.f;
+        }
       }
       if (dA) st4(dA + (int64_t)row * W + 4 * q, d);
       const float4 x = ld4(gc + (int64_t)row * W + 4 * q);
-      const float4 mu = ld4(sMean + 4 * q), iv = ld4(sInv + 4 * q);
+      const BnQuad bq = bn_quad(bn, W, q);
+      const float4 mu = bq.mean, iv = bq.invstd;
       dx.x = d.x * (x.x - mu.x) * iv.x;
       dx.y = d.y * (x.y - mu.y) * iv.y;
       dx.z = d.z * (x.z - mu.z) * iv.z;
@@ -949,42 +1147,23 @@ struct ConvBwdArgs {
   int32_t slab_start[GCMI_MAX_DEG + 2];  // 64-row slabs per degree block, prefix
 };
 
-__device__ __forceinline__ void conv_dg_to_lds(const ConvBwdArgs& a, int row0, int nrows, int tile_rows,
-                                               const float* sA, const float* sB, const float* sC, float* sG,
+__device__ __forceinline__ void conv_dg_to_lds(const ConvBwdArgs& a, int row0, int nrows, int tile_rows, float* sG,
                                                int pitch) {
   const int W = a.W, q4 = W / 4;
   for (int idx = threadIdx.x; idx < tile_rows * q4; idx += kSBlock) {
     const int r = idx / q4, q = idx - r * q4;
     float4 dg = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < nrows) {
+      const BwdQuad cq = bn_bwd_quad(a.bn, a.dbeta, a.dgamma, W, q);
+      const float4 cA = cq.A, cB = cq.B, cC = cq.C;
       const float4 dy = ld4(a.dA + (int64_t)(row0 + r) * W + 4 * q);
       const float4 x = ld4(a.gc + (int64_t)(row0 + r) * W + 4 * q);
-      const float4 cA = ld4(sA + 4 * q), cB = ld4(sB + 4 * q), cC = ld4(sC + 4 * q);
       dg.x = x.x > 0.f ? fmaf(cA.x, dy.x, fmaf(cB.x, x.x, cC.x)) : 0.f;
       dg.y = x.y > 0.f ? fmaf(cA.y, dy.y, fmaf(cB.y, x.y, cC.y)) : 0.f;
       dg.z = x.z > 0.f ? fmaf(cA.z, dy.z, fmaf(cB.z, x.z, cC.z)) : 0.f;
       dg.w = x.w > 0.f ? fmaf(cA.w, dy.w, fmaf(cB.w, x.w, cC.w)) : 0.f;
     }
     st4(sG + r * pitch + 4 * q, dg);
-  }
-}
-
-__device__ __forceinline__ void conv_bwd_coeffs(const ConvBwdArgs& a, float* sA, float* sB, float* sC) {
-  for (int c = threadIdx.x; c < a.W; c += kSBlock) {
-    if (a.bn.mode == 0) {
-      sA[c] = 1.f;
-      sB[c] = 0.f;
-      sC[c] = 0.f;
-      continue;
-    }
-    const BnCol b = bn_col(a.bn, a.W, c);
-    const double inv_n = 1.0 / (double)a.bn.n_rows;
-    const double A = (double)a.bn.gamma[c] * (double)b.invstd;
-    const double B = -A * (double)b.invstd * (double)a.dgamma[c] * inv_n;
-    const double C = -A * (double)a.dbeta[c] * inv_n - B * (double)b.mean;
-    sA[c] = (float)A;
-    sB[c] = (float)B;
-    sC[c] = (float)C;
   }
 }
 
@@ -995,18 +1174,13 @@ small_conv_bwd_kernel(SmallGraph g, ConvBwdArgs a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lr = lane & 15, kq = lane >> 4;
   const int64_t blk = (int64_t)K * W;
-  float* sA = smem;
-  float* sB = smem + W;
-  float* sC = smem + 2 * W;
   int b = blockIdx.x;
   const int n_dgrad = a.dS ? g.n_tiles : 0;
   if (b < n_dgrad) {
     const Tile tl = tile_of(g, b);
     const int WP = pitch_a(W);
-    float* sG = smem + 3 * W;  // [16][WP]
-    conv_bwd_coeffs(a, sA, sB, sC);
-    __syncthreads();
-    conv_dg_to_lds(a, tl.row0, tl.nrows, kTileRows, sA, sB, sC, sG, WP);
+    float* sG = smem;  // [16][WP]
+    conv_dg_to_lds(a, tl.row0, tl.nrows, kTileRows, sG, WP);
     __syncthreads();
     const float* Wself = a.Wl + (tl.d == 0 ? (int64_t)(2 * g.max_deg) * blk : (int64_t)(2 * (tl.d - 1) + 1) * blk);
     const float* Wrel = tl.d == 0 ? nullptr : a.Wl + (int64_t)(2 * (tl.d - 1)) * blk;
@@ -1042,26 +1216,17 @@ small_conv_bwd_kernel(SmallGraph g, ConvBwdArgs a) {
   const int nrows = min(kSlabRows, g.deg_start[d + 1] - row0);
   const int e0 = g.edge_start[d] + (row0 - g.deg_start[d]) * d;
   const int WT = pitch_t(W), KT = pitch_t(K4);
-  float* sG = smem + 3 * W;             // [64][WT]
-  float* sX = sG + kSlabRows * WT;      // [64][KT] own rows
-  float* sS = sX + kSlabRows * KT;      // [64][KT] neighbour sums
-  conv_bwd_coeffs(a, sA, sB, sC);
-  __syncthreads();
-  conv_dg_to_lds(a, row0, nrows, kSlabRows, sA, sB, sC, sG, WT);
+  float* sG = smem;                     // [slab][WT]
+  float* sX = sG + kSlabRows * WT;      // [slab][KT] own rows
+  float* sS = sX + kSlabRows * KT;      // [slab][KT] neighbour sums
+  conv_dg_to_lds(a, row0, nrows, kSlabRows, sG, WT);
   const int q4 = K4 / 4;
   for (int idx = threadIdx.x; idx < kSlabRows * q4; idx += kSBlock) {
     const int r = idx / q4, q = idx - r * q4;
     float4 self = make_float4(0.f, 0.f, 0.f, 0.f), s = self;
     if (r < nrows) {
       self = ld4(a.x + (int64_t)(row0 + r) * a.ldx + 4 * q);
-      const int32_t* nb = g.col_idx + e0 + r * d;
-      for (int j = 0; j < d; ++j) {
-        const float4 v = ld4(a.x + (int64_t)nb[j] * a.ldx + 4 * q);
-        s.x += v.x;
-        s.y += v.y;
-        s.z += v.z;
-        s.w += v.w;
-      }
+      s = gather_sum_quad(a.x, a.ldx, g.col_idx + e0 + r * d, d, row0 + r, q);
     }
     st4(sX + r * KT + 4 * q, self);
     st4(sS + r * KT + 4 * q, s);
@@ -1127,14 +1292,11 @@ small_gather_add_kernel(SmallGraph g, const float* __restrict__ dXs, const float
     const int r = idx / q4, q = idx - r * q4;
     const int row = tl.row0 + r;
     float4 s = ld4(dXs + (int64_t)row * W + 4 * q);
-    const int32_t* nb = g.col_idx + tl.e0 + r * tl.d;
-    for (int j = 0; j < tl.d; ++j) {
-      const float4 v = ld4(dS + (int64_t)nb[j] * W + 4 * q);
-      s.x += v.x;
-      s.y += v.y;
-      s.z += v.z;
-      s.w += v.w;
-    }
+    const float4 n = gather_sum_quad(dS, W, g.col_idx + tl.e0 + r * tl.d, tl.d, row, q);
+    s.x += n.x;
+    s.y += n.y;
+    s.z += n.z;
+    s.w += n.w;
     st4(dP + (int64_t)row * W + 4 * q, s);
   }
 }
@@ -1311,6 +1473,8 @@ static int make_small_graph(const gcmi_graph* g, bool need_rev, SmallGraph* out)
     if (d <= g->max_deg) t += (g->deg_start[d + 1] - g->deg_start[d] + kTileRows - 1) / kTileRows;
   }
   s.n_tiles = t;
+  static const int diag = getenv("GCMI_SMALL_DIAG") ? atoi(getenv("GCMI_SMALL_DIAG")) : 0;
+  s.diag = diag;
   s.col_idx = g->d_col_idx;
   s.membership = g->d_membership;
   s.mol_runs = g->d_mol_runs;
@@ -1365,6 +1529,7 @@ static BnArgs bn_args(const SmallCtx& c, int layer, int n_rows) {
   b.beta = c.params + m->off_bn_beta[layer];
   b.eps = m->bn_eps;
   b.n_rows = n_rows;
+  b.inv_n = n_rows > 0 ? 1.0 / (double)n_rows : 0.0;
   return b;
 }
 
@@ -1459,7 +1624,10 @@ static int launch_readout(const SmallCtx& c, const SmallGraph& g, ReadoutArgs& a
   a.mode = m->mode;
   // per wave: fingerprint [2F], logits [TCp], dlogits [TCp], fingerprint gradient [2F] (TCp: TC rounded up to 4)
   const int TCp = (TC + 3) & ~3;
-  const size_t lds = sizeof(float) * 4 * (4 * F + 2 * TCp);
+  size_t lds = sizeof(float) * 4 * (4 * F + 2 * TCp);
+  const size_t wh_bytes = sizeof(float) * (size_t)TC * (2 * F + 4);
+  a.wh_in_lds = lds + wh_bytes <= 96 * 1024 ? 1 : 0;
+  if (a.wh_in_lds) lds += wh_bytes;
   const dim3 grid((g.n_mols + 3) / 4), block(kSBlock);
   switch (F) {
     case 64:

@@ -389,7 +389,7 @@ class GraphConvModel(TorchModel):
     # set to False to keep fit()/predict() on the per-batch path whatever the batch size
     small_batch_engine: bool = True
     # batches of a chunk (one C call); chunks end early at checkpoint steps
-    small_chunk_batches: int = 256
+    small_chunk_batches: int = 48
 
     def _packed_view(self, dataset, epochs, deterministic, pad_batches):
         """(packed molecule set, y, w, iterator of (molecule indices, real molecules) per batch) for the dataset
@@ -532,16 +532,25 @@ class GraphConvModel(TorchModel):
                     if (first + k) % self.log_frequency == 0:
                         window.close(first + k)
 
-        buf_idx, buf_real = [], []
+        from deepchem_amd.small import chunks_ahead
+        step0 = self._global_step
 
-        def flush():
-            if not buf_idx:
-                return
-            ch = collator.collate(buf_idx, buf_real)
-            sel = torch.from_numpy(np.concatenate(buf_idx)).to(self.device, non_blocking=True)
+        def cut_after(k):  # the optimizer step that a checkpoint follows ends its chunk
+            return interval > 0 and (step0 + k) % interval == interval - 1
+
+        def checked(batches):
+            for idx, n_real in batches:
+                if idx.shape[0] != B:
+                    raise ValueError("the small-batch engine needs padded batches")
+                yield idx, n_real
+
+        for host_chunk, at_checkpoint in chunks_ahead(collator, checked(index_batches), self.small_chunk_batches,
+                                                      cut_after):
+            ch = collator.to_device(host_chunk)
+            sel = torch.from_numpy(ch.sel).to(self.device, non_blocking=True)
             y_t = y_dev.index_select(0, sel)
             w_t = w_dev.index_select(0, sel)
-            for b, r in enumerate(buf_real):
+            for b, r in enumerate(ch.n_real):
                 if r < B:
                     w_t[b * B + r:(b + 1) * B] = 0  # padding rows of a ragged last batch carry no weight
             collator.bind(ch, [B] * ch.n_batches, labels=y_t, label_stride=label_stride, weights=w_t, weight_stride=T)
@@ -549,21 +558,9 @@ class GraphConvModel(TorchModel):
             held.hold(ch)
             pending.append((self._global_step + 1, losses))
             self._global_step += ch.n_batches
-            del buf_idx[:], buf_real[:]
             fold(False)
-
-        for idx, n_real in index_batches:
-            if idx.shape[0] != B:
-                raise ValueError("the small-batch engine needs padded batches")
-            buf_idx.append(idx)
-            buf_real.append(int(n_real))
-            step_after = self._global_step + len(buf_idx)
-            at_checkpoint = interval > 0 and step_after % interval == interval - 1
-            if len(buf_idx) >= self.small_chunk_batches or at_checkpoint:
-                flush()
-                if at_checkpoint:
-                    self.save_checkpoint(max_keep)
-        flush()
+            if at_checkpoint:
+                self.save_checkpoint(max_keep)
         fold(True)
         window.close(self._global_step)
         held.drain()

@@ -163,9 +163,11 @@ class ChunkCollator:
         self.atom_ptr = np.ascontiguousarray(packed.atom_ptr, np.int64)
         self.adj_ptr = np.ascontiguousarray(packed.adj_ptr, np.int64)
         self.adj_idx = np.ascontiguousarray(packed.adj_idx, np.int32)
-        self.ring = PinnedRing(3)
+        self.ring = PinnedRing(6)  # a worker may be two chunks ahead of the copies
 
-    def collate(self, idx_batches: Sequence[np.ndarray], n_real: Sequence[int]) -> Chunk:
+    def collate_host(self, idx_batches: Sequence[np.ndarray], n_real: Sequence[int]):
+        """The CPU half (may run on a worker thread: the native call releases the GIL): index batches -> one
+        pinned arena + per-batch graph structs and offsets."""
         lib = _lib.load()
         n = len(idx_batches)
         sel = np.ascontiguousarray(np.concatenate(idx_batches), np.int64)
@@ -181,19 +183,29 @@ class ChunkCollator:
         if words < 0:
             _lib.check(words, "gcmi_collate_batches_layout")
         arena = self.ring.get(words)[:words]
+        slot = self.ring._last
         graphs = (GcmiGraph * n)()
         sym = np.ones(n, np.int32)
         _lib.call("gcmi_collate_batches", self.feats.ctypes.data, self.n_feat, self.atom_ptr.ctypes.data,
                   self.adj_ptr.ctypes.data, self.adj_idx.ctypes.data, sel.ctypes.data, batch_ptr.ctypes.data, n,
                   self.max_deg, self.ld, self.mols_out, arena.data_ptr(), parts.ctypes.data, counts.ctypes.data,
                   ctypes.cast(graphs, ctypes.c_void_p), sym.ctypes.data, 0)
-        dev_arena = arena.to(self.device, non_blocking=True)
-        self.ring.mark()
+        return dict(n=n, sel=sel, parts=parts, counts=counts, arena=arena, slot=slot, graphs=graphs, sym=sym,
+                    n_real=[int(r) for r in n_real])
+
+    def to_device(self, h) -> Chunk:
+        """The stream half (consumer thread): one H2D copy, atom codes expanded by one launch."""
+        n, counts = h["n"], h["counts"]
+        dev_arena = h["arena"].to(self.device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self.ring.events[h["slot"]] = ev  # the pinned buffer may be refilled once this copy has run
         ch = Chunk()
         ch.n_batches = n
         ch.max_atoms = int(counts[:, 0].max()) if n else 0
-        ch.symmetric = bool(sym.all())
-        ch.n_real = [int(r) for r in n_real]
+        ch.symmetric = bool(h["sym"].all())
+        ch.n_real = h["n_real"]
+        ch.sel = h["sel"]
         rows = int(counts[-1, 2] + (counts[-1, 0] + 1) // 2 * 2) if n else 0
         if self.coded:
             from deepchem_amd import ops
@@ -203,8 +215,11 @@ class ChunkCollator:
         else:
             feats, ld = dev_arena, self.ld
         ch.keep = [dev_arena, feats]
-        ch._bind = (graphs, parts, counts, dev_arena, feats, ld)
+        ch._bind = (h["graphs"], h["parts"], counts, dev_arena, feats, ld)
         return ch
+
+    def collate(self, idx_batches: Sequence[np.ndarray], n_real: Sequence[int]) -> Chunk:
+        return self.to_device(self.collate_host(idx_batches, n_real))
 
     def bind(self, ch: Chunk, n_rows: Sequence[int], labels=None, label_stride=0, weights=None, weight_stride=0,
              logits=None, probs=None, logit_stride=0, fp=None, fp_stride=0) -> None:
@@ -244,3 +259,57 @@ class HeldChunks:
         if self.q:
             self.q[-1][0].synchronize()
         self.q.clear()
+
+
+def chunks_ahead(collator: ChunkCollator, index_batches, chunk_batches: int, cut_after=None, depth: int = 2):
+    """Iterate host-collated chunks (``collate_host`` results) produced by a worker thread ``depth`` chunks ahead of the
+    consumer.  ``cut_after(k)``: True when the k-th batch of the whole iteration (1-based) must end its chunk
+    (checkpoint steps)."""
+    import queue
+    import threading
+    q: "queue.Queue" = queue.Queue(maxsize=depth)
+    stop = threading.Event()
+
+    def put(item) -> bool:
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.05)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def work():
+        try:
+            buf_idx, buf_real, k = [], [], 0
+            for idx, n_real in index_batches:
+                if stop.is_set():
+                    return
+                k += 1
+                buf_idx.append(idx)
+                buf_real.append(int(n_real))
+                cut = cut_after is not None and cut_after(k)
+                if len(buf_idx) >= chunk_batches or cut:
+                    if not put((collator.collate_host(buf_idx, buf_real), cut)):
+                        return
+                    buf_idx, buf_real = [], []
+            if buf_idx:
+                if not put((collator.collate_host(buf_idx, buf_real), False)):
+                    return
+            put(None)
+        except BaseException as e:  # surface in the consumer
+            put(e)
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    try:
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+    finally:
+        stop.set()
+        th.join(timeout=5.0)

@@ -188,8 +188,10 @@ def test_real_tox21_training_tracks_the_reference(run):
     such trajectory after 650-4 000 steps; +-0.002 is asserted where it is meaningful (the test above: same
     parameters in, same AUC out).  Here: (1) the first 25 steps, before the noise has been amplified, follow the
     reference's per-step losses to 1e-3; (2) the whole loss curve stays with it (mean of the last 100 steps to
-    3 %); (3) the end point lies inside the reference's own perturbation envelope: mean valid AUC within 0.02,
-    every task within 0.05."""
+    3 %); (3) the end point lies inside the reference's own perturbation envelope, measured by that tool over
+    four perturbed CPU runs and committed as tests/golden/tox21_envelope_<run>.json: per-task and mean valid AUC
+    within twice the largest deviation those four runs showed among themselves (four samples underestimate the
+    spread of a maximum)."""
     from deepchem_amd.metrics import roc_auc_per_task
     import deepchem_amd as dc
     g = load_golden("tox21_ref.npz")
@@ -218,5 +220,9 @@ def test_real_tox21_training_tracks_the_reference(run):
     ref_auc = g[run + "_valid_auc"]
     print(run, "fit wall %.2f s (reference: %.1f s on %d cores)" % (wall, float(g[run + "_wall_s"]), int(g[run + "_cores"])),
           "mean valid AUC", np.nanmean(auc), "reference", np.nanmean(ref_auc), "max |dAUC|", np.nanmax(np.abs(auc - ref_auc)))
-    assert abs(np.nanmean(auc) - np.nanmean(ref_auc)) <= 0.02, (auc, ref_auc)
-    assert np.nanmax(np.abs(auc - ref_auc)) <= 0.05, (auc, ref_auc)
+    import json
+    with open(os.path.join(GOLDEN, "tox21_envelope_%s.json" % run)) as f:
+        env = json.load(f)
+    assert env["oracle_equals_reference_bitwise"]
+    assert abs(np.nanmean(auc) - np.nanmean(ref_auc)) <= 2 * max(env["d_mean_auc"]), (auc, ref_auc, env)
+    assert np.nanmax(np.abs(auc - ref_auc)) <= 2 * max(env["max_per_task_dauc"]), (auc, ref_auc, env)
