@@ -470,15 +470,18 @@ small_pool_dense_fwd_kernel(SmallGraph g, const float* __restrict__ gc, int K, B
   const int q4 = K / 4;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int lr = lane & 15, kq = lane >> 4;
-  constexpr int CH = NT <= 2 ? 16 : 8;
-  float bw[CH][NT];
-  auto load_w = [&](int ks0) {
+  // k order of the product: step (s, j) takes k = 16 s + 4 kq + j from lane group kq (any order sums the same
+  // terms; A and B use the same one), so a lane's four B values of a step group are ONE float4 of its row of Wd --
+  // a wave load touches 16 rows x 64 contiguous bytes instead of 16 rows x 16 bytes four times over
+  const int n_s = K / 16;  // K is a multiple of 64
+  constexpr int SG = NT <= 2 ? 4 : 2;  // step groups fetched ahead
+  float4 bw[SG][NT];
+  auto load_w = [&](int s0) {
 #pragma unroll
-    for (int u = 0; u < CH; ++u) {
-      int k = 4 * (ks0 + u) + kq;
-      k = k < K ? k : K - 1;
+    for (int u = 0; u < SG; ++u) {
+      const int sg = s0 + u < n_s ? s0 + u : n_s - 1;
 #pragma unroll
-      for (int i = 0; i < NT; ++i) bw[u][i] = Wd[(int64_t)(16 * (wave + 4 * i) + lr) * K + k];
+      for (int i = 0; i < NT; ++i) bw[u][i] = ld4(Wd + (int64_t)(16 * (wave + 4 * i) + lr) * K + 16 * sg + 4 * kq);
     }
   };
   load_w(0);  // in flight while the pooled tile is gathered
@@ -501,19 +504,24 @@ small_pool_dense_fwd_kernel(SmallGraph g, const float* __restrict__ gc, int K, B
   f4v c[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) c[i] = (f4v){0.f, 0.f, 0.f, 0.f};
-  for (int ks0 = 0; ks0 < q4 && !(g.diag & 8); ks0 += CH) {
-    float cw[CH][NT];
+  for (int s0 = 0; s0 < n_s && !(g.diag & 8); s0 += SG) {
+    float4 cw[SG][NT];
 #pragma unroll
-    for (int u = 0; u < CH; ++u)
+    for (int u = 0; u < SG; ++u)
 #pragma unroll
       for (int i = 0; i < NT; ++i) cw[u][i] = bw[u][i];
-    if (ks0 + CH < q4) load_w(ks0 + CH);
+    if (s0 + SG < n_s) load_w(s0 + SG);
 #pragma unroll
-    for (int u = 0; u < CH; ++u) {
-      if (ks0 + u < q4) {
-        const float a = sP[lr * KP + 4 * (ks0 + u) + kq];
+    for (int u = 0; u < SG; ++u) {
+      if (s0 + u < n_s) {
+        const float4 a4 = ld4(sP + lr * KP + 16 * (s0 + u) + 4 * kq);
 #pragma unroll
-        for (int i = 0; i < NT; ++i) c[i] = mfma16(a, cw[u][i], c[i]);
+        for (int i = 0; i < NT; ++i) {
+          c[i] = mfma16(a4.x, cw[u][i].x, c[i]);
+          c[i] = mfma16(a4.y, cw[u][i].y, c[i]);
+          c[i] = mfma16(a4.z, cw[u][i].z, c[i]);
+          c[i] = mfma16(a4.w, cw[u][i].w, c[i]);
+        }
       }
     }
   }
@@ -580,66 +588,76 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-// Lanes along the feature axis in float4 pieces: LPR = F / 4 lanes cover one row, 64 / LPR rows are read per
-// wave instruction; the molecule's rows (<= 11 contiguous runs) are enumerated up front so that the row loads of
-// several iterations are independent and in flight together.
+// One workgroup per molecule.  Lanes along the feature axis in float4 pieces: LPR = F / 4 lanes cover one row,
+// 64 / LPR rows per wave instruction; each of the four waves takes a quarter of the molecule's rows (<= 11
+// contiguous runs, enumerated up front so that eight wave-loads of rows are in flight together), the quarters
+// meet in LDS.  Head, loss and the gradient of the fingerprint are spread over all 256 threads, and every piece
+// of the head matrix a thread will need is requested at the top of the kernel: the kernel's memory round trips
+// are (1) parameters + run bounds, (2) rows.
 template <int LPR>  // F = 4 * LPR in {64, 128, 256}
 __global__ void __launch_bounds__(kSBlock)
 small_readout_kernel(SmallGraph g, ReadoutArgs a) {
   if (g.diag & 1024) return;
   extern __shared__ float smem[];
   constexpr int F = 4 * LPR, RPW = 64 / LPR, F2 = 2 * F;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int m = blockIdx.x * 4 + wave;
+  constexpr int NH4 = F2 / 32;       // float4 pieces of a head row per thread (8 column segments)
+  constexpr int SEG = F2 / 8;        // columns per segment
+  constexpr int ND = 6;              // head rows per thread fetched ahead for the fingerprint gradient
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int m = blockIdx.x;
   const int TC = a.T * a.C, TCp = (TC + 3) & ~3;
-  float* sfp = smem + wave * (2 * F2 + 2 * TCp);  // [2F] fingerprint, [TCp] logits, [TCp] dlogits, [2F] its gradient
-  float* slog = sfp + F2;
-  float* sdl = slog + TCp;
-  float* sgr = sdl + TCp;
-  // the head matrix, shared by the four molecules of the workgroup: all its loads go out at once, up front
-  const int WP = F2 + 4;
-  const float* whp = a.Wh;
-  int wh_ld = F2;
-  if (a.wh_in_lds) {
-    float* sWh = smem + 4 * (2 * F2 + 2 * TCp);
-    for (int idx = threadIdx.x; idx < TC * (F2 / 4); idx += kSBlock) {
-      const int tc = idx / (F2 / 4), q = idx - tc * (F2 / 4);
-      st4(sWh + tc * WP + 4 * q, ld4(a.Wh + (int64_t)tc * F2 + 4 * q));
-    }
-    __syncthreads();
-    whp = sWh;
-    wh_ld = WP;
-  }
-  if (m >= g.n_mols) return;
-  // what the tail of the kernel needs from memory, requested now: bias of this lane's first output, label pair and
-  // weight of this lane's first task
+  float* sfp = smem;                  // [2F] fingerprint
+  float* slog = sfp + F2;             // [TCp] logits
+  float* sdl = slog + TCp;            // [TCp] d loss / d logits
+  float* sgr = sdl + TCp;             // [2F] gradient w.r.t. the gather output
+  float* comb = sgr + F2;             // [4 waves][5][F]
+  float* part = comb + 20 * F;        // [8][TCp] head partial sums
+  float* gpart = part + 8 * TCp;      // [4][2F] gradient partial sums
   const bool train = a.labels != nullptr;
-  const float bh0 = (lane & 31) < TC ? a.bh[lane & 31] : 0.f;
+  // ---- requests that do not depend on the rows
+  const int tcl = tid & 31, fseg = tid >> 5;
+  float4 wh[NH4];
+#pragma unroll
+  for (int j = 0; j < NH4; ++j)
+    wh[j] = tcl < TC ? ld4(a.Wh + (int64_t)tcl * F2 + fseg * SEG + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int f4 = tid & 63, tcg = tid >> 6;
+  const int TQ = (TC + 3) / 4, tc_lo = tcg * TQ, tc_hi = min(TC, tc_lo + TQ);
+  float4 wd[ND];
+  if (train) {
+#pragma unroll
+    for (int j = 0; j < ND; ++j)
+      wd[j] = (tc_lo + j < tc_hi && 4 * f4 < F2) ? ld4(a.Wh + (int64_t)(tc_lo + j) * F2 + 4 * f4)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float bias0 = tid < TC ? a.bh[tid] : 0.f;
   float y_pre[2] = {0.f, 0.f}, w_pre = 1.f;
-  const bool pre = train && lane < a.T && (a.mode == 1 || a.C <= 2);
+  const bool pre = train && tid < a.T && (a.mode == 1 || a.C <= 2);
   if (pre) {
     if (a.mode == 0) {
-      y_pre[0] = a.labels[((int64_t)m * a.T + lane) * a.C];
-      if (a.C > 1) y_pre[1] = a.labels[((int64_t)m * a.T + lane) * a.C + 1];
+      y_pre[0] = a.labels[((int64_t)m * a.T + tid) * a.C];
+      if (a.C > 1) y_pre[1] = a.labels[((int64_t)m * a.T + tid) * a.C + 1];
     } else {
-      y_pre[0] = a.labels[(int64_t)m * a.T + lane];
+      y_pre[0] = a.labels[(int64_t)m * a.T + tid];
     }
-    if (a.weights) w_pre = a.weights[(int64_t)m * a.T + lane];
+    if (a.weights) w_pre = a.weights[(int64_t)m * a.T + tid];
   }
   const int fq = lane % LPR, grp = lane / LPR;  // this lane's 4 features, its row slot
   BnCol bn[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) bn[e] = bn_col(a.bn, F, 4 * fq + e);
-  // run bounds: lanes 0..21 hold them, then every lane derives the row of its list position
+  BnCol bnf = bn[0];
+  if (tid < F) bnf = bn_col(a.bn, F, tid);
   const int n_b = 2 * (g.max_deg + 1);
   const int rb = lane < n_b ? g.mol_runs[(int64_t)m * n_b + lane] : 0;
   int n_m = 0;
   for (int dd = 0; dd <= g.max_deg; ++dd) n_m += __shfl(rb, 2 * dd + 1) - __shfl(rb, 2 * dd);
+  // ---- rows: wave w takes list positions [w Q, (w + 1) Q)
   float s[4] = {0.f, 0.f, 0.f, 0.f}, raw[4] = {0.f, 0.f, 0.f, 0.f}, rawarg[4] = {0.f, 0.f, 0.f, 0.f};
   float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
   int arow[4] = {-1, -1, -1, -1};
-  for (int base = 0; base < n_m && !(g.diag & 32); base += 64) {
-    // row of list position base + lane (the walk order of segment max: degree blocks ascending, rows ascending)
+  const int Q = (n_m + 3) / 4;
+  const int p_lo = wave * Q, p_hi = min(n_m, p_lo + Q);
+  for (int base = p_lo; base < p_hi && !(g.diag & 32); base += 64) {
     int myrow = -1, pos = 0;
     for (int dd = 0; dd <= g.max_deg; ++dd) {
       const int b0 = __shfl(rb, 2 * dd), len = __shfl(rb, 2 * dd + 1) - b0;
@@ -647,7 +665,7 @@ small_readout_kernel(SmallGraph g, ReadoutArgs a) {
       if (j >= 0 && j < len) myrow = b0 + j;
       pos += len;
     }
-    const int cnt = min(64, n_m - base);
+    const int cnt = min(64, p_hi - base);
     for (int p = 0; p < cnt; p += 8 * RPW) {  // eight wave-loads of rows in flight
       float4 v4[8];
       int rr[8];
@@ -677,7 +695,7 @@ small_readout_kernel(SmallGraph g, ReadoutArgs a) {
       }
     }
   }
-  // combine the row slots: sums add; the maximum keeps the first row of the walk (= the lowest row index) on ties
+  // row slots of a wave: sums add; the maximum keeps the lowest row index on ties (= the first row of the walk)
 #pragma unroll
   for (int o = LPR; o < 64; o <<= 1) {
 #pragma unroll
@@ -695,45 +713,70 @@ small_readout_kernel(SmallGraph g, ReadoutArgs a) {
     }
   }
   if (grp == 0) {
-    float4 ts, tm;
-    ts.x = tanhf(s[0]); ts.y = tanhf(s[1]); ts.z = tanhf(s[2]); ts.w = tanhf(s[3]);
-    tm.x = tanhf(mx[0]); tm.y = tanhf(mx[1]); tm.z = tanhf(mx[2]); tm.w = tanhf(mx[3]);
-    st4(sfp + 4 * fq, ts);
-    st4(sfp + F + 4 * fq, tm);
-    st4(a.fp + (int64_t)m * F2 + 4 * fq, ts);
-    st4(a.fp + (int64_t)m * F2 + F + 4 * fq, tm);
+    float* cw = comb + wave * 5 * F;
+    st4(cw + 4 * fq, make_float4(s[0], s[1], s[2], s[3]));
+    st4(cw + F + 4 * fq, make_float4(raw[0], raw[1], raw[2], raw[3]));
+    st4(cw + 2 * F + 4 * fq, make_float4(mx[0], mx[1], mx[2], mx[3]));
+    st4(cw + 3 * F + 4 * fq, make_float4(rawarg[0], rawarg[1], rawarg[2], rawarg[3]));
+    *reinterpret_cast<int4*>(cw + 4 * F + 4 * fq) = make_int4(arow[0], arow[1], arow[2], arow[3]);
   }
-  if (g.diag & 64) return;
-  // task head: lane = (output tc mod 32, half of the 2F inputs); every lane reads its own row of Wh in float4
-  // pieces (independent loads), the fingerprint comes from LDS as a broadcast
-  {
-    const int tcl = lane & 31, half = lane >> 5;
-    for (int tc0 = 0; tc0 < TC; tc0 += 32) {
-      const int tc = tc0 + tcl;
-      float p = 0.f;
-      if (tc < TC) {
-        const float* wrow = whp + (int64_t)tc * wh_ld + half * F;
-        const float* frow = sfp + half * F;
-#pragma unroll 8
-        for (int f = 0; f < F; f += 4) {
-          const float4 w4 = ld4(wrow + f), x4 = ld4(frow + f);
-          p = fmaf(x4.x, w4.x, p);
-          p = fmaf(x4.y, w4.y, p);
-          p = fmaf(x4.z, w4.z, p);
-          p = fmaf(x4.w, w4.w, p);
-        }
-      }
-      p += __shfl_xor(p, 32);
-      if (half == 0 && tc < TC) {
-        const float v = p + (tc0 == 0 ? bh0 : a.bh[tc]);
-        slog[tc] = v;
-        a.logits[(int64_t)m * TC + tc] = v;
+  __syncthreads();
+  // ---- the four quarters meet: thread f owns feature f from here on
+  float f_raw = 0.f, f_rawarg = 0.f;
+  if (tid < F) {
+    float fs = 0.f, fmx = -INFINITY;
+    int frow = -1;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float* cw = comb + w * 5 * F;
+      fs += cw[tid];
+      f_raw += cw[F + tid];
+      const float omx = cw[2 * F + tid];
+      const int orow = reinterpret_cast<const int*>(cw + 4 * F)[tid];
+      if (omx > fmx || (omx == fmx && orow >= 0 && (frow < 0 || orow < frow))) {
+        fmx = omx;
+        frow = orow;
+        f_rawarg = cw[3 * F + tid];
       }
     }
+    const float ts = tanhf(fs), tm = tanhf(fmx);
+    sfp[tid] = ts;
+    sfp[F + tid] = tm;
+    a.fp[(int64_t)m * F2 + tid] = ts;
+    a.fp[(int64_t)m * F2 + F + tid] = tm;
+    if (train) a.argrow[(int64_t)m * F + tid] = frow;
   }
+  __syncthreads();
+  if (g.diag & 64) return;
+  // ---- task head: thread = (output tc mod 32, one of 8 column segments)
+  for (int tc0 = 0; tc0 < TC; tc0 += 32) {
+    const int tc = tc0 + tcl;
+    float p = 0.f;
+    if (tc < TC) {
+#pragma unroll
+      for (int j = 0; j < NH4; ++j) {
+        const float4 w4 = tc0 == 0 ? wh[j] : ld4(a.Wh + (int64_t)tc * F2 + fseg * SEG + 4 * j);
+        const float4 x4 = ld4(sfp + fseg * SEG + 4 * j);
+        p = fmaf(x4.x, w4.x, p);
+        p = fmaf(x4.y, w4.y, p);
+        p = fmaf(x4.z, w4.z, p);
+        p = fmaf(x4.w, w4.w, p);
+      }
+      part[fseg * TCp + tc] = p;
+    }
+  }
+  __syncthreads();
+  for (int tc = tid; tc < TC; tc += kSBlock) {
+    float v = tc == tid && tid < TC ? bias0 : a.bh[tc];
+#pragma unroll
+    for (int sgm = 0; sgm < 8; ++sgm) v += part[sgm * TCp + tc];
+    slog[tc] = v;
+    a.logits[(int64_t)m * TC + tc] = v;
+  }
+  __syncthreads();
   float lsum = 0.f;
-  for (int t = lane; t < a.T; t += 64) {
-    const bool use_pre = pre && t == lane;
+  for (int t = tid; t < a.T; t += kSBlock) {
+    const bool use_pre = pre && t == tid;
     if (a.mode == 0) {
       const float* x = slog + t * a.C;
       float mxl = -INFINITY;
@@ -766,43 +809,47 @@ small_readout_kernel(SmallGraph g, ReadoutArgs a) {
   if (!train) return;
   lsum = wave_sum(lsum);
   if (lane == 0 && lsum != 0.f && !(g.diag & 2)) atomicAdd(a.loss_acc, (double)lsum);
-  for (int tc = lane; tc < TC; tc += 64) a.dlogits[(int64_t)m * TC + tc] = sdl[tc];
-  // d fingerprint = dlogits . Wh through tanh; lane = 4 consecutive inputs, coalesced rows of Wh
+  __syncthreads();
+  for (int tc = tid; tc < TC; tc += kSBlock) a.dlogits[(int64_t)m * TC + tc] = sdl[tc];
+  // ---- d fingerprint = dlogits . Wh: thread = (4 consecutive inputs, a quarter of the outputs)
   for (int f0 = 0; f0 < F2; f0 += 256) {
-    const int f = f0 + 4 * lane;
-    if (f >= F2) break;
-    float4 gacc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 8
-    for (int tc = 0; tc < TC; ++tc) {
-      const float d = sdl[tc];
-      const float4 w4 = ld4(whp + (int64_t)tc * wh_ld + f);
-      gacc.x = fmaf(d, w4.x, gacc.x);
-      gacc.y = fmaf(d, w4.y, gacc.y);
-      gacc.z = fmaf(d, w4.z, gacc.z);
-      gacc.w = fmaf(d, w4.w, gacc.w);
-    }
-    const float4 y4 = ld4(sfp + f);
-    gacc.x *= (1.f - y4.x * y4.x);
-    gacc.y *= (1.f - y4.y * y4.y);
-    gacc.z *= (1.f - y4.z * y4.z);
-    gacc.w *= (1.f - y4.w * y4.w);
-    st4(a.g2 + (int64_t)m * F2 + f, gacc);
-    st4(sgr + f, gacc);  // read back below by the lanes that own the features
-  }
-  if (grp == 0) {
-    *reinterpret_cast<int4*>(a.argrow + (int64_t)m * F + 4 * fq) = make_int4(arow[0], arow[1], arow[2], arow[3]);
-    if (a.bsum && n_m > 0 && !(g.diag & 2)) {
-      const float4 gs4 = ld4(sgr + 4 * fq), gm4 = ld4(sgr + F + 4 * fq);
-      const float* gs = reinterpret_cast<const float*>(&gs4);
-      const float* gm = reinterpret_cast<const float*>(&gm4);
+    const int f = f0 + 4 * f4;
+    if (f < F2) {
+      float4 gacc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int tc = tc_lo; tc < tc_hi; ++tc) {
+        const float d = sdl[tc];
+        const int j = tc - tc_lo;
+        float4 w4;
+        if (f0 == 0 && j < ND) {
+          w4 = wd[0];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float sum_xhat = bn[e].invstd * (raw[e] - (float)n_m * bn[e].mean);
-        const float xhat_arg = (rawarg[e] - bn[e].mean) * bn[e].invstd;
-        atomicAdd(a.bsum + 4 * fq + e, (double)((float)n_m * gs[e] + gm[e]));
-        atomicAdd(a.bsum + F + 4 * fq + e, (double)(gs[e] * sum_xhat + gm[e] * xhat_arg));
+          for (int jj = 1; jj < ND; ++jj)
+            if (j == jj) w4 = wd[jj];
+        } else {
+          w4 = ld4(a.Wh + (int64_t)tc * F2 + f);
+        }
+        gacc.x = fmaf(d, w4.x, gacc.x);
+        gacc.y = fmaf(d, w4.y, gacc.y);
+        gacc.z = fmaf(d, w4.z, gacc.z);
+        gacc.w = fmaf(d, w4.w, gacc.w);
       }
+      st4(gpart + tcg * F2 + f, gacc);
     }
+  }
+  __syncthreads();
+  for (int f = tid; f < F2; f += kSBlock) {
+    const float y = sfp[f];
+    const float gsum = (gpart[f] + gpart[F2 + f] + gpart[2 * F2 + f] + gpart[3 * F2 + f]) * (1.f - y * y);
+    a.g2[(int64_t)m * F2 + f] = gsum;
+    sgr[f] = gsum;
+  }
+  __syncthreads();
+  if (tid < F && a.bsum && n_m > 0 && !(g.diag & 2)) {
+    const float gs = sgr[tid], gm = sgr[F + tid];
+    const float sum_xhat = bnf.invstd * (f_raw - (float)n_m * bnf.mean);
+    const float xhat_arg = (f_rawarg - bnf.mean) * bnf.invstd;
+    atomicAdd(a.bsum + tid, (double)((float)n_m * gs + gm));
+    atomicAdd(a.bsum + F + tid, (double)(gs * sum_xhat + gm * xhat_arg));
   }
 }
 
@@ -1622,13 +1669,12 @@ static int launch_readout(const SmallCtx& c, const SmallGraph& g, ReadoutArgs& a
   a.T = m->n_tasks;
   a.C = m->n_classes;
   a.mode = m->mode;
-  // per wave: fingerprint [2F], logits [TCp], dlogits [TCp], fingerprint gradient [2F] (TCp: TC rounded up to 4)
   const int TCp = (TC + 3) & ~3;
-  size_t lds = sizeof(float) * 4 * (4 * F + 2 * TCp);
-  const size_t wh_bytes = sizeof(float) * (size_t)TC * (2 * F + 4);
-  a.wh_in_lds = lds + wh_bytes <= 96 * 1024 ? 1 : 0;
-  if (a.wh_in_lds) lds += wh_bytes;
-  const dim3 grid((g.n_mols + 3) / 4), block(kSBlock);
+  // fingerprint [2F], logits + dlogits [2 TCp], gradient [2F], wave quarters [20 F], head partials [8 TCp],
+  // gradient partials [8 F]
+  const size_t lds = sizeof(float) * (size_t)(4 * F + 2 * TCp + 20 * F + 8 * TCp + 8 * F);
+  a.wh_in_lds = 0;
+  const dim3 grid(g.n_mols), block(kSBlock);
   switch (F) {
     case 64:
       SRUN(ensure_lds(small_readout_kernel<16>, lds));

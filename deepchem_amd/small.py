@@ -282,6 +282,7 @@ def chunks_ahead(collator: ChunkCollator, index_batches, chunk_batches: int, cut
     def work():
         try:
             buf_idx, buf_real, k = [], [], 0
+            limit = min(chunk_batches, 8)  # short first chunks: the GPU starts after 8 batches are collated, not 48
             for idx, n_real in index_batches:
                 if stop.is_set():
                     return
@@ -289,10 +290,11 @@ def chunks_ahead(collator: ChunkCollator, index_batches, chunk_batches: int, cut
                 buf_idx.append(idx)
                 buf_real.append(int(n_real))
                 cut = cut_after is not None and cut_after(k)
-                if len(buf_idx) >= chunk_batches or cut:
+                if len(buf_idx) >= limit or cut:
                     if not put((collator.collate_host(buf_idx, buf_real), cut)):
                         return
                     buf_idx, buf_real = [], []
+                    limit = min(chunk_batches, 2 * limit)
             if buf_idx:
                 if not put((collator.collate_host(buf_idx, buf_real), False)):
                     return
