@@ -162,6 +162,11 @@ _SIGNATURES = {
     "gcmi_edge_network_moments": [_P, c_int64, c_int32, c_int32, _P, c_int64, _P, _P, c_int32, _P, c_int64, _P],
     "gcmi_gru_gates": [_P, _P, _P, _P, c_int64, _P],
     "gcmi_gru_out": [_P, _P, _P, _P, c_int64, _P],
+    "gcmi_gru_gates_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P],
+    "gcmi_gru_out_bwd": [_P, _P, _P, _P, _P, _P, _P, c_int64, _P],
+    "gcmi_lstm_cell_bwd": [_P, c_int64, c_int32, c_int64, _P, _P, _P, _P, _P, _P],
+    "gcmi_set2set_attend_bwd": [_P, c_int64, c_int32, _P, c_int32, _P, c_int64, _P, c_int64, _P, c_int64, c_int32, _P,
+                                c_int64, _P],
     "gcmi_set2set_attend": [_P, c_int64, c_int32, _P, c_int32, _P, c_int64, _P, c_int64, _P],
     "gcmi_lstm_cell": [_P, c_int64, c_int32, c_int64, _P, c_int64, _P, c_int64, _P],
     "gcmi_model_forward": [_MD, _G, _P, _MIO, c_int32, _P],

@@ -219,6 +219,138 @@ __global__ void lstm_cell_kernel(const float* __restrict__ z, int64_t ldz, int n
   }
 }
 
+// ---------------------------------------------------------------- backward of the elementwise pieces
+// GRU gates: z = sig(zp), r = sig(rp), hr = h r.  Given dz (w.r.t. the z OUTPUT, from gru_out) and dhr:
+//   dzp = dz z (1 - z);  drp = dhr h r (1 - r);  dh = dhr r
+__global__ void gru_gates_bwd_kernel(const float* __restrict__ z, const float* __restrict__ r,
+                                     const float* __restrict__ h, const float* __restrict__ dz,
+                                     const float* __restrict__ dhr, float* __restrict__ dzp, float* __restrict__ drp,
+                                     float* __restrict__ dh, int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const float zz = z[e], rr = r[e], g = dhr[e];
+    dzp[e] = dz[e] * zz * (1.f - zz);
+    drp[e] = g * h[e] * rr * (1.f - rr);
+    dh[e] = g * rr;
+  }
+}
+
+// out = (1 - z) tanh(hpre) + z x:  dz = dout (x - t);  dhpre = dout (1 - z)(1 - t^2);  dx = dout z
+__global__ void gru_out_bwd_kernel(const float* __restrict__ z, const float* __restrict__ hpre,
+                                   const float* __restrict__ x, const float* __restrict__ dout,
+                                   float* __restrict__ dz, float* __restrict__ dhpre, float* __restrict__ dx,
+                                   int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const float t = tanhf(hpre[e]), g = dout[e], zz = z[e];
+    dz[e] = g * (x[e] - t);
+    dhpre[e] = g * (1.f - zz) * (1.f - t * t);
+    dx[e] = g * zz;
+  }
+}
+
+// LSTM cell backward.  Forward: i, f, o = sig(z[0:3H]), gg = tanh(z[3H:4H]); c' = f c + i gg; h' = o tanh(c').
+// Given dh' and dc' (gradient arriving at c' from the next step): dz (B x 4H) and dc (w.r.t. the incoming c).
+__global__ void lstm_cell_bwd_kernel(const float* __restrict__ z, int64_t ldz, int n_hidden, int64_t n_rows,
+                                     const float* __restrict__ c_prev, const float* __restrict__ dh,
+                                     const float* __restrict__ dc_next, float* __restrict__ dz,
+                                     float* __restrict__ dc_prev) {
+  const int64_t total = n_rows * n_hidden;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / n_hidden;
+    const int j = (int)(e - r * n_hidden);
+    const float* zr = z + r * ldz;
+    const float i = sigmoidf_(zr[j]), f = sigmoidf_(zr[n_hidden + j]), o = sigmoidf_(zr[2 * n_hidden + j]);
+    const float gg = tanhf(zr[3 * n_hidden + j]);
+    const float cp = c_prev[e];
+    const float tc = tanhf(f * cp + i * gg);
+    const float gh = dh[e];
+    const float dc = (dc_next ? dc_next[e] : 0.f) + gh * o * (1.f - tc * tc);
+    float* dzr = dz + r * 4 * n_hidden;
+    dzr[j] = dc * gg * i * (1.f - i);
+    dzr[n_hidden + j] = dc * cp * f * (1.f - f);
+    dzr[2 * n_hidden + j] = gh * tc * o * (1.f - o);
+    dzr[3 * n_hidden + j] = dc * i * (1.f - gg * gg);
+    dc_prev[e] = dc * f;
+  }
+}
+
+// set2set attention backward for one step.  Forward per molecule: e_a = <x_a, h>, w = softmax(e), r = sum_a w_a x_a,
+// q = [h | r].  Given dq = [dqh | dr]:  dw_a = <dr, x_a>;  de_a = w_a (dw_a - sum_b w_b dw_b);
+//   dx_a (+)= w_a dr + de_a h;   dh = dqh + sum_a de_a x_a.   One wave per molecule; the softmax is recomputed.
+__global__ void __launch_bounds__(kMpBlock)
+set2set_attend_bwd_kernel(const float* __restrict__ x, int64_t ldx, int n_feat, const int32_t* __restrict__ mol_ptr,
+                          int n_mols, const float* __restrict__ h, int64_t ldh, const float* __restrict__ dq,
+                          int64_t lddq, float* __restrict__ dx, int64_t lddx, int accumulate, float* __restrict__ dh,
+                          int64_t lddh) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * kMpBlock + threadIdx.x) >> 6;
+  const int n_waves = (gridDim.x * kMpBlock) >> 6;
+  constexpr int kPer = 8;
+  for (int m = wave; m < n_mols; m += n_waves) {
+    const int a0 = mol_ptr[m], a1 = mol_ptr[m + 1];
+    float hv[kPer], drv[kPer], dhacc[kPer];
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      const int f = lane + 64 * q;
+      hv[q] = f < n_feat ? h[(int64_t)m * ldh + f] : 0.f;
+      drv[q] = f < n_feat ? dq[(int64_t)m * lddq + n_feat + f] : 0.f;
+      dhacc[q] = f < n_feat ? dq[(int64_t)m * lddq + f] : 0.f;
+    }
+    float emax = -INFINITY;
+    for (int a = a0; a < a1; ++a) {
+      float part = 0.f;
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) {
+        const int f = lane + 64 * q;
+        if (f < n_feat) part = fmaf(x[(int64_t)a * ldx + f], hv[q], part);
+      }
+      emax = fmaxf(emax, wave_sum(part));
+    }
+    float denom = 0.f, wdw = 0.f;  // sum_b exp(e_b - max), sum_b exp(e_b - max) dw_b
+    for (int a = a0; a < a1; ++a) {
+      float pe = 0.f, pw = 0.f;
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) {
+        const int f = lane + 64 * q;
+        const float xv = f < n_feat ? x[(int64_t)a * ldx + f] : 0.f;
+        pe = fmaf(xv, hv[q], pe);
+        pw = fmaf(xv, drv[q], pw);
+      }
+      const float w = expf(wave_sum(pe) - emax);
+      denom += w;
+      wdw += w * wave_sum(pw);
+    }
+    const float inv = a1 > a0 ? 1.f / denom : 0.f;
+    const float mean_dw = wdw * inv;
+    for (int a = a0; a < a1; ++a) {
+      float xv[kPer], pe = 0.f, pw = 0.f;
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) {
+        const int f = lane + 64 * q;
+        xv[q] = f < n_feat ? x[(int64_t)a * ldx + f] : 0.f;
+        pe = fmaf(xv[q], hv[q], pe);
+        pw = fmaf(xv[q], drv[q], pw);
+      }
+      const float w = expf(wave_sum(pe) - emax) * inv;
+      const float de = w * (wave_sum(pw) - mean_dw);
+#pragma unroll
+      for (int q = 0; q < kPer; ++q) {
+        const int f = lane + 64 * q;
+        if (f < n_feat) {
+          const float g = fmaf(w, drv[q], de * hv[q]);
+          float* p = dx + (int64_t)a * lddx + f;
+          *p = accumulate ? *p + g : g;
+          dhacc[q] = fmaf(de, xv[q], dhacc[q]);
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      const int f = lane + 64 * q;
+      if (f < n_feat) dh[(int64_t)m * lddh + f] = dhacc[q];
+    }
+  }
+}
+
 }  // namespace gcmi
 
 using namespace gcmi;
@@ -299,6 +431,54 @@ int gcmi_lstm_cell(const float* d_z, int64_t ldz, int32_t n_hidden, int64_t n_ro
   hipLaunchKernelGGL(lstm_cell_kernel, dim3(grid_for(n_rows * n_hidden, 256)), dim3(256), 0, (hipStream_t)stream, d_z,
                      ldz, n_hidden, n_rows, d_c, ldc, d_h, ldh);
   GCMI_CHECK_LAUNCH("lstm_cell");
+  return GCMI_OK;
+}
+
+int gcmi_gru_gates_bwd(const float* d_z, const float* d_r, const float* d_h, const float* d_dz, const float* d_dhr,
+                       float* d_dzp, float* d_drp, float* d_dh, int64_t n, void* stream) {
+  GCMI_CHECK_ARG(n >= 0, "gru_gates_bwd: bad size");
+  if (n == 0) return GCMI_OK;
+  GCMI_CHECK_ARG(d_z && d_r && d_h && d_dz && d_dhr && d_dzp && d_drp && d_dh, "gru_gates_bwd: NULL buffer");
+  hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, d_z, d_r, d_h,
+                     d_dz, d_dhr, d_dzp, d_drp, d_dh, n);
+  GCMI_CHECK_LAUNCH("gru_gates_bwd");
+  return GCMI_OK;
+}
+
+int gcmi_gru_out_bwd(const float* d_z, const float* d_hpre, const float* d_x, const float* d_dout, float* d_dz,
+                     float* d_dhpre, float* d_dx, int64_t n, void* stream) {
+  GCMI_CHECK_ARG(n >= 0, "gru_out_bwd: bad size");
+  if (n == 0) return GCMI_OK;
+  GCMI_CHECK_ARG(d_z && d_hpre && d_x && d_dout && d_dz && d_dhpre && d_dx, "gru_out_bwd: NULL buffer");
+  hipLaunchKernelGGL(gru_out_bwd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, d_z, d_hpre, d_x,
+                     d_dout, d_dz, d_dhpre, d_dx, n);
+  GCMI_CHECK_LAUNCH("gru_out_bwd");
+  return GCMI_OK;
+}
+
+int gcmi_lstm_cell_bwd(const float* d_z, int64_t ldz, int32_t n_hidden, int64_t n_rows, const float* d_c_prev,
+                       const float* d_dh, const float* d_dc_next, float* d_dz, float* d_dc_prev, void* stream) {
+  GCMI_CHECK_ARG(n_hidden > 0 && n_rows >= 0 && ldz >= 4 * n_hidden, "lstm_cell_bwd: bad shape");
+  if (n_rows == 0) return GCMI_OK;
+  GCMI_CHECK_ARG(d_z && d_c_prev && d_dh && d_dz && d_dc_prev, "lstm_cell_bwd: NULL buffer");
+  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid_for(n_rows * n_hidden, 256)), dim3(256), 0, (hipStream_t)stream,
+                     d_z, ldz, n_hidden, n_rows, d_c_prev, d_dh, d_dc_next, d_dz, d_dc_prev);
+  GCMI_CHECK_LAUNCH("lstm_cell_bwd");
+  return GCMI_OK;
+}
+
+int gcmi_set2set_attend_bwd(const float* d_x, int64_t ldx, int32_t n_feat, const int32_t* d_mol_ptr, int32_t n_mols,
+                            const float* d_h, int64_t ldh, const float* d_dq, int64_t lddq, float* d_dx, int64_t lddx,
+                            int32_t accumulate, float* d_dh, int64_t lddh, void* stream) {
+  GCMI_CHECK_ARG(n_feat > 0 && n_feat <= 512 && n_mols >= 0 && ldx >= n_feat && ldh >= n_feat && lddq >= 2 * n_feat &&
+                     lddx >= n_feat && lddh >= n_feat,
+                 "set2set_attend_bwd: bad shape (n_feat <= 512)");
+  if (n_mols == 0) return GCMI_OK;
+  GCMI_CHECK_ARG(d_x && d_mol_ptr && d_h && d_dq && d_dx && d_dh, "set2set_attend_bwd: NULL buffer");
+  hipLaunchKernelGGL(set2set_attend_bwd_kernel, dim3(grid_for((int64_t)n_mols * 64, kMpBlock)), dim3(kMpBlock), 0,
+                     (hipStream_t)stream, d_x, ldx, n_feat, d_mol_ptr, n_mols, d_h, ldh, d_dq, lddq, d_dx, lddx,
+                     accumulate, d_dh, lddh);
+  GCMI_CHECK_LAUNCH("set2set_attend_bwd");
   return GCMI_OK;
 }
 

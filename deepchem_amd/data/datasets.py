@@ -26,6 +26,17 @@ import numpy as np
 Batch = Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]
 
 
+def pad_features(batch_size: int, X_b: np.ndarray) -> np.ndarray:
+    """``X_b`` tiled up to exactly ``batch_size`` entries (data/datasets.py:83-139): what the generators of the
+    batch-size-bound models (MPNN) do to the features of a short last batch."""
+    n = len(X_b)
+    if n > batch_size:
+        raise ValueError("Cannot pad an array longer than `batch_size`")
+    if n == batch_size:
+        return X_b
+    return X_b[np.arange(batch_size) % n]
+
+
 def pad_batch(batch_size: int, X_b, y_b, w_b, ids_b) -> Batch:
     """Tile X, y and ids up to ``batch_size`` rows (datasets.py:142-218); the weights of the padding
     rows are zero, so they do not count in the loss (they DO enter BatchNorm statistics, as in the

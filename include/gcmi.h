@@ -361,6 +361,20 @@ int gcmi_edge_network_sum(const float* d_g, int64_t ldg, int32_t n_hidden, int32
 int gcmi_edge_network_moments(const float* d_h, int64_t ldh, int32_t n_hidden, int32_t n_pair_feat,
                               const float* d_pair_feat, int64_t ldp, const int32_t* d_dst_ptr, const int32_t* d_src,
                               int32_t n_dst, float* d_t, int64_t ldt, void* stream);
+/* Backward of the same pieces (the training step of MPNNModel, models/graph_models.py:1045-1247; forward
+ * formulas models/layers.py:3755-3887).  gru_gates_bwd: dzp = dz z(1-z), drp = dhr h r(1-r), dh = dhr r;
+ * gru_out_bwd: dz = dout (x - tanh hpre), dhpre = dout (1-z)(1-tanh^2), dx = dout z; lstm_cell_bwd: dz (rows x 4H,
+ * gate order i, f, o, g) and dc of the incoming cell state from dh', dc' (NULL = 0); set2set_attend_bwd: dx (written,
+ * or added to when accumulate != 0) and dh from dq = [dh | dr], softmax recomputed.                          */
+int gcmi_gru_gates_bwd(const float* d_z, const float* d_r, const float* d_h, const float* d_dz, const float* d_dhr,
+                       float* d_dzp, float* d_drp, float* d_dh, int64_t n, void* stream);
+int gcmi_gru_out_bwd(const float* d_z, const float* d_hpre, const float* d_x, const float* d_dout, float* d_dz,
+                     float* d_dhpre, float* d_dx, int64_t n, void* stream);
+int gcmi_lstm_cell_bwd(const float* d_z, int64_t ldz, int32_t n_hidden, int64_t n_rows, const float* d_c_prev,
+                       const float* d_dh, const float* d_dc_next, float* d_dz, float* d_dc_prev, void* stream);
+int gcmi_set2set_attend_bwd(const float* d_x, int64_t ldx, int32_t n_feat, const int32_t* d_mol_ptr, int32_t n_mols,
+                            const float* d_h, int64_t ldh, const float* d_dq, int64_t lddq, float* d_dx, int64_t lddx,
+                            int32_t accumulate, float* d_dh, int64_t lddh, void* stream);
 int gcmi_gru_gates(float* d_z, float* d_r, const float* d_h, float* d_hr, int64_t n, void* stream);
 int gcmi_gru_out(const float* d_z, const float* d_hpre, const float* d_x, float* d_out, int64_t n, void* stream);
 int gcmi_set2set_attend(const float* d_x, int64_t ldx, int32_t n_feat, const int32_t* d_mol_ptr, int32_t n_mols,

@@ -94,3 +94,65 @@ def ccc_pair_features(center_last: bool = True) -> Tuple[np.ndarray, np.ndarray,
     C0, C1 = np.meshgrid(np.arange(n), np.arange(n))
     a2p = np.transpose(np.array([C1.flatten(), C0.flatten()]))
     return atoms, pairs.reshape(n * n, 14), a2p
+
+
+# ---------------------------------------------------------------------------------------------- the whole model
+class MPNNOracle:
+    """MPNNModel (deepchem/models/graph_models.py:1045-1247) restated on torch-CPU tensors with autograd:
+    MessagePassing (T rounds of edge_network + gru, models/layers.py:3648-3799; zero padding of the atom features
+    up to n_hidden), Dense(n_hidden), SetGather (M rounds), Dense(2 n_hidden, relu), task head, L2Loss /
+    SoftmaxCrossEntropy through _StandardLoss.  ``params``: the state_dict of deepchem_amd's ``_MPNNTorchModel``
+    (nn.Linear weights are (out, in)).  MODEL-LEVEL PARITY IS UNPINNED: the Keras model cannot run here (no
+    TensorFlow) and the torch MPNNModel is dgllife's; the sub-layers this composes are pinned above."""
+
+    def __init__(self, params, n_atom_feat, n_hidden, T, M, batch_size, mode="regression", n_tasks=1, n_classes=2):
+        self.p = {k: v.detach().clone().float().requires_grad_(True) for k, v in params.items()}
+        self.n_atom_feat, self.d, self.T, self.M, self.B = n_atom_feat, n_hidden, T, M, batch_size
+        self.mode, self.n_tasks, self.n_classes = mode, n_tasks, n_classes
+
+    def forward(self, atom_features, pair_features, atom_split, atom_to_pair, n_samples):
+        p, d = self.p, self.d
+        x = torch.as_tensor(np.asarray(atom_features)).float()
+        pf = torch.as_tensor(np.asarray(pair_features)).float()
+        a2p = torch.as_tensor(np.asarray(atom_to_pair)).long()
+        split = torch.as_tensor(np.asarray(atom_split)).long()
+        n = x.shape[0]
+        h = torch.cat([x, torch.zeros((n, d - x.shape[1]))], 1)
+        for _ in range(self.T):
+            A = (pf @ p["edge_W"] + p["edge_b"]).reshape(-1, d, d)
+            msg = torch.matmul(A, h[a2p[:, 1]].unsqueeze(2)).squeeze(2)
+            m = torch.zeros((n, d)).index_add(0, a2p[:, 0], msg)
+            z = torch.sigmoid(m @ p["gru_Wz"] + h @ p["gru_Uz"] + p["gru_bz"])
+            r = torch.sigmoid(m @ p["gru_Wr"] + h @ p["gru_Ur"] + p["gru_br"])
+            h = (1 - z) * torch.tanh(m @ p["gru_Wh"] + (h * r) @ p["gru_Uh"] + p["gru_bh"]) + z * m
+        emb = h @ p["atom_embed.weight"].t() + p["atom_embed.bias"]
+        c = torch.zeros((self.B, d))
+        hs = torch.zeros((self.B, d))
+        q_star = None
+        for _ in range(self.M):
+            e = (emb * hs[split]).sum(-1)
+            a = torch.zeros_like(e)
+            for mol in range(self.B):
+                mask = split == mol
+                if mask.any():
+                    a = a + torch.zeros_like(e).masked_scatter(mask, torch.softmax(e[mask], 0))
+            r = torch.zeros((self.B, d)).index_add(0, split, a.reshape(-1, 1) * emb)
+            q_star = torch.cat([hs, r], 1)
+            hs, c = lstm_step(q_star, c, p["set_U"], p["set_b"], d)
+        dense1 = torch.relu(q_star @ p["dense1.weight"].t() + p["dense1.bias"])
+        out = dense1 @ p["head.weight"].t() + p["head.bias"]
+        if self.mode == "classification":
+            logits = out.reshape(-1, self.n_tasks, self.n_classes)[:n_samples]
+            return [torch.softmax(logits, -1), logits]
+        return [out[:n_samples]]
+
+    def loss(self, outputs, labels, weights):
+        y = torch.as_tensor(np.asarray(labels)).float()
+        w = torch.as_tensor(np.asarray(weights)).float()
+        if self.mode == "classification":
+            losses = -(y * torch.log_softmax(outputs[1], -1)).sum(-1)
+        else:
+            losses = (outputs[0] - y.reshape(outputs[0].shape)) ** 2
+        if w.dim() < losses.dim():
+            w = w.reshape(tuple(w.shape) + (1,) * (losses.dim() - w.dim()))
+        return (losses * w).mean()

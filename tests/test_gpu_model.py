@@ -135,7 +135,21 @@ def dataset_from(g):
 
 
 @pytest.mark.parametrize("name", MODEL_FIXTURES)
-def test_first_batch_outputs_loss_grads(name):
+@pytest.mark.parametrize("gemm", ["exact", "fast"])
+def test_first_batch_outputs_loss_grads(name, gemm):
+    """Outputs, loss and every parameter gradient of the first batch against the reference's own (fixtures).
+    Gradients: 1e-4 of the tensor's largest entry on the exact-fp32 products (north_star's bound); 1e-3 on the
+    split-bf16 products, whose per-product error is the same (tools/gemm_accuracy.py) but whose rounding differs
+    from the reference's, which is enough to move an arg-max of a pool or a ReLU boundary of single atoms."""
+    import deepchem_amd
+    deepchem_amd.set_gemm_mode(gemm)
+    try:
+        _first_batch_outputs_loss_grads(name, 1e-4 if gemm == "exact" else 1e-3)
+    finally:
+        deepchem_amd.set_gemm_mode("fast")
+
+
+def _first_batch_outputs_loss_grads(name, grad_tol):
     g = load_golden("model_%s.npz" % name)
     for gm in ("reference", "full"):
         model, cfg, state = build_model(g, gm)
@@ -169,11 +183,11 @@ def test_first_batch_outputs_loss_grads(name):
             gk = got[k].cpu().numpy()
             if full in g.files:
                 scale = max(np.abs(g[full]).max(), 1e-6)
-                assert np.abs(gk - g[full]).max() / scale < 1e-3, (gm, k)
+                assert np.abs(gk - g[full]).max() / scale < grad_tol, (gm, k, float(np.abs(gk - g[full]).max() / scale))
             else:
                 from oracle.gen_golden import sample
                 exp = g["%s_gradsample__%s" % (gm, k)]
-                assert np.abs(sample(gk) - exp).max() / max(np.abs(exp).max(), 1e-6) < 1e-3, (gm, k)
+                assert np.abs(sample(gk) - exp).max() / max(np.abs(exp).max(), 1e-6) < grad_tol, (gm, k)
         # BatchNorm running statistics after one training forward
         tr = O.OracleTrainer(cfg, state, grad_mode=gm)
         cpu_inputs = [t.cpu() for t in inputs]
