@@ -208,7 +208,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB
+    # GCMI_HOST_ONLY_LIB: a sanitizer build of the host-side sources only (tools/asan_host.sh); the kernels'
+    # entry points are absent from it and anything that needs them fails with AttributeError
+    host_only = os.environ.get("GCMI_HOST_ONLY_LIB")
+    path = host_only or _build.LIB
     if not os.path.exists(path):
         try:
             _build.build_lib(verbose=False)
@@ -220,19 +223,25 @@ def load():
         lib = ctypes.CDLL(path)
     except OSError as e:
         raise GcmiError("cannot load %s: %s" % (path, e))
-    lib.gcmi_version.restype = ctypes.c_int
-    lib.gcmi_last_error.restype = c_char_p
-    lib.gcmi_model_workspace_floats.restype = c_int64
-    lib.gcmi_model_workspace_floats.argtypes = [_MD, c_int64, c_int64]
-    lib.gcmi_collate_batches_layout.restype = c_int64
-    lib.gcmi_collate_batches_layout.argtypes = [_P, _P, _P, _P, c_int64, c_int64, c_int32, c_int64, _P, _P]
-    lib.gcmi_small_workspace_floats.restype = c_int64
-    lib.gcmi_small_workspace_floats.argtypes = [_MD, c_int64, c_int64]
-    lib.gcmi_smiles_check.restype = c_char_p
-    lib.gcmi_collate_plan_words.restype = c_int64
-    lib.gcmi_collate_plan_words.argtypes = [c_int64]
-    lib.gcmi_smiles_check.argtypes = [c_char_p]
+    special = {
+        "gcmi_version": (ctypes.c_int, None),
+        "gcmi_last_error": (c_char_p, None),
+        "gcmi_model_workspace_floats": (c_int64, [_MD, c_int64, c_int64]),
+        "gcmi_collate_batches_layout": (c_int64, [_P, _P, _P, _P, c_int64, c_int64, c_int32, c_int64, _P, _P]),
+        "gcmi_small_workspace_floats": (c_int64, [_MD, c_int64, c_int64]),
+        "gcmi_smiles_check": (c_char_p, [c_char_p]),
+        "gcmi_collate_plan_words": (c_int64, [c_int64]),
+    }
+    for name, (restype, argtypes) in special.items():
+        if host_only and not hasattr(lib, name):
+            continue
+        fn = getattr(lib, name)
+        fn.restype = restype
+        if argtypes is not None:
+            fn.argtypes = argtypes
     for name, argtypes in _SIGNATURES.items():
+        if host_only and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int

@@ -115,6 +115,7 @@ def test_device_expansion_covers_every_row_of_a_large_batch():
     assert np.array_equal(out[:, :75], want) and not out[:, 75].any()
 
 
+@pytest.mark.gpu
 def test_training_on_codes_equals_training_on_floats():
     from deepchem_amd.models.torch_models import GraphConvModel
     smiles = _sample_smiles()
