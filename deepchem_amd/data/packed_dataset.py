@@ -343,11 +343,19 @@ class DeviceBatchPipeline:
                 except StopIteration:
                     state["exhausted"] = True
                     return None
+                except BaseException as e:  # the batch source failed: every batch before this one is still delivered
+                    state["exhausted"] = True
+                    with cond:
+                        if state["error"] is None:
+                            state["error"] = (state["taken"], e)
+                        cond.notify_all()
+                    return None
                 seq = state["taken"]
                 state["taken"] += 1
                 return seq, idx, n_real
 
         def work():
+            seq = None
             try:
                 torch.cuda.set_device(dev)
                 stream = torch.cuda.Stream(device=dev)
@@ -358,6 +366,7 @@ class DeviceBatchPipeline:
                             cond.wait(0.05)
                     if stop.is_set():
                         break
+                    seq = None
                     job = take()
                     if job is None:
                         break
@@ -366,9 +375,11 @@ class DeviceBatchPipeline:
                     with cond:
                         results[seq] = item
                         cond.notify_all()
-            except BaseException as e:  # surface worker errors in the consumer
+            except BaseException as e:  # surface worker errors in the consumer, at the batch they belong to
                 with cond:
-                    state["error"] = e
+                    at = seq if seq is not None else state["taken"]
+                    if state["error"] is None or at < state["error"][0]:
+                        state["error"] = (at, e)
                     cond.notify_all()
             finally:
                 with cond:
@@ -383,11 +394,13 @@ class DeviceBatchPipeline:
             seq = 0
             while True:
                 with cond:
-                    while seq not in results and state["error"] is None and state["alive"] > 0:
+                    def failed_here():
+                        return state["error"] is not None and state["error"][0] <= seq
+                    while seq not in results and not failed_here() and state["alive"] > 0:
                         cond.wait(0.05)
-                    if state["error"] is not None:
-                        raise state["error"]
                     if seq not in results:
+                        if state["error"] is not None:
+                            raise state["error"][1]  # batches before the failing one have all been handed out
                         break  # every worker has finished and this batch was never produced: end of the stream
                     batch, y_t, w_t, ev = results.pop(seq)
                     state["consumed"] += 1

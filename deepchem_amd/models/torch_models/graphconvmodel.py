@@ -547,9 +547,8 @@ class GraphConvModel(TorchModel):
         for host_chunk, at_checkpoint in chunks_ahead(collator, checked(index_batches), self.small_chunk_batches,
                                                       cut_after):
             ch = collator.to_device(host_chunk)
-            sel = torch.from_numpy(ch.sel).to(self.device, non_blocking=True)
-            y_t = y_dev.index_select(0, sel)
-            w_t = w_dev.index_select(0, sel)
+            y_t = y_dev.index_select(0, ch.sel_dev)
+            w_t = w_dev.index_select(0, ch.sel_dev)
             for b, r in enumerate(ch.n_real):
                 if r < B:
                     w_t[b * B + r:(b + 1) * B] = 0  # padding rows of a ragged last batch carry no weight

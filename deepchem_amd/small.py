@@ -182,16 +182,20 @@ class ChunkCollator:
                                                     parts.ctypes.data, counts.ctypes.data))
         if words < 0:
             _lib.check(words, "gcmi_collate_batches_layout")
-        arena = self.ring.get(words)[:words]
+        # the molecule indices ride behind the arena (int64 pairs of words): one pinned H2D copy carries everything a
+        # chunk needs -- a separate copy from pageable memory would block the host until the stream has drained
+        total = words + 2 * int(sel.shape[0]) + 4
+        arena = self.ring.get(total)[:total]
         slot = self.ring._last
+        arena[words:].numpy().view(np.int64)[:sel.shape[0]] = sel
         graphs = (GcmiGraph * n)()
         sym = np.ones(n, np.int32)
         _lib.call("gcmi_collate_batches", self.feats.ctypes.data, self.n_feat, self.atom_ptr.ctypes.data,
                   self.adj_ptr.ctypes.data, self.adj_idx.ctypes.data, sel.ctypes.data, batch_ptr.ctypes.data, n,
                   self.max_deg, self.ld, self.mols_out, arena.data_ptr(), parts.ctypes.data, counts.ctypes.data,
                   ctypes.cast(graphs, ctypes.c_void_p), sym.ctypes.data, 0)
-        return dict(n=n, sel=sel, parts=parts, counts=counts, arena=arena, slot=slot, graphs=graphs, sym=sym,
-                    n_real=[int(r) for r in n_real])
+        return dict(n=n, sel=sel, words=words, parts=parts, counts=counts, arena=arena, slot=slot, graphs=graphs,
+                    sym=sym, n_real=[int(r) for r in n_real])
 
     def to_device(self, h) -> Chunk:
         """The stream half (consumer thread): one H2D copy, atom codes expanded by one launch."""
@@ -206,6 +210,7 @@ class ChunkCollator:
         ch.symmetric = bool(h["sym"].all())
         ch.n_real = h["n_real"]
         ch.sel = h["sel"]
+        ch.sel_dev = dev_arena[h["words"]:].view(torch.int64)[:h["sel"].shape[0]]
         rows = int(counts[-1, 2] + (counts[-1, 0] + 1) // 2 * 2) if n else 0
         if self.coded:
             from deepchem_amd import ops

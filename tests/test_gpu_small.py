@@ -56,6 +56,20 @@ def _device_batches(model, packed, y, w, cfg, B):
     return out
 
 
+def _same_after_adam(key, got, want, n_steps, is_param, lr=1e-3):
+    """Parameters after a few Adam steps.  Adam moves every entry by about lr per step in the direction of
+    g / (|g| + eps): an entry whose gradient is at rounding-noise level can go either way, so single entries may
+    differ by up to 2 lr per step whatever the implementation; a systematic error shows in the typical entry.
+    Buffers (running statistics) are plain averages and must agree tightly."""
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64))
+    scale = max(np.abs(want).max(), 1e-3)
+    if not is_param:
+        assert err.max() <= 2e-4 * scale, (key, float(err.max()), scale)
+        return
+    assert err.max() <= 2.2 * lr * n_steps, (key, float(err.max()))
+    assert np.median(err) <= 2e-4 * scale and np.mean(err) <= 1e-3 * scale, (key, float(np.median(err)), float(np.mean(err)))
+
+
 CASES = [
     ("classification", 12, 10, 48, True, "reference"),
     ("classification", 12, 10, 48, True, "full"),
@@ -91,12 +105,11 @@ def test_small_engine_training_matches_the_oracle(mode, T, B, n, bn, grad_mode):
             ref.append(tr.train_step(inputs, labels, weights))
     assert np.allclose(losses, ref, rtol=2e-4, atol=1e-6), (losses, ref)
     sd = model.model.state_dict()
+    n_steps = 2 * len(batches)
     for k, v in tr.state.items():
         got = sd[k].detach().float().cpu().numpy()
         want = v.detach().float().numpy()
-        scale = max(np.abs(want).max(), 1e-3)
-        tol = 2e-3 if O.is_parameter(k) else 2e-4  # Adam turns tiny gradient differences into lr-sized steps
-        assert np.abs(got - want).max() <= tol * scale, (k, float(np.abs(got - want).max()), scale)
+        _same_after_adam(k, got, want, n_steps, O.is_parameter(k))
     # untrained parameters did not move in reference mode
     if grad_mode == "reference":
         for k in state:
@@ -183,5 +196,4 @@ def test_small_engine_other_widths():
     sd, rsd = model.model.state_dict(), ref_model.model.state_dict()
     for k in sd:
         a, b = sd[k].float().cpu().numpy(), rsd[k].float().cpu().numpy()
-        # (zero-initialised biases sit at +-lr after one Adam step: an absolute floor keeps the bound meaningful)
-        assert np.abs(a - b).max() <= 2e-3 * max(np.abs(b).max(), 1e-2), k
+        _same_after_adam(k, a, b, len(batches), "running" not in k and "num_batches" not in k)

@@ -37,6 +37,15 @@ def main():
         print("\n%d dispatches matching %r: span %.1f us, busy %.1f us (%.1f %%), median gap %.2f us, p90 %.2f us, max %.1f us"
               % (len(sel), flt, span / 1e3, busy / 1e3, 100.0 * busy / span, gaps_sorted[len(gaps) // 2] / 1e3,
                  gaps_sorted[int(len(gaps) * 0.9)] / 1e3, gaps_sorted[-1] / 1e3))
+    if "--gaps" in sys.argv and len(sel) > 1:
+        k = int(sys.argv[sys.argv.index("--gaps") + 1])
+        big = sorted(range(len(sel) - 1), key=lambda i: -(sel[i + 1][1] - sel[i][2]))[:k]
+        total_gap = sum(max(0, sel[i + 1][1] - sel[i][2]) for i in range(len(sel) - 1))
+        print("\nidle between matching dispatches: %.1f us in all; the %d largest gaps (us, at us since first, after -> before):"
+              % (total_gap / 1e3, k))
+        for i in sorted(big):
+            print("  %9.1f  @%10.1f  %s -> %s" % ((sel[i + 1][1] - sel[i][2]) / 1e3, (sel[i][2] - sel[0][1]) / 1e3,
+                                                 sel[i][0].split("(")[0][-40:], sel[i + 1][0].split("(")[0][-40:]))
     if n_tl:
         mid = len(sel) // 2
         t0 = sel[mid][1]
