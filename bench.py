@@ -74,22 +74,29 @@ def gather_sum_bytes(n_atoms, n_edges, n_deg0, feats, accumulate):
     return b
 
 
-def measured_traffic(launches_per_step):
-    """HBM bytes per gather-sum launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 +
-    WRITE_SIZE, tools/pmc_traffic.py) -- counters cannot be read from inside the process."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            kernels = json.load(f)["kernels"]
-    except (OSError, ValueError, KeyError):
-        return None
-    tot, n = 0, 0
-    for name, rec in kernels.items():
-        if "SumOp" in name and "hbm_bytes_per_launch" in rec:
-            k = rec.get("fetch_launches", 1)
-            tot += rec["hbm_bytes_per_launch"] * k
-            n += k
-    return int(tot / n) if n else None
+def measured_traffic():
+    """HBM bytes per gather-sum launch from the newest committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json:
+    FETCH_SIZE x2 + WRITE_SIZE per the gfx950 corrections of MI355X_MICROARCH.md, separate passes, tools/pmc_passes.sh
+    over THIS command with --profile-only) -- counters cannot be read from inside the process.  Returns
+    (bytes per launch, file name) or (None, None)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    files = [f for f in files if "R1" not in os.path.basename(f)]
+    for path in reversed(files):
+        try:
+            with open(path) as f:
+                kernels = json.load(f)["kernels"]
+        except (OSError, ValueError, KeyError):
+            continue
+        tot, n = 0, 0
+        for name, rec in kernels.items():
+            if "SumOp" in name and "hbm_bytes_per_launch" in rec:
+                k = rec.get("fetch_launches", 1)
+                tot += rec["hbm_bytes_per_launch"] * k
+                n += k
+        if n:
+            return int(tot / n), os.path.basename(path)
+    return None, None
 
 
 def make_workload(args, rank, device, batch):
@@ -142,7 +149,7 @@ def usable_cores() -> int:
     return max(1, min(n, 64))
 
 
-def cpu_baseline(args, seconds):
+def cpu_baseline(args, seconds, batch=100, faithful=True, grad_mode="reference"):
     """The oracle's training step (reference-faithful ops, reference gradient cut, Adam) at the
     reference's default batch size on pre-collated batches; threads = all host cores."""
     from deepchem_amd.feat.mol_graphs import collate_packed
@@ -150,12 +157,12 @@ def cpu_baseline(args, seconds):
     from oracle import graphconv_oracle as O
     cores = usable_cores()
     torch.set_num_threads(cores)
-    B = 100
-    n_batches = 8
+    B = batch
+    n_batches = 8 if batch <= 1000 else 2
     packed = synthetic_molecules(B * n_batches, seed=77)
     y, w = synthetic_labels(B * n_batches, args.tasks, "classification", seed=77)
     cfg = O.ModelConfig(args.tasks, batch_size=B)
-    tr = O.OracleTrainer(cfg, O.init_state(cfg, 0), grad_mode="reference", faithful=True)
+    tr = O.OracleTrainer(cfg, O.init_state(cfg, 0), grad_mode=grad_mode, faithful=faithful)
     batches = []
     for b in range(n_batches):
         sel = np.arange(b * B, (b + 1) * B)
@@ -175,9 +182,10 @@ def cpu_baseline(args, seconds):
         "unit": "molecules/s",
         "cores": cores,
         "kind": "port",
-        "sample": "%d training steps (fwd+bwd+Adam, reference grad semantics, batch %d, pre-collated "
+        "sample": "%d training steps (fwd+bwd+Adam, grad_mode=%s, %s segment max, batch %d, pre-collated "
                   "Tox21-like synthetic batches, %d tasks) in %.1f s; torch threads=%d" %
-                  (steps, B, args.tasks, wall, torch.get_num_threads()),
+                  (steps, grad_mode, "faithful O(B N F)" if faithful else "O(N F)", B, args.tasks, wall,
+                   torch.get_num_threads()),
     }
 
 
@@ -357,6 +365,7 @@ def main():
         launches_per_step = 3
     n_launch, ms = gather_time
     achieved = (per_step * args.steps) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    traffic, traffic_file = measured_traffic()
 
     out = {
         "metric": "molecules/sec fwd+bwd GraphConvModel",
@@ -383,13 +392,19 @@ def main():
             "parallelism": "dp%d (molecules sharded by rank, one flat all-reduce per step)" % world,
         },
         "roofline": {
-            "kernel": "gather_sum_kernel (GraphConv.sum_neigh and its backward)",
+            "kernel": "win_kernel<512, {16|19}, false, SumOp> (gather_lds.hip: GraphConv.sum_neigh over LDS molecule "
+                      "windows, forward of both layers and the backward of layer 1)",
             "bound": "hbm",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": measured_traffic(launches_per_step),
+            "traffic": traffic,
+            "traffic_source": traffic_file,
+            # the same launches priced by the bytes they actually move (every atom row is read from HBM once and the
+            # ~3-fold re-reads of SURVEY 8d's count are served from LDS): PMC bytes per launch / measured launch time
+            "achieved_real": round(traffic / (ms * 1e-3 / max(n_launch, 1)) / 1e9, 1) if traffic and ms > 0 else None,
+            "frac_real": round(traffic / (ms * 1e-3 / max(n_launch, 1)) / 1e9 / HBM_PEAK_GBS, 4) if traffic and ms > 0 else None,
             "algorithmic_bytes_per_step": int(per_step),
             "launches_per_step": launches_per_step,
             "avg_launch_us": round(ms * 1e3 / max(n_launch, 1), 2),
@@ -474,12 +489,28 @@ def main():
         out["config"]["fit_molecules_per_s_batch_%d_atom_codes" % args.batch] = round(
             fit_epochs * big.n_mols / (time.perf_counter() - t1), 1)
 
+    if rank == 0 and world == 1 and not args.profile_only and args.gemm_mode == "fast":
+        # the same step on the exact-fp32 matrix-core chain (the arithmetic whose trajectories track the reference)
+        deepchem_amd.set_gemm_mode("exact")
+        try:
+            run_steps(model, dbatch, labels, weights, 2)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_steps(model, dbatch, labels, weights, 5)
+            torch.cuda.synchronize()
+            out["config"]["value_exact_gemm_mode"] = round(args.batch * 5 / (time.perf_counter() - t1), 1)
+        finally:
+            deepchem_amd.set_gemm_mode("fast")
     if rank == 0 and world == 1 and args.fit_pipeline:
         real = tox21_real(device)
         if real is not None:
             out["config"]["tox21_real"] = real
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        # beside it (not the headline baseline): the oracle at a large batch, where its O(B N F) faithful segment max
+        # cannot finish -- the same results by the O(N F) form (faithful=False), same gradient mode as the GPU line
+        out["cpu_baseline_large_batch"] = cpu_baseline(args, min(args.cpu_seconds, 10.0), batch=4096, faithful=False,
+                                                       grad_mode=args.grad_mode)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
