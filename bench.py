@@ -215,7 +215,7 @@ TOX21_TASKS = ['NR-AR', 'NR-AR-LBD', 'NR-AhR', 'NR-Aromatase', 'NR-ER', 'NR-ER-L
                'SR-ATAD5', 'SR-HSE', 'SR-MMP', 'SR-p53']
 
 
-def tox21_real(device, epochs=3):
+def tox21_real(device, epochs=10):
     """BASELINE.json config 2 on the real file (tests/golden/tox21.csv.gz, a copy of the reference tree's
     datasets/tox21.csv.gz): MolNet recipe -- native featurizer, index split 80/10/10, BalancingTransformer -- and
     fit() / predict() timed end to end (shuffle, collation, H2D, every optimizer step) at MolNet's preset batch 64

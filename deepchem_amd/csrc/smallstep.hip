@@ -25,6 +25,9 @@
 // (torch_model.py:435-443), over MANY batches per call: the host loop here replaces the Python loop.
 #include <math.h>
 
+#include <mutex>
+#include <vector>
+
 #include "common.h"
 
 namespace gcmi {
@@ -35,6 +38,8 @@ constexpr int kTileRows = 16;
 constexpr int kSlabRows = 32;
 constexpr int kSBlock = 256;
 constexpr int kMaxL = GCMI_MAX_CONV_LAYERS;
+constexpr int kAhead = 8;            // conv stacks computed ahead per group (reference gradient mode)
+constexpr int kSlots = 2 * kAhead;   // two sets of them
 
 // A collated batch as the kernels see it (by value in the kernarg segment).
 struct SmallGraph {
@@ -1367,8 +1372,10 @@ struct StepEnd {
   float* rm[kMaxL + 1];
   float* rv[kMaxL + 1];
   int64_t* tracked[kMaxL + 1];
-  double* zero_from;       // accumulator region to clear for the next step
+  double* zero_from;       // accumulator regions to clear for the next step that uses them
   int64_t zero_doubles;
+  double* zero2_from;
+  int64_t zero2_doubles;
 };
 
 __global__ void __launch_bounds__(kSBlock)
@@ -1412,6 +1419,7 @@ small_step_end_kernel(StepEnd s) {
   }
   __syncthreads();
   for (int64_t i = threadIdx.x; i < s.zero_doubles; i += kSBlock) s.zero_from[i] = 0.0;
+  for (int64_t i = threadIdx.x; i < s.zero2_doubles; i += kSBlock) s.zero2_from[i] = 0.0;
 }
 
 }  // namespace gcmi
@@ -1422,11 +1430,15 @@ namespace gcmi {
 static inline int64_t up4s(int64_t n) { return (n + 3) / 4 * 4; }
 
 struct SmallWs {  // offsets in floats into the workspace
-  int64_t gc[kMaxL], pool[kMaxL], arg[kMaxL], dA[kMaxL];
+  // GraphConv outputs and their BatchNorm sums exist in kSlots copies: in reference gradient mode the conv stack of
+  // a later step depends on nothing an earlier step trains, so the stacks of the next kAhead steps run on a second
+  // stream while the current group of steps finishes on the caller's (two sets of kAhead slots)
+  int64_t gc[kSlots][kMaxL], pool[kMaxL], arg[kMaxL], dA[kMaxL];
   int64_t dense, fp, logits, dlogits, g2, argrow, dpool, dS, dXs;
-  int64_t acc0;                 // start of the fp64 accumulator region
-  int64_t acc[kMaxL + 1];       // doubles, relative to acc0: [sum | sumsq] per BatchNorm layer
-  int64_t bsum, loss;           // doubles, relative to acc0
+  int64_t acc0;                   // start of the fp64 accumulator region
+  int64_t acc[kSlots][kMaxL];     // doubles, relative to acc0: [sum | sumsq] per GraphConv BatchNorm and slot
+  int64_t acc_dense, bsum, loss;  // doubles, relative to acc0: dense-layer sums, its backward sums, the loss
+  int64_t par_begin[kSlots], par_doubles, shared_begin, shared_doubles;
   int64_t acc_doubles;
   int64_t total;
 };
@@ -1444,7 +1456,7 @@ static SmallWs small_carve(const gcmi_model_desc* m, int64_t N, int64_t B) {
   int64_t wmax = 0;
   for (int l = 0; l < L; ++l) {
     const int64_t W = m->conv_width[l];
-    w.gc[l] = take(N * W);
+    for (int p = 0; p < kSlots; ++p) w.gc[p][l] = take(N * W);
     w.pool[l] = take(N * W);
     w.arg[l] = take((N * W + 3) / 4);
     w.dA[l] = take(N * W);
@@ -1463,16 +1475,22 @@ static SmallWs small_carve(const gcmi_model_desc* m, int64_t N, int64_t B) {
   off = (off + 3) / 4 * 4;
   w.acc0 = off;
   int64_t d = 0;
-  for (int l = 0; l < L; ++l) {
-    w.acc[l] = d;
-    d += 2 * m->conv_width[l];
+  for (int p = 0; p < kSlots; ++p) {
+    w.par_begin[p] = d;
+    for (int l = 0; l < L; ++l) {
+      w.acc[p][l] = d;
+      d += 2 * m->conv_width[l];
+    }
   }
-  w.acc[L] = d;
+  w.par_doubles = w.par_begin[1] - w.par_begin[0];
+  w.shared_begin = d;
+  w.acc_dense = d;
   d += 2 * F;
   w.bsum = d;
   d += 2 * F;
   w.loss = d;
   d += 2;
+  w.shared_doubles = d - w.shared_begin;
   w.acc_doubles = d;
   off += 2 * d;
   w.total = off;
@@ -1561,7 +1579,13 @@ struct SmallCtx {
   double* accs;
   hipStream_t st;
   bool training;
+  int parity;
 };
+
+static inline float* gc_of(const SmallCtx& c, int l) { return c.ws + c.w.gc[c.parity][l]; }
+static inline double* acc_of(const SmallCtx& c, int l) {
+  return c.accs + (l < c.m->n_layers ? c.w.acc[c.parity][l] : c.w.acc_dense);
+}
 
 static BnArgs bn_args(const SmallCtx& c, int layer, int n_rows) {
   BnArgs b;
@@ -1569,7 +1593,7 @@ static BnArgs bn_args(const SmallCtx& c, int layer, int n_rows) {
   const gcmi_model_desc* m = c.m;
   if (!m->batch_norm) return b;
   b.mode = c.training ? 1 : 2;
-  b.acc = c.accs + c.w.acc[layer];
+  b.acc = acc_of(c, layer);
   b.rm = c.io->d_bn_running_mean[layer];
   b.rv = c.io->d_bn_running_var[layer];
   b.gamma = c.params + m->off_bn_gamma[layer];
@@ -1609,8 +1633,8 @@ static int launch_conv_fwd(const SmallGraph& g, const float* x, int ldx, int K, 
   return GCMI_OK;
 }
 
-// conv / pool stack + dense; leaves the dense output in the workspace
-static int small_forward_body(const SmallCtx& c, const SmallGraph& g, const float* x, int64_t ldx) {
+// the GraphConv stack (with the pools between the layers) on `st`
+static int small_conv_stack(const SmallCtx& c, const SmallGraph& g, const float* x, int64_t ldx, hipStream_t st) {
   const gcmi_model_desc* m = c.m;
   const int L = m->n_layers;
   const int N = g.n_atoms;
@@ -1620,31 +1644,40 @@ static int small_forward_body(const SmallCtx& c, const SmallGraph& g, const floa
                  "small: atom features must be 16-byte aligned rows (ld %lld for %d columns)", (long long)ldx, K);
   for (int l = 0; l < L; ++l) {
     const int W = m->conv_width[l];
-    double* acc = (m->batch_norm && c.training) ? c.accs + c.w.acc[l] : nullptr;
+    double* acc = (m->batch_norm && c.training) ? acc_of(c, l) : nullptr;
     if (l == 0) {
       BnArgs none;
       memset(&none, 0, sizeof(none));
-      SRUN(launch_conv_fwd(g, x, (int)ldx, K, c.params + m->off_conv_w[l], c.params + m->off_conv_b[l], W,
-                           c.ws + c.w.gc[l], acc, false, none, nullptr, nullptr, c.st));
+      SRUN(launch_conv_fwd(g, x, (int)ldx, K, c.params + m->off_conv_w[l], c.params + m->off_conv_b[l], W, gc_of(c, l),
+                           acc, false, none, nullptr, nullptr, st));
     } else {
       // the GraphPool between the layers is computed by the consumer's gather; its rows and arg-max are written
       // only when a backward pass will read them ("full" gradient mode)
       const bool keep = c.training && m->grad_mode == 1;
-      SRUN(launch_conv_fwd(g, c.ws + c.w.gc[l - 1], K, K, c.params + m->off_conv_w[l], c.params + m->off_conv_b[l], W,
-                           c.ws + c.w.gc[l], acc, true, bn_args(c, l - 1, N), keep ? c.ws + c.w.pool[l - 1] : nullptr,
-                           keep ? reinterpret_cast<uint8_t*>(c.ws + c.w.arg[l - 1]) : nullptr, c.st));
+      SRUN(launch_conv_fwd(g, gc_of(c, l - 1), K, K, c.params + m->off_conv_w[l], c.params + m->off_conv_b[l], W,
+                           gc_of(c, l), acc, true, bn_args(c, l - 1, N), keep ? c.ws + c.w.pool[l - 1] : nullptr,
+                           keep ? reinterpret_cast<uint8_t*>(c.ws + c.w.arg[l - 1]) : nullptr, st));
     }
     K = W;
   }
+  return GCMI_OK;
+}
+
+// last pool + dense layer; leaves the dense output in the workspace
+static int small_dense_stage(const SmallCtx& c, const SmallGraph& g) {
+  const gcmi_model_desc* m = c.m;
+  const int L = m->n_layers;
+  const int N = g.n_atoms;
+  if (g.n_tiles == 0) return GCMI_OK;
   const int Wl = m->conv_width[L - 1], F = m->dense_width;
-  double* accD = (m->batch_norm && c.training) ? c.accs + c.w.acc[L] : nullptr;
+  double* accD = (m->batch_norm && c.training) ? acc_of(c, L) : nullptr;
   const size_t lds = sizeof(float) * (2 * Wl + kTileRows * pitch_a(Wl));
   uint8_t* arg = c.training ? reinterpret_cast<uint8_t*>(c.ws + c.w.arg[L - 1]) : nullptr;
   const float* Wd = c.params + m->off_dense_w;
   const float* bd = c.params + m->off_dense_b;
   const dim3 grid(g.n_tiles), block(kSBlock);
 #define PD(NT)                                                                                                      \
-  hipLaunchKernelGGL(small_pool_dense_fwd_kernel<NT>, grid, block, lds, c.st, g, c.ws + c.w.gc[L - 1], Wl,           \
+  hipLaunchKernelGGL(small_pool_dense_fwd_kernel<NT>, grid, block, lds, c.st, g, gc_of(c, L - 1), Wl,                \
                      bn_args(c, L - 1, N), c.ws + c.w.pool[L - 1], arg, Wd, bd, c.ws + c.w.dense, accD)
   switch (F / 64) {
     case 1: PD(1); break;
@@ -1655,6 +1688,11 @@ static int small_forward_body(const SmallCtx& c, const SmallGraph& g, const floa
 #undef PD
   GCMI_CHECK_LAUNCH("small_pool_dense_fwd");
   return GCMI_OK;
+}
+
+static int small_forward_body(const SmallCtx& c, const SmallGraph& g, const float* x, int64_t ldx) {
+  SRUN(small_conv_stack(c, g, x, ldx, c.st));
+  return small_dense_stage(c, g);
 }
 
 static int launch_readout(const SmallCtx& c, const SmallGraph& g, ReadoutArgs& a) {
@@ -1757,7 +1795,7 @@ static int small_backward(const SmallCtx& c, const SmallGraph& g, const gcmi_sma
     const int K = l == 0 ? m->n_feat_in : m->conv_width[l - 1];
     float* dA = full ? c.ws + c.w.dA[l] : nullptr;
     hipLaunchKernelGGL(small_pool_bwd_kernel, dim3(g.n_tiles), dim3(kSBlock), sizeof(float) * (2 * W + kTileRows * 2 * W),
-                       c.st, g, dpool, reinterpret_cast<const uint8_t*>(c.ws + c.w.arg[l]), c.ws + c.w.gc[l], W,
+                       c.st, g, dpool, reinterpret_cast<const uint8_t*>(c.ws + c.w.arg[l]), gc_of(c, l), W,
                        bn_args(c, l, N), dA, m->batch_norm ? grads + m->off_bn_gamma[l] : nullptr,
                        m->batch_norm ? grads + m->off_bn_beta[l] : nullptr);
     GCMI_CHECK_LAUNCH("small_pool_bwd");
@@ -1765,7 +1803,7 @@ static int small_backward(const SmallCtx& c, const SmallGraph& g, const gcmi_sma
     ConvBwdArgs cb;
     memset(&cb, 0, sizeof(cb));
     cb.dA = dA;
-    cb.gc = c.ws + c.w.gc[l];
+    cb.gc = gc_of(c, l);
     cb.bn = bn_args(c, l, N);
     cb.dgamma = m->batch_norm ? grads + m->off_bn_gamma[l] : nullptr;
     cb.dbeta = m->batch_norm ? grads + m->off_bn_beta[l] : nullptr;
@@ -1799,6 +1837,30 @@ static int small_backward(const SmallCtx& c, const SmallGraph& g, const gcmi_sma
     dpool = c.ws + c.w.dpool;
   }
   return GCMI_OK;
+}
+
+// the second stream of gcmi_small_fit and its events: created once per process (one process per GPU)
+struct SideStream {
+  hipStream_t st;
+  hipEvent_t ev_start, ev_conv[2], ev_free[2];
+};
+static SideStream* side_stream() {
+  static std::mutex mu;
+  static SideStream* s = nullptr;
+  static bool failed = false;
+  std::lock_guard<std::mutex> lock(mu);
+  if (s || failed) return s;
+  SideStream* n = new SideStream();
+  bool ok = hipStreamCreateWithFlags(&n->st, hipStreamNonBlocking) == hipSuccess;
+  hipEvent_t* evs[5] = {&n->ev_start, &n->ev_conv[0], &n->ev_conv[1], &n->ev_free[0], &n->ev_free[1]};
+  for (int i = 0; ok && i < 5; ++i) ok = hipEventCreateWithFlags(evs[i], hipEventDisableTiming) == hipSuccess;
+  if (!ok) {
+    failed = true;  // no overlap then: the one-stream path is always valid
+    delete n;
+    return nullptr;
+  }
+  s = n;
+  return s;
 }
 
 }  // namespace gcmi
@@ -1837,6 +1899,7 @@ int gcmi_small_fit(const gcmi_model_desc* m, float* d_params, float* d_grads, fl
   c.accs = reinterpret_cast<double*>(c.ws + c.w.acc0);
   c.st = (hipStream_t)stream;
   c.training = true;
+  c.parity = 0;
   if (m->batch_norm)
     for (int l = 0; l <= L; ++l)
       GCMI_CHECK_ARG(io->d_bn_running_mean[l] && io->d_bn_running_var[l], "small_fit: NULL running statistics");
@@ -1846,6 +1909,12 @@ int gcmi_small_fit(const gcmi_model_desc* m, float* d_params, float* d_grads, fl
     set_error("small_fit: memset failed");
     return GCMI_ERR_LAUNCH;
   }
+  // Reference gradient mode trains nothing the GraphConv stack reads (frozen weights, frozen BatchNorm 0..L-2), so
+  // the stack of step i+1 runs on a second stream while step i's dense layer, readout, backward and Adam run on the
+  // caller's; the two parities of the conv outputs / statistics keep them apart.  (GCMI_SMALL_OVERLAP=0: one stream.)
+  static const bool overlap_env = !(getenv("GCMI_SMALL_OVERLAP") && atoi(getenv("GCMI_SMALL_OVERLAP")) == 0);
+  SideStream* side = (!full && overlap_env && n_batches > 1) ? side_stream() : nullptr;
+  std::vector<SmallGraph> graphs((size_t)n_batches);
   for (int64_t i = 0; i < n_batches; ++i) {
     const gcmi_small_batch* b = batches + i;
     GCMI_CHECK_ARG(b->graph.n_atoms <= ws_atoms && b->graph.n_mols <= ws_mols,
@@ -1856,9 +1925,46 @@ int gcmi_small_fit(const gcmi_model_desc* m, float* d_params, float* d_grads, fl
     GCMI_CHECK_ARG(b->graph.n_atoms == 0 || b->d_atom_features, "small_fit: NULL atom features");
     GCMI_CHECK_ARG(b->graph.max_deg == m->max_deg, "small_fit: graph max_deg %d != model max_deg %d", b->graph.max_deg,
                    m->max_deg);
-    SmallGraph g;
-    SRUN(make_small_graph(&b->graph, true, &g));
-    SRUN(small_forward_body(c, g, b->d_atom_features, b->ld_features));
+    SRUN(make_small_graph(&b->graph, true, &graphs[(size_t)i]));
+  }
+  auto slot_of = [](int64_t i) { return (int)(((i / kAhead) & 1) * kAhead + i % kAhead); };
+  const int64_t n_groups = (n_batches + kAhead - 1) / kAhead;
+  auto conv_group = [&](int64_t k) -> int {  // the conv stacks of group k on the side stream
+    const int set = (int)(k & 1);
+    if (k >= 2 && hipStreamWaitEvent(side->st, side->ev_free[set], 0) != hipSuccess) return GCMI_ERR_LAUNCH;
+    for (int64_t i = k * kAhead; i < std::min(n_batches, (k + 1) * kAhead); ++i) {
+      SmallCtx cc = c;
+      cc.parity = slot_of(i);
+      SRUN(small_conv_stack(cc, graphs[(size_t)i], batches[i].d_atom_features, batches[i].ld_features, side->st));
+    }
+    if (hipEventRecord(side->ev_conv[set], side->st) != hipSuccess) return GCMI_ERR_LAUNCH;
+    return GCMI_OK;
+  };
+  if (side) {
+    // the side stream starts behind everything queued on the caller's stream so far (copies, the memsets above)
+    if (hipEventRecord(side->ev_start, c.st) != hipSuccess || hipStreamWaitEvent(side->st, side->ev_start, 0) != hipSuccess) {
+      set_error("small_fit: event record / wait failed");
+      return GCMI_ERR_LAUNCH;
+    }
+    SRUN(conv_group(0));
+  }
+  for (int64_t i = 0; i < n_batches; ++i) {
+    const gcmi_small_batch* b = batches + i;
+    const SmallGraph& g = graphs[(size_t)i];
+    c.parity = side ? slot_of(i) : 0;
+    if (side) {
+      if (i % kAhead == 0) {
+        const int64_t k = i / kAhead;
+        if (k + 1 < n_groups) SRUN(conv_group(k + 1));
+        if (hipStreamWaitEvent(c.st, side->ev_conv[k & 1], 0) != hipSuccess) {
+          set_error("small_fit: stream wait failed");
+          return GCMI_ERR_LAUNCH;
+        }
+      }
+      SRUN(small_dense_stage(c, g));
+    } else {
+      SRUN(small_forward_body(c, g, b->d_atom_features, b->ld_features));
+    }
     ReadoutArgs ra;
     memset(&ra, 0, sizeof(ra));
     ra.fp = c.ws + c.w.fp;
@@ -1900,20 +2006,27 @@ int gcmi_small_fit(const gcmi_model_desc* m, float* d_params, float* d_grads, fl
     se.n_rows = g.n_atoms;
     se.momentum = m->bn_momentum;
     for (int l = 0; l <= L; ++l) {
-      se.acc[l] = c.accs + c.w.acc[l];
+      se.acc[l] = acc_of(c, l);
       se.width[l] = l < L ? m->conv_width[l] : m->dense_width;
       se.rm[l] = io->d_bn_running_mean[l];
       se.rv[l] = io->d_bn_running_var[l];
       se.tracked[l] = io->d_bn_batches_tracked[l];
     }
-    se.zero_from = c.accs;
-    se.zero_doubles = c.w.acc_doubles;
+    se.zero_from = c.accs + c.w.par_begin[c.parity];
+    se.zero_doubles = c.w.par_doubles;
+    se.zero2_from = c.accs + c.w.shared_begin;
+    se.zero2_doubles = c.w.shared_doubles;
     const int64_t n4 = (hi - lo) / 4;
     int blocks = (int)((n4 + kSBlock - 1) / kSBlock);
     if (blocks < 1) blocks = 1;
     if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(small_step_end_kernel, dim3(blocks), dim3(kSBlock), 0, c.st, se);
     GCMI_CHECK_LAUNCH("small_step_end");
+    if (side && ((i + 1) % kAhead == 0 || i + 1 == n_batches) &&
+        hipEventRecord(side->ev_free[(i / kAhead) & 1], c.st) != hipSuccess) {
+      set_error("small_fit: event record failed");
+      return GCMI_ERR_LAUNCH;
+    }
   }
   return GCMI_OK;
 }
@@ -1932,6 +2045,7 @@ int gcmi_small_predict(const gcmi_model_desc* m, const float* d_params, const gc
   c.accs = reinterpret_cast<double*>(c.ws + c.w.acc0);
   c.st = (hipStream_t)stream;
   c.training = false;
+  c.parity = 0;
   if (m->batch_norm)
     for (int l = 0; l <= m->n_layers; ++l)
       GCMI_CHECK_ARG(io->d_bn_running_mean[l] && io->d_bn_running_var[l], "small_predict: NULL running statistics");
