@@ -78,6 +78,8 @@ class GcmiModelDesc(Structure):
         ("off_head_w", c_int64),
         ("off_head_b", c_int64),
         ("n_params", c_int64),
+        ("storage", c_int32),
+        ("reserved_", c_int32),
     ]
 
 

@@ -107,6 +107,10 @@ static int check_desc(const gcmi_model_desc* m) {
   GCMI_CHECK_ARG(m->mode == 0 || m->mode == 1, "mode must be 0 (classification) or 1 (regression)");
   GCMI_CHECK_ARG(m->mode == 0 || m->n_classes == 1, "regression needs n_classes == 1");
   for (int l = 0; l < m->n_layers; ++l) GCMI_CHECK_ARG(m->conv_width[l] > 0, "bad conv width");
+  if (m->storage != 0) {
+    set_error("gcmi_model_*: bf16 activation storage is implemented by the small-batch engine (gcmi_small_*) only");
+    return GCMI_ERR_UNSUPPORTED;
+  }
   return GCMI_OK;
 }
 

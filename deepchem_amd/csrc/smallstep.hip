@@ -45,6 +45,7 @@ constexpr int kSlots = 2 * kAhead;   // two sets of them
 struct SmallGraph {
   int32_t n_atoms, n_mols, max_deg, n_tiles;
   int32_t diag;  // GCMI_SMALL_DIAG: parts of the kernels switched off for timing experiments (results are wrong then)
+  int32_t bf16;  // activations the step writes (GraphConv outputs, pooled rows, dense output) are stored as bf16
   int32_t deg_start[GCMI_MAX_DEG + 2];
   int32_t edge_start[GCMI_MAX_DEG + 2];
   int32_t tile_start[GCMI_MAX_DEG + 2];  // 16-row tiles per degree block, prefix
@@ -135,6 +136,41 @@ __device__ __forceinline__ BnCol bn_col(const BnArgs& a, int width, int c) {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+// ---- activation storage.  gcmi_model_desc.storage = 1 ("bf16 storage"): every matrix the step WRITES
+// and reads back -- GraphConv outputs, pooled rows, the dense output -- is kept as bfloat16 (round to nearest even),
+// half the bytes per row; all arithmetic stays fp32 (operands widen on load, products and sums accumulate in fp32,
+// BatchNorm sums in fp64, parameters / gradients / optimizer state fp32).  The pointers keep their float type in the
+// signatures; with `bf` set the same buffer is addressed as 16-bit elements.
+__device__ __forceinline__ float bf2f(uint32_t h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ uint32_t f2bf(float f) {
+  const uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;  // NaN stays NaN
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float round_act(int bf, float v) { return bf ? bf2f(f2bf(v)) : v; }
+// four consecutive columns 4q..4q+3 of row `row` (leading dimension ld, in elements)
+__device__ __forceinline__ float4 ldA(int bf, const float* p, int64_t row, int64_t ld, int q) {
+  if (!bf) return ld4(p + row * ld + 4 * q);
+  const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p) + row * ld + 4 * q);
+  return make_float4(bf2f(w.x & 0xffffu), bf2f(w.x >> 16), bf2f(w.y & 0xffffu), bf2f(w.y >> 16));
+}
+__device__ __forceinline__ void stA(int bf, float* p, int64_t row, int64_t ld, int q, float4 v) {
+  if (!bf) {
+    st4(p + row * ld + 4 * q, v);
+    return;
+  }
+  uint2 w;
+  w.x = f2bf(v.x) | (f2bf(v.y) << 16);
+  w.y = f2bf(v.z) | (f2bf(v.w) << 16);
+  *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p) + row * ld + 4 * q) = w;
+}
+__device__ __forceinline__ void stA1(int bf, float* p, int64_t idx, float v) {  // v already rounded by round_act
+  if (!bf)
+    p[idx] = v;
+  else
+    reinterpret_cast<uint16_t*>(p)[idx] = (uint16_t)(__float_as_uint(v) >> 16);
+}
+
 // ------------------------------------------------------------------------------------------------ pooled row chunk
 // One row of GraphPool over the folded BatchNorm of gc: max over {self} U neighbours, first maximum wins
 // (self, then neighbours in table order: layers.py:6353-6361; torch.max(dim) tie rule).  arg: 0 = self, j+1.
@@ -167,7 +203,7 @@ __device__ __forceinline__ BnQuad bn_quad(const BnArgs& bn, int W, int q) {
 __device__ __forceinline__ void pool_chunk(const SmallGraph& g, int row, int d, int e, const float* __restrict__ gc,
                                            int W, int q, const float4& sc, const float4& sh, float4& best,
                                            uint32_t& arg) {
-  float4 v = ld4(gc + (int64_t)row * W + 4 * q);
+  float4 v = ldA(g.bf16, gc, row, W, q);
   const int32_t* nb = g.col_idx + e;
   uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
   bool first = true;
@@ -177,7 +213,7 @@ __device__ __forceinline__ void pool_chunk(const SmallGraph& g, int row, int d, 
 #pragma unroll
     for (int t = 0; t < 4; ++t) id[t] = j0 + t < d ? nb[j0 + t] : row;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) u[t] = ld4(gc + (int64_t)id[t] * W + 4 * q);
+    for (int t = 0; t < 4; ++t) u[t] = ldA(g.bf16, gc, id[t], W, q);
     if (first) {
       best = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
       first = false;
@@ -199,8 +235,8 @@ __device__ __forceinline__ void pool_chunk(const SmallGraph& g, int row, int d, 
 }
 
 // sum of the d neighbour rows (quad q), four rows in flight per round
-__device__ __forceinline__ float4 gather_sum_quad(const float* __restrict__ x, int64_t ld, const int32_t* nb, int d,
-                                                  int self_row, int q) {
+__device__ __forceinline__ float4 gather_sum_quad(int bf, const float* __restrict__ x, int64_t ld, const int32_t* nb,
+                                                  int d, int self_row, int q) {
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int j0 = 0; j0 < d; j0 += 4) {
     int id[4];
@@ -208,7 +244,7 @@ __device__ __forceinline__ float4 gather_sum_quad(const float* __restrict__ x, i
 #pragma unroll
     for (int t = 0; t < 4; ++t) id[t] = j0 + t < d ? nb[j0 + t] : self_row;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) u[t] = ld4(x + (int64_t)id[t] * ld + 4 * q);
+    for (int t = 0; t < 4; ++t) u[t] = ldA(bf, x, id[t], ld, q);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
       if (j0 + t < d) {
@@ -239,7 +275,7 @@ __device__ __forceinline__ bool pool_two_hop(const SmallGraph& g, int row, int d
   int id[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) id[t] = t < d ? nb[t] : row;
-  const float4 own = ld4(gc + (int64_t)row * W + 4 * q);
+  const float4 own = ldA(g.bf16, gc, row, W, q);
   int dn[4];
   const int32_t* nn[4];
   bool ok = true;
@@ -254,7 +290,7 @@ __device__ __forceinline__ bool pool_two_hop(const SmallGraph& g, int row, int d
   int id2[4][4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    r1[t] = ld4(gc + (int64_t)id[t] * W + 4 * q);
+    r1[t] = ldA(g.bf16, gc, id[t], W, q);
 #pragma unroll
     for (int k = 0; k < 4; ++k) id2[t][k] = (t < d && k < dn[t]) ? nn[t][k] : row;
   }
@@ -262,7 +298,7 @@ __device__ __forceinline__ bool pool_two_hop(const SmallGraph& g, int row, int d
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) r2[t][k] = ld4(gc + (int64_t)id2[t][k] * W + 4 * q);
+    for (int k = 0; k < 4; ++k) r2[t][k] = ldA(g.bf16, gc, id2[t][k], W, q);
   auto bnq = [&](const float4& v) {
     return make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
   };
@@ -288,12 +324,14 @@ __device__ __forceinline__ bool pool_two_hop(const SmallGraph& g, int row, int d
           p.w = fmaxf(p.w, z.w);
         }
       }
+      if (g.bf16) p = make_float4(round_act(1, p.x), round_act(1, p.y), round_act(1, p.z), round_act(1, p.w));
       nsum.x += p.x;
       nsum.y += p.y;
       nsum.z += p.z;
       nsum.w += p.w;
     }
   }
+  if (g.bf16) self = make_float4(round_act(1, self.x), round_act(1, self.y), round_act(1, self.z), round_act(1, self.w));
   arg = a0 | (a1 << 8) | (a2 << 16) | (a3 << 24);
   return true;
 }
@@ -370,6 +408,7 @@ small_conv_fwd_kernel(SmallGraph g, const float* __restrict__ x, int ldx, int K,
         const int e = tl.e0 + r * tl.d;
         if (!(tl.d <= 4 && pool_two_hop(g, row, tl.d, e, x, K, q, bq.scale, bq.shift, self, a, s))) {
           pool_chunk(g, row, tl.d, e, x, K, q, bq.scale, bq.shift, self, a);
+          if (g.bf16) self = make_float4(round_act(1, self.x), round_act(1, self.y), round_act(1, self.z), round_act(1, self.w));
           s = make_float4(0.f, 0.f, 0.f, 0.f);
           for (int j = 0; j < tl.d; ++j) {
             const int nr = nb[j];
@@ -377,17 +416,18 @@ small_conv_fwd_kernel(SmallGraph g, const float* __restrict__ x, int ldx, int K,
             float4 v;
             uint32_t an;
             pool_chunk(g, nr, dn, g.edge_start[dn] + (nr - g.deg_start[dn]) * dn, x, K, q, bq.scale, bq.shift, v, an);
+            if (g.bf16) v = make_float4(round_act(1, v.x), round_act(1, v.y), round_act(1, v.z), round_act(1, v.w));
             s.x += v.x;
             s.y += v.y;
             s.z += v.z;
             s.w += v.w;
           }
         }
-        if (pool_out) st4(pool_out + (int64_t)row * K + 4 * q, self);
+        if (pool_out) stA(g.bf16, pool_out, row, K, q, self);
         if (arg_out) *reinterpret_cast<uint32_t*>(arg_out + (int64_t)row * K + 4 * q) = a;
       } else {
-        self = ld4(x + (int64_t)row * ldx + 4 * q);
-        s = gather_sum_quad(x, ldx, nb, tl.d, row, q);
+        self = ld4(x + (int64_t)row * ldx + 4 * q);  // the atom features arrive as fp32 rows (one-hot: exact anyway)
+        s = gather_sum_quad(0, x, ldx, nb, tl.d, row, q);
         if (4 * q + 3 >= K) {  // columns beyond K (alignment padding of the input) never count
           float* sf = reinterpret_cast<float*>(&self);
           float* ss = reinterpret_cast<float*>(&s);
@@ -435,8 +475,8 @@ small_conv_fwd_kernel(SmallGraph g, const float* __restrict__ x, int ldx, int K,
     for (int j = 0; j < 4; ++j) {
       const int r = 4 * kq + j;
       if (r < tl.nrows) {
-        const float v = fmaxf(c[i][j] + bias[i], 0.f);
-        out[(int64_t)(tl.row0 + r) * W + col] = v;
+        const float v = round_act(g.bf16, fmaxf(c[i][j] + bias[i], 0.f));  // statistics describe what is stored
+        stA1(g.bf16, out, (int64_t)(tl.row0 + r) * W + col, v);
         s1 += v;
         s2 += v * v;
       }
@@ -500,7 +540,8 @@ small_pool_dense_fwd_kernel(SmallGraph g, const float* __restrict__ gc, int K, B
       uint32_t a;
       const BnQuad bq = bn_quad(bn, K, q);
       pool_chunk(g, tl.row0 + r, tl.d, tl.e0 + r * tl.d, gc, K, q, bq.scale, bq.shift, best, a);
-      st4(pool + (int64_t)(tl.row0 + r) * K + 4 * q, best);
+      stA(g.bf16, pool, tl.row0 + r, K, q, best);
+      if (g.bf16) best = ldA(1, pool, tl.row0 + r, K, q);  // the product sees the stored (rounded) rows, like the backward will
       if (arg) *reinterpret_cast<uint32_t*>(arg + (int64_t)(tl.row0 + r) * K + 4 * q) = a;
     }
     st4(sP + r * KP + 4 * q, best);
@@ -539,8 +580,8 @@ small_pool_dense_fwd_kernel(SmallGraph g, const float* __restrict__ gc, int K, B
     for (int j = 0; j < 4; ++j) {
       const int r = 4 * kq + j;
       if (r < tl.nrows) {
-        const float v = fmaxf(c[i][j] + bias, 0.f);
-        dense[(int64_t)(tl.row0 + r) * D + col] = v;
+        const float v = round_act(g.bf16, fmaxf(c[i][j] + bias, 0.f));
+        stA1(g.bf16, dense, (int64_t)(tl.row0 + r) * D + col, v);
         s1 += v;
         s2 += v * v;
       }
@@ -680,7 +721,7 @@ small_readout_kernel(SmallGraph g, ReadoutArgs a) {
         const int pp = p + u * RPW + grp;
         rr[u] = __shfl(myrow, pp & 63);
         ok[u] = pp < cnt;
-        v4[u] = ok[u] ? ld4(a.dense + (int64_t)rr[u] * F + 4 * fq) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v4[u] = ok[u] ? ldA(g.bf16, a.dense, rr[u], F, fq) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -940,7 +981,7 @@ __device__ __forceinline__ void dense_dx_to_lds(const SmallGraph& g, const Dense
     for (int t = 0; t < 4; ++t) {
       const int r = r0 + t * r_step;
       const int row = r < nrows ? row0 + r : row0;
-      x[t] = ld4(a.dense + (int64_t)row * F + 4 * q);
+      x[t] = ldA(g.bf16, a.dense, row, F, q);
       gs[t] = ld4(a.g2 + (int64_t)m[t] * 2 * F + 4 * q);
       gm[t] = ld4(a.g2 + (int64_t)m[t] * 2 * F + F + 4 * q);
       ar[t] = *reinterpret_cast<const int4*>(a.argrow + (int64_t)m[t] * F + 4 * q);
@@ -1035,7 +1076,7 @@ small_dense_bwd_kernel(SmallGraph g, DenseBwdArgs a) {
 #pragma unroll 4
     for (int idx = threadIdx.x; idx < kSlabRows * (K / 4); idx += kSBlock) {
       const int r = idx / (K / 4), q = idx - r * (K / 4);
-      st4(sP + r * KT + 4 * q, r < nrows ? ld4(a.pool + (int64_t)(row0 + r) * K + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f));
+      st4(sP + r * KT + 4 * q, r < nrows ? ldA(g.bf16, a.pool, row0 + r, K, q) : make_float4(0.f, 0.f, 0.f, 0.f));
     }
     __syncthreads();
     const int n_ot = F / 16, n_kt = K / 16;
@@ -1153,7 +1194,7 @@ small_pool_bwd_kernel(SmallGraph g, const float* __restrict__ dpool, const uint8
         }
       }
       if (dA) st4(dA + (int64_t)row * W + 4 * q, d);
-      const float4 x = ld4(gc + (int64_t)row * W + 4 * q);
+      const float4 x = ldA(g.bf16, gc, row, W, q);
       const BnQuad bq = bn_quad(bn, W, q);
       const float4 mu = bq.mean, iv = bq.invstd;
       dx.x = d.x * (x.x - mu.x) * iv.x;
@@ -1189,6 +1230,7 @@ struct ConvBwdArgs {
   const float* dgamma;   // sum dA xhat
   const float* dbeta;    // sum dA
   const float* x;        // N x ldx layer input
+  int x_bf;              // the layer input is a stored activation (bf16 storage mode), not the fp32 atom features
   int ldx, K, W;
   const float* Wl;       // 21 x K x W
   float* dWl;            // accumulated
@@ -1199,8 +1241,8 @@ struct ConvBwdArgs {
   int32_t slab_start[GCMI_MAX_DEG + 2];  // 64-row slabs per degree block, prefix
 };
 
-__device__ __forceinline__ void conv_dg_to_lds(const ConvBwdArgs& a, int row0, int nrows, int tile_rows, float* sG,
-                                               int pitch) {
+__device__ __forceinline__ void conv_dg_to_lds(int bf, const ConvBwdArgs& a, int row0, int nrows, int tile_rows,
+                                               float* sG, int pitch) {
   const int W = a.W, q4 = W / 4;
   for (int idx = threadIdx.x; idx < tile_rows * q4; idx += kSBlock) {
     const int r = idx / q4, q = idx - r * q4;
@@ -1209,7 +1251,7 @@ __device__ __forceinline__ void conv_dg_to_lds(const ConvBwdArgs& a, int row0, i
       const BwdQuad cq = bn_bwd_quad(a.bn, a.dbeta, a.dgamma, W, q);
       const float4 cA = cq.A, cB = cq.B, cC = cq.C;
       const float4 dy = ld4(a.dA + (int64_t)(row0 + r) * W + 4 * q);
-      const float4 x = ld4(a.gc + (int64_t)(row0 + r) * W + 4 * q);
+      const float4 x = ldA(bf, a.gc, row0 + r, W, q);
       dg.x = x.x > 0.f ? fmaf(cA.x, dy.x, fmaf(cB.x, x.x, cC.x)) : 0.f;
       dg.y = x.y > 0.f ? fmaf(cA.y, dy.y, fmaf(cB.y, x.y, cC.y)) : 0.f;
       dg.z = x.z > 0.f ? fmaf(cA.z, dy.z, fmaf(cB.z, x.z, cC.z)) : 0.f;
@@ -1232,7 +1274,7 @@ small_conv_bwd_kernel(SmallGraph g, ConvBwdArgs a) {
     const Tile tl = tile_of(g, b);
     const int WP = pitch_a(W);
     float* sG = smem;  // [16][WP]
-    conv_dg_to_lds(a, tl.row0, tl.nrows, kTileRows, sG, WP);
+    conv_dg_to_lds(g.bf16, a, tl.row0, tl.nrows, kTileRows, sG, WP);
     __syncthreads();
     const float* Wself = a.Wl + (tl.d == 0 ? (int64_t)(2 * g.max_deg) * blk : (int64_t)(2 * (tl.d - 1) + 1) * blk);
     const float* Wrel = tl.d == 0 ? nullptr : a.Wl + (int64_t)(2 * (tl.d - 1)) * blk;
@@ -1271,14 +1313,14 @@ small_conv_bwd_kernel(SmallGraph g, ConvBwdArgs a) {
   float* sG = smem;                     // [slab][WT]
   float* sX = sG + kSlabRows * WT;      // [slab][KT] own rows
   float* sS = sX + kSlabRows * KT;      // [slab][KT] neighbour sums
-  conv_dg_to_lds(a, row0, nrows, kSlabRows, sG, WT);
+  conv_dg_to_lds(g.bf16, a, row0, nrows, kSlabRows, sG, WT);
   const int q4 = K4 / 4;
   for (int idx = threadIdx.x; idx < kSlabRows * q4; idx += kSBlock) {
     const int r = idx / q4, q = idx - r * q4;
     float4 self = make_float4(0.f, 0.f, 0.f, 0.f), s = self;
     if (r < nrows) {
-      self = ld4(a.x + (int64_t)(row0 + r) * a.ldx + 4 * q);
-      s = gather_sum_quad(a.x, a.ldx, g.col_idx + e0 + r * d, d, row0 + r, q);
+      self = ldA(a.x_bf, a.x, row0 + r, a.ldx, q);
+      s = gather_sum_quad(a.x_bf, a.x, a.ldx, g.col_idx + e0 + r * d, d, row0 + r, q);
     }
     st4(sX + r * KT + 4 * q, self);
     st4(sS + r * KT + 4 * q, s);
@@ -1344,7 +1386,7 @@ small_gather_add_kernel(SmallGraph g, const float* __restrict__ dXs, const float
     const int r = idx / q4, q = idx - r * q4;
     const int row = tl.row0 + r;
     float4 s = ld4(dXs + (int64_t)row * W + 4 * q);
-    const float4 n = gather_sum_quad(dS, W, g.col_idx + tl.e0 + r * tl.d, tl.d, row, q);
+    const float4 n = gather_sum_quad(0, dS, W, g.col_idx + tl.e0 + r * tl.d, tl.d, row, q);
     s.x += n.x;
     s.y += n.y;
     s.z += n.z;
@@ -1503,6 +1545,7 @@ static int small_check(const gcmi_model_desc* m) {
   GCMI_CHECK_ARG(m->max_deg >= 0 && m->max_deg <= GCMI_MAX_DEG, "small: bad max_deg");
   GCMI_CHECK_ARG(m->n_feat_in > 0 && m->n_tasks > 0 && m->n_classes > 0, "small: bad widths");
   GCMI_CHECK_ARG(m->mode == 0 || (m->mode == 1 && m->n_classes == 1), "small: bad mode / n_classes");
+  GCMI_CHECK_ARG(m->storage == 0 || m->storage == 1, "small: storage must be 0 (fp32) or 1 (bf16 activations)");
   for (int l = 0; l < m->n_layers; ++l)
     if (m->conv_width[l] <= 0 || m->conv_width[l] % 64 || m->conv_width[l] > 256) {
       set_error("small: GraphConv width %d is not a multiple of 64 in [64, 256]", m->conv_width[l]);
@@ -1809,6 +1852,7 @@ static int small_backward(const SmallCtx& c, const SmallGraph& g, const gcmi_sma
     cb.dbeta = m->batch_norm ? grads + m->off_bn_beta[l] : nullptr;
     cb.x = l == 0 ? b->d_atom_features : c.ws + c.w.pool[l - 1];
     cb.ldx = l == 0 ? (int)b->ld_features : m->conv_width[l - 1];
+    cb.x_bf = (l > 0 && g.bf16) ? 1 : 0;
     cb.K = K;
     cb.W = W;
     cb.Wl = c.params + m->off_conv_w[l];
@@ -1926,6 +1970,7 @@ int gcmi_small_fit(const gcmi_model_desc* m, float* d_params, float* d_grads, fl
     GCMI_CHECK_ARG(b->graph.max_deg == m->max_deg, "small_fit: graph max_deg %d != model max_deg %d", b->graph.max_deg,
                    m->max_deg);
     SRUN(make_small_graph(&b->graph, true, &graphs[(size_t)i]));
+    graphs[(size_t)i].bf16 = m->storage == 1 ? 1 : 0;
   }
   auto slot_of = [](int64_t i) { return (int)(((i / kAhead) & 1) * kAhead + i % kAhead); };
   const int64_t n_groups = (n_batches + kAhead - 1) / kAhead;
@@ -2058,6 +2103,7 @@ int gcmi_small_predict(const gcmi_model_desc* m, const float* d_params, const gc
     GCMI_CHECK_ARG(b->graph.max_deg == m->max_deg, "small_predict: graph max_deg != model max_deg");
     SmallGraph g;
     SRUN(make_small_graph(&b->graph, false, &g));
+    g.bf16 = m->storage == 1 ? 1 : 0;
     SRUN(small_forward_body(c, g, b->d_atom_features, b->ld_features));
     ReadoutArgs ra;
     memset(&ra, 0, sizeof(ra));

@@ -472,6 +472,10 @@ typedef struct gcmi_model_desc {
   int64_t off_bn_gamma[GCMI_MAX_CONV_LAYERS + 1], off_bn_beta[GCMI_MAX_CONV_LAYERS + 1];
   int64_t off_dense_w, off_dense_b, off_head_w, off_head_b;
   int64_t n_params;
+  int32_t storage;                       /* activations the step writes and reads back: 0 fp32, 1 bfloat16 (fp32
+                                            arithmetic and accumulation either way; gcmi_small_* only: gcmi_model_*
+                                            rejects 1 with GCMI_ERR_UNSUPPORTED)                                   */
+  int32_t reserved_;
 } gcmi_model_desc;
 
 typedef struct gcmi_model_io {

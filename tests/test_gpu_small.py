@@ -197,3 +197,70 @@ def test_small_engine_other_widths():
     for k in sd:
         a, b = sd[k].float().cpu().numpy(), rsd[k].float().cpu().numpy()
         _same_after_adam(k, a, b, len(batches), "running" not in k and "num_batches" not in k)
+
+
+# ------------------------------------------------------------------ bf16 activation storage (opt-in)
+def _bf16(x):
+    """Round an fp32 array to bfloat16 (nearest even) and back."""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32)
+
+
+@pytest.mark.parametrize("grad_mode", ["reference", "full"])
+def test_bf16_storage_follows_fp32_within_bf16_resolution(grad_mode):
+    """``activation_storage="bf16"``: the same two epochs as the fp32 engine from the same state.  Stored activations
+    carry 8 significant bits (relative rounding 2^-9 per stored matrix, three to five of them between input and
+    loss), so first-epoch losses agree to ~1 %, far outside the fp32 mode's bound and far inside an error: a
+    wrong stride or a missing conversion is off by O(1)."""
+    import deepchem_amd as dc
+    from deepchem_amd.small import SmallBatchEngine
+    results = {}
+    for storage in ("fp32", "bf16"):
+        packed, y, w, cfg, state, _ = _setup("classification", 12, 10, 48, True, grad_mode, seed=7)
+        model = dc.models.torch_models.GraphConvModel(12, number_input_features=[75, 64], batch_size=10,
+                                                      grad_mode=grad_mode, device=torch.device(DEV), learning_rate=1e-3,
+                                                      activation_storage=storage)
+        model.model.load_state_dict({k: v.clone() for k, v in state.items()})
+        model._ensure_built()
+        model.model.train()
+        engine = SmallBatchEngine(model.model._native_net())
+        assert engine.native.desc.storage == (1 if storage == "bf16" else 0)
+        batches = _device_batches(model, packed, y, w, cfg, 10)
+        descs = [engine.describe(b, l, ww, 10) for b, l, ww, _, _ in batches]
+        losses = []
+        for _ in range(2):
+            losses += engine.fit(descs, model._pytorch_optimizer, max(b.n_atoms for b, *_ in batches), 10).cpu().tolist()
+        outs = []
+        model.model.eval()
+        for b, *_ in batches:
+            d = engine.describe(b)
+            lo, pr, fp = (torch.empty((10, 24), device=DEV), torch.empty((10, 24), device=DEV),
+                          torch.empty((10, 256), device=DEV))
+            d.d_logits, d.d_probs, d.d_fingerprint = lo.data_ptr(), pr.data_ptr(), fp.data_ptr()
+            engine.predict([d], b.n_atoms, 10)
+            outs.append(pr.cpu().numpy())
+        results[storage] = (np.array(losses), np.concatenate(outs))
+    l32, p32 = results["fp32"]
+    l16, p16 = results["bf16"]
+    assert not np.array_equal(l32, l16)                       # the mode is really on
+    # ten-molecule batches (BatchNorm over ~200 rows) and ten optimizer steps: the two runs drift by a few percent
+    assert np.allclose(l16, l32, rtol=8e-2), (l16, l32)
+    assert np.allclose(l16[:5], l32[:5], rtol=2e-2), (l16, l32)  # first epoch: rounding only, no drift yet
+    assert np.abs(p16 - p32).max() < 0.15 and np.abs(p16 - p32).mean() < 1e-2
+
+
+def test_bf16_storage_is_refused_outside_the_small_engine():
+    import deepchem_amd as dc
+    from deepchem_amd.utils.synthetic import synthetic_labels, synthetic_molecules
+    packed = synthetic_molecules(16, seed=1, max_atoms=20)
+    y, w = synthetic_labels(16, 2, "classification", 1)
+    model = dc.models.torch_models.GraphConvModel(2, number_input_features=[75, 64], batch_size=8,
+                                                  device=torch.device(DEV), activation_storage="bf16")
+    ds = dc.data.PackedDataset(packed, y, w)
+    model.fit(ds, nb_epoch=1, checkpoint_interval=0)           # small batches: runs
+    assert model.predict(ds).shape == (16, 2, 2)
+    with pytest.raises(NotImplementedError, match="small-batch engine"):
+        model.fit(ds, nb_epoch=1, checkpoint_interval=0, callbacks=[lambda m, s: None])   # per-batch path
+    with pytest.raises(ValueError):
+        dc.models.torch_models.GraphConvModel(2, number_input_features=[75, 64], activation_storage="fp8")
