@@ -265,6 +265,20 @@ def tox21_real(device, epochs=10):
                         model.predict(valid)
                     rec["predict_molecules_per_s_batch_%d%s" % (B, "" if engine else "_per_batch_path")] = round(
                         5 * len(valid) / (time.perf_counter() - t1), 1)
+    # the opt-in bf16 activation storage, beside -- never instead of -- the fp32 numbers above
+    bf = {"dtype": "bf16-storage", "what": "GraphConv outputs, pooled rows and the dense output stored as bfloat16; fp32 "
+                                           "operands, accumulation, parameters, gradients and optimizer state"}
+    for B, lr in ((64, 5e-4), (100, 1e-3)):
+        model = dc.models.torch_models.GraphConvModel(12, number_input_features=[75, 64], batch_size=B, learning_rate=lr,
+                                                      device=device, log_frequency=10**9, activation_storage="bf16")
+        np.random.seed(123)
+        model.fit(train, nb_epoch=1, checkpoint_interval=0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        model.fit(train, nb_epoch=epochs, checkpoint_interval=0)
+        torch.cuda.synchronize()
+        bf["fit_molecules_per_s_batch_%d_reference" % B] = round(epochs * a / (time.perf_counter() - t1), 1)
+    rec["bf16_storage"] = bf
     # the whole MolNet preset (40 epochs at batch 64), wall time next to examples/stable_results.csv:5 (165.2 s)
     model = dc.models.torch_models.GraphConvModel(12, number_input_features=[75, 64], batch_size=64, learning_rate=5e-4,
                                                   device=device, log_frequency=10**9)

@@ -233,7 +233,8 @@ def test_real_tox21_bf16_storage_auc(run):
     """The opt-in bf16 activation storage judged on the real file: the REFERENCE's trained
     parameters in the drop-in model with ``activation_storage="bf16"`` -- every stored activation rounded to 8
     significant bits, fp32 arithmetic.  Probabilities move by up to a few 1e-2 (measured, printed); the per-task
-    ROC-AUC, a rank statistic over 801 molecules, stays within 0.004 of the reference's and the mean within 0.001."""
+    ROC-AUC stays within the north_star's +-0.002 of the reference's (measured 0.0018 / 0.0008; eval mode has no
+    atomics, so the numbers repeat) and the mean within 0.001."""
     from deepchem_amd.metrics import roc_auc_per_task
     g = load_golden("tox21_ref.npz")
     prefix = run + "_trained__"
@@ -248,4 +249,4 @@ def test_real_tox21_bf16_storage_auc(run):
           (np.abs(probs - ref).max(), np.abs(probs - ref).mean(), np.nanmax(d_auc),
            abs(np.nanmean(auc) - np.nanmean(g[run + "_valid_auc"]))))
     assert np.abs(probs - ref).max() < 0.1 and np.abs(probs - ref).mean() < 5e-3
-    assert np.nanmax(d_auc) <= 0.004 and abs(np.nanmean(auc) - np.nanmean(g[run + "_valid_auc"])) <= 0.001
+    assert np.nanmax(d_auc) <= 0.002 and abs(np.nanmean(auc) - np.nanmean(g[run + "_valid_auc"])) <= 0.001
