@@ -246,8 +246,10 @@ class EdgeNetworkFn(torch.autograd.Function):
 class _MPNNTorchModel(nn.Module):
 
     def __init__(self, n_tasks: int, n_atom_feat: int = 70, n_pair_feat: int = 8, n_hidden: int = 100, T: int = 5,
-                 M: int = 10, mode: str = "regression", n_classes: int = 2, batch_size: int = 100):
+                 M: int = 10, mode: str = "regression", n_classes: int = 2, batch_size: int = 100,
+                 uncertainty: bool = False):
         super().__init__()
+        self.uncertainty = uncertainty
         if n_atom_feat > n_hidden:
             raise ValueError("Too large initial feature vector")
         if n_hidden > 128 or n_pair_feat > 16:
@@ -271,7 +273,11 @@ class _MPNNTorchModel(nn.Module):
         self.set_b = nn.Parameter(torch.cat([torch.zeros(d), torch.ones(d), torch.zeros(d), torch.zeros(d)]))
         self.dense1 = nn.Linear(2 * d, 2 * d)
         self.head = nn.Linear(2 * d, n_tasks * n_classes if mode == "classification" else n_tasks)
-        for lin in (self.atom_embed, self.dense1, self.head):  # Keras Dense: glorot uniform, zero bias
+        dense_layers = [self.atom_embed, self.dense1, self.head]
+        if uncertainty:  # a second head on the same features predicts the log-variance (graph_models.py:1147-1151)
+            self.log_var_head = nn.Linear(2 * d, n_tasks)
+            dense_layers.append(self.log_var_head)
+        for lin in dense_layers:  # Keras Dense: glorot uniform, zero bias
             glorot(lin.weight)
             nn.init.zeros_(lin.bias)
 
@@ -312,7 +318,11 @@ class _MPNNTorchModel(nn.Module):
         if self.mode == "classification":
             logits = out.reshape(-1, self.n_tasks, self.n_classes)[0:n_samples]
             return [ops.SoftmaxFn.apply(logits), logits]
-        return [out[0:n_samples]]
+        output = out[0:n_samples]
+        if self.uncertainty:
+            log_var = ops.LinearFn.apply(dense1, self.log_var_head.weight, self.log_var_head.bias, False, False)[0:n_samples]
+            return [output, torch.exp(log_var), output, log_var]
+        return [output]
 
 
 class MPNNModel(TorchModel):
@@ -329,12 +339,25 @@ class MPNNModel(TorchModel):
                 raise ValueError("Uncertainty is only supported in regression mode")
             if dropout == 0.0:
                 raise ValueError('Dropout must be included to predict uncertainty')
-            raise NotImplementedError("the uncertainty head of MPNNModel is not built")
         self.n_tasks, self.n_atom_feat, self.n_pair_feat, self.n_hidden = n_tasks, n_atom_feat, n_pair_feat, n_hidden
         self.T, self.M, self.mode, self.n_classes, self.uncertainty = T, M, mode, n_classes, uncertainty
-        model = _MPNNTorchModel(n_tasks, n_atom_feat, n_pair_feat, n_hidden, T, M, mode, n_classes, batch_size)
+        model = _MPNNTorchModel(n_tasks, n_atom_feat, n_pair_feat, n_hidden, T, M, mode, n_classes, batch_size,
+                                uncertainty)
         if mode == "classification":
             output_types, loss = ['prediction', 'loss'], SoftmaxCrossEntropy()
+        elif uncertainty:
+            # the Keras model validates `dropout` but builds no Dropout layer (graph_models.py:1110-1170), so every
+            # mask of predict_uncertainty gives the same prediction and the reported deviation is the predicted
+            # (aleatoric) one; kept as it is
+            output_types = ['prediction', 'variance', 'loss', 'loss']
+
+            def loss(outputs, labels, weights):
+                diff = outputs[0] - labels[0].reshape(outputs[0].shape)
+                losses = torch.square(diff) / torch.exp(outputs[1]) + outputs[1]
+                w = weights[0]
+                if w.dim() < losses.dim():
+                    w = w.reshape(tuple(w.shape) + (1,) * (losses.dim() - w.dim()))
+                return torch.mean(losses * w)
         else:
             output_types, loss = ['prediction'], L2Loss()
         super(MPNNModel, self).__init__(model, loss, output_types=output_types, batch_size=batch_size, **kwargs)
