@@ -1,0 +1,524 @@
+// One pass over the rows for everything the backward of a GraphConv / dense block does with the gradient of its
+// pre-activation (autograd of models/torch_models/layers.py:6204-6246 and graphconvmodel.py:222-229):
+//
+//     G   = relu'(x) * (A*dy + B*x + C)              BatchNorm backward, elementwise part (bn.hip), never written
+//     dW_o += In_o^T . G   (o = rel, self | dense)   weight gradients, bias gradient = column sums of G
+//     dIn_o = G . W_o^T                              gradients of the block's inputs
+//
+// The separate kernels (bn_bwd_dx, two wgrad launches, two dgrad launches) each stream N x 64..128 floats; together
+// they move 896 floats per atom for a K = 64 GraphConv and 640 (+ per-molecule rows) for the dense layer.  Here a
+// 64-row tile of G is formed once in LDS from the prefetched dy / x rows (for the dense layer dy itself is recomputed
+// from the per-molecule GraphGather gradient, readout_dy of bn.hip) and both products read it from there:
+// 384 / 256 floats per atom.
+//
+// Workgroup = 8 waves on one 64-row tile of ONE degree segment: waves 0-3 form dIn (32 rows x 32..64 columns each,
+// weights as three bf16 images in LDS, built once per segment), waves 4-7 accumulate dW in registers over all tiles
+// of the segment the workgroup walks (one (operand, 32-column group of G) each; the rows of In arrive as per-lane
+// dword loads one tile ahead, as in wgrad3_kernel) and add them to the gradient with one float atomic per element at
+// the end of the segment.  Arithmetic = the exact three-way bf16 split of gemm_split.hip (six products per term on
+// v_mfma_f32_32x32x16_bf16, fp32 accumulation).  A block that needs no input gradient (the first GraphConv) runs
+// the four weight-gradient waves only.
+#include <atomic>
+
+#include "common.h"
+#include "split_bf16.h"
+
+namespace gcmi {
+
+constexpr int kFRows = 64;
+constexpr int kFMaxSeg = 16;
+
+struct FusedTable {
+  int32_t n_seg;
+  int32_t seg_begin[kFMaxSeg];
+  int32_t seg_end[kFMaxSeg];
+  int32_t tile_start[kFMaxSeg + 1];
+  int64_t w_off[2][kFMaxSeg];  // weight block of operand o = the same block of the gradient; < 0: term absent
+  int64_t db_off[kFMaxSeg];    // bias-gradient row; < 0: none
+};
+
+struct FusedArgs {
+  // sources of G
+  const float* dy;       // incoming gradient rows (nullptr: recomputed from the readout gradient)
+  int64_t lddy;
+  const float* x;        // BatchNorm input = the block's ReLU output
+  int64_t ldx;
+  const float* coef;     // [A | B | C], 3 * NG floats; nullptr: G = relu'(x) * dy
+  const int32_t* membership;
+  const float* g2;       // n_mols x ldg2: [dsum | dmax]
+  int64_t ldg2;
+  const int32_t* arg;    // n_mols x NG
+  // weight-gradient operands
+  const float* in[2];
+  int64_t ldin[2];
+  int32_t k_in;
+  const float* w;
+  float* dw;
+  float* db;
+  // input gradients (DGRAD)
+  float* dout[2];
+  int64_t lddout[2];
+};
+
+template <int NG, int KT, int NOPS, bool TRANS, bool RD, bool DGRAD>
+__global__ void __launch_bounds__(DGRAD ? 512 : 256)
+fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
+  constexpr int NT = DGRAD ? 512 : 256;
+  constexpr int NJ = NG / 32;                 // 32-column groups of G
+  constexpr int KP = KT * 32;                 // padded width of In
+  constexpr int GP = NG + 4;                  // pitch of a G row in LDS (floats): 16-byte rows
+  constexpr int IP = KP + 4;                  // pitch of an In row in LDS
+  constexpr int WP = NG + 8;                  // pitch of a weight-image row (bf16): conflict-free b128 reads
+  constexpr int QPR = NG / 4;                 // 16-byte pieces of a G row
+  constexpr int RPP = NT / QPR;               // rows per pass of the tile loads
+  constexpr int GPASS = kFRows / RPP;         // passes
+  constexpr int IQ = KP / 4;                  // 16-byte pieces of an In row
+  constexpr int IPASS = kFRows * IQ / NT;     // passes of the In loads, per operand
+  constexpr int STEPS = kFRows / 16;          // k-steps of the weight-gradient contraction
+  constexpr int OT = NOPS * KT;               // 32-column tiles of the input gradients
+  constexpr int TPW = OT / 2;                 // ... per dgrad wave (two waves per 32-row block)
+  static_assert(NOPS * NJ == 4, "four weight-gradient waves: one (operand, column group) each");
+  static_assert(!DGRAD || (OT % 2 == 0), "input-gradient tiles split over two waves per row block");
+  static_assert(kFRows * IQ % NT == 0, "In tile loads divide evenly");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  float* Gs = reinterpret_cast<float*>(lds_raw);
+  float* Ins = Gs + kFRows * GP;                                   // [NOPS][64][IP]
+  unsigned short* Wimg = reinterpret_cast<unsigned short*>(Ins + NOPS * kFRows * IP);
+  // the segment table, in LDS (indexing the by-value struct dynamically would go through scratch)
+  __shared__ int t_begin_s[kFMaxSeg], t_end_s[kFMaxSeg], t_tile_s[kFMaxSeg + 1];
+  __shared__ long long t_w_s[2][kFMaxSeg], t_db_s[kFMaxSeg];
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int lane = tid & 63;
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+  const bool is_dgrad = DGRAD && wave < 4;
+  const int wq = wave & 3;
+  // weight-gradient wave: operand wo, column group wj of G
+  const int wo = wq / NJ, wj = wq % NJ;
+  // input-gradient wave: row block rb, output tiles [cg * TPW, cg * TPW + TPW)
+  const int rb = wq & 1, cg = wq >> 1;
+
+  if (tid <= kFMaxSeg) {
+    t_tile_s[tid] = pick_n(st.tile_start, tid);
+    if (tid < kFMaxSeg) {
+      t_begin_s[tid] = pick_n(st.seg_begin, tid);
+      t_end_s[tid] = pick_n(st.seg_end, tid);
+      t_w_s[0][tid] = pick_n(st.w_off[0], tid);
+      t_w_s[1][tid] = pick_n(st.w_off[1], tid);
+      t_db_s[tid] = pick_n(st.db_off, tid);
+    }
+  }
+  const int n_seg = st.n_seg;
+  __syncthreads();
+
+  const int b = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+  const int t_begin = (int)((int64_t)b * n_tiles / gridDim.x);
+  const int t_end = (int)((int64_t)(b + 1) * n_tiles / gridDim.x);
+  const int my_tiles = t_end - t_begin;
+  if (my_tiles <= 0) return;
+  auto tile_at = [&](int i) { return rev ? t_end - 1 - i : t_begin + i; };
+  auto tile_info = [&](int tile, int& seg, int& row0, int& valid) {
+    int s = 0;
+    for (int k = 1; k < n_seg; ++k) s += tile >= t_tile_s[k] ? 1 : 0;
+    seg = s;
+    row0 = t_begin_s[s] + (tile - t_tile_s[s]) * kFRows;
+    const int left = t_end_s[s] - row0;
+    valid = left < kFRows ? left : kFRows;
+  };
+
+  // ---- per-thread constants of the G phase: this thread's 16-byte column piece
+  const int gq = tid % QPR;
+  const int gr = tid / QPR;
+  float cA[4] = {1.f, 1.f, 1.f, 1.f}, cB[4] = {0.f, 0.f, 0.f, 0.f}, cC[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.coef != nullptr) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      cA[q] = a.coef[4 * gq + q];
+      cB[q] = a.coef[NG + 4 * gq + q];
+      cC[q] = a.coef[2 * NG + 4 * gq + q];
+    }
+  }
+
+  // ---- prefetch registers (one tile ahead; the molecule index two tiles ahead): all loads are 16 bytes per lane,
+  // unconditional, from clamped addresses; what lies outside the tile is zeroed when it goes to LDS
+  float4 pdy[GPASS], px[GPASS], pgm[RD ? GPASS : 1], pin[NOPS][IPASS];
+  int4 parg[RD ? GPASS : 1];
+  int mem1[RD ? GPASS : 1], mem2[RD ? GPASS : 1];
+  auto clampr = [](int r, int valid) { return r < valid ? r : valid - 1; };
+  auto load_mem = [&](int row0, int valid, int (&mem)[RD ? GPASS : 1]) {
+    if constexpr (RD) {
+#pragma unroll
+      for (int p = 0; p < GPASS; ++p) mem[p] = a.membership[row0 + clampr(gr + p * RPP, valid)];
+    }
+  };
+  auto load_src = [&](int row0, int valid) {
+#pragma unroll
+    for (int p = 0; p < GPASS; ++p) {
+      const int64_t r = row0 + clampr(gr + p * RPP, valid);
+      px[p] = *reinterpret_cast<const float4*>(a.x + r * a.ldx + 4 * gq);
+      if constexpr (RD) {
+        const int64_t m = mem1[p];
+        pdy[p] = *reinterpret_cast<const float4*>(a.g2 + m * a.ldg2 + 4 * gq);
+        pgm[p] = *reinterpret_cast<const float4*>(a.g2 + m * a.ldg2 + NG + 4 * gq);
+        parg[p] = *reinterpret_cast<const int4*>(a.arg + m * NG + 4 * gq);
+      } else {
+        pdy[p] = *reinterpret_cast<const float4*>(a.dy + r * a.lddy + 4 * gq);
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o) {
+#pragma unroll
+      for (int p = 0; p < IPASS; ++p) {
+        const int slot = tid + p * NT;
+        const int r = slot / IQ, q = slot - r * IQ;
+        const int64_t ld = a.ldin[o];
+        const int qc = 4 * q + 4 <= ld ? 4 * q : 0;
+        pin[o][p] = *reinterpret_cast<const float4*>(a.in[o] + (int64_t)(row0 + clampr(r, valid)) * ld + qc);
+      }
+    }
+  };
+
+  // ---- weight-gradient state
+  f32x16 wacc[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wacc[t][i] = 0.f;
+  float bsum = 0.f;
+  auto flush_w = [&](int seg) {
+    const int64_t woff = t_w_s[NOPS == 2 ? wo : 0][seg];
+    if (woff >= 0) {
+      // this lane's first element; the pointer is made opaque so that the 32 addresses behind it are formed here
+      // and not hoisted out of the tile loop into 64 registers
+      float* wp = a.dw + woff + (TRANS ? (int64_t)(wj * 32 + 4 * half) * a.k_in + l31
+                                       : (int64_t)(4 * half) * NG + wj * 32 + l31);
+      asm volatile("" : "+v"(wp));
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int r8 = (reg & 3) + 8 * (reg >> 2);  // + 4 * half: row of the accumulator tile
+          if constexpr (TRANS) {  // dW stored NG x k_in: the accumulator holds (column of G) x (column of In)
+            if (t * 32 + l31 < a.k_in) atomicAdd(wp + (int64_t)r8 * a.k_in + t * 32, wacc[t][reg]);
+          } else {                // dW stored k_in x NG
+            if (t * 32 + r8 + 4 * half < a.k_in) atomicAdd(wp + (t * 32 + r8) * NG, wacc[t][reg]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) wacc[t][i] = 0.f;
+    if (wo == 0) {
+      const int64_t boff = t_db_s[seg];
+      const float s = bsum + __shfl_xor(bsum, 32);
+      if (half == 0 && a.db != nullptr && boff >= 0) atomicAdd(a.db + boff + wj * 32 + l31, s);
+    }
+    bsum = 0.f;
+  };
+
+  // ---- prologue: sources of the first tile, molecule indices of the first two
+  int seg, row0, valid;
+  tile_info(tile_at(0), seg, row0, valid);
+  int nseg = seg, nrow0 = row0, nvalid = valid;  // the tile after this one (itself when there is none)
+  if (my_tiles > 1) tile_info(tile_at(1), nseg, nrow0, nvalid);
+  load_mem(row0, valid, mem1);
+  load_src(row0, valid);
+  load_mem(nrow0, nvalid, mem1);  // mem1 now describes tile 1: its sources are requested in phase (b) of tile 0
+  int cur_seg = -1;
+
+  for (int i = 0; i < my_tiles; ++i) {
+    if (seg != cur_seg) {
+      if (cur_seg >= 0 && !is_dgrad) flush_w(cur_seg);
+      cur_seg = seg;
+      if constexpr (DGRAD) {
+        // the segment's weight blocks as three bf16 images [operand][piece][input column][column of G]
+        // (everyone passed the barrier that ended the previous tile: nobody reads the old images any more)
+        constexpr int NE = NOPS * KP * NG;
+        for (int e = tid; e < NE; e += NT) {
+          int o, ko, c;
+          if constexpr (TRANS) {  // w is NG x k_in: consecutive threads along k_in
+            o = 0;
+            c = e / KP;
+            ko = e - c * KP;
+          } else {                // w is k_in x NG: consecutive threads along NG
+            o = e / (KP * NG);
+            const int r = e - o * (KP * NG);
+            ko = r / NG;
+            c = r - ko * NG;
+          }
+          const int64_t woff = t_w_s[NOPS == 2 ? (o & 1) : 0][seg];
+          float v = 0.f;
+          if (woff >= 0 && ko < a.k_in)
+            v = TRANS ? a.w[woff + (int64_t)c * a.k_in + ko] : a.w[woff + (int64_t)ko * NG + c];
+          unsigned p1, p2, p3;
+          split3(v, p1, p2, p3);
+          unsigned short* dst = Wimg + ((size_t)(o * 3) * KP + ko) * WP + c;
+          dst[0] = (unsigned short)(p1 >> 16);
+          dst[(size_t)KP * WP] = (unsigned short)(p2 >> 16);
+          dst[(size_t)2 * KP * WP] = (unsigned short)(p3 >> 16);
+        }
+      }
+    }
+
+    // ---- phase (a): G and the In rows of this tile -> LDS
+#pragma unroll
+    for (int p = 0; p < GPASS; ++p) {
+      const int r = gr + p * RPP;
+      float dyv[4] = {pdy[p].x, pdy[p].y, pdy[p].z, pdy[p].w};
+      const float xv[4] = {px[p].x, px[p].y, px[p].z, px[p].w};
+      if constexpr (RD) {
+        const int rg = row0 + r;
+        const float gm[4] = {pgm[p].x, pgm[p].y, pgm[p].z, pgm[p].w};
+        const int av[4] = {parg[p].x, parg[p].y, parg[p].z, parg[p].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dyv[q] = dyv[q] + (av[q] == rg ? gm[q] : 0.f);
+      }
+      float o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float v = fmaf(cA[q], dyv[q], fmaf(cB[q], xv[q], cC[q]));
+        o[q] = (r < valid && xv[q] > 0.f) ? v : 0.f;
+      }
+      *reinterpret_cast<float4*>(Gs + r * GP + 4 * gq) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o) {
+#pragma unroll
+      for (int p = 0; p < IPASS; ++p) {
+        const int slot = tid + p * NT;
+        const int r = slot / IQ, q = slot - r * IQ;
+        const int tail = a.k_in - 4 * q;
+        float4 v = pin[o][p];
+        const bool ok = r < valid;
+        v.x = (ok && tail > 0) ? v.x : 0.f;
+        v.y = (ok && tail > 1) ? v.y : 0.f;
+        v.z = (ok && tail > 2) ? v.z : 0.f;
+        v.w = (ok && tail > 3) ? v.w : 0.f;
+        *reinterpret_cast<float4*>(Ins + (o * kFRows + r) * IP + 4 * q) = v;
+      }
+    }
+    __syncthreads();
+
+    // ---- phase (b): next tile's sources in flight, products from LDS
+    int n2seg = nseg, n2row0 = nrow0, n2valid = nvalid;
+    if (i + 2 < my_tiles) tile_info(tile_at(i + 2), n2seg, n2row0, n2valid);
+    load_src(nrow0, nvalid);             // uses mem1 = molecule indices of the next tile
+    load_mem(n2row0, n2valid, mem2);     // and the indices of the tile after it
+    if (is_dgrad) {
+      if constexpr (DGRAD) {
+        f32x16 acc[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+          for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+        bool on[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          const int ot = cg * TPW + t;
+          on[t] = t_w_s[NOPS == 2 ? ((ot / KT) & 1) : 0][seg] >= 0;
+        }
+#pragma unroll
+        for (int ks = 0; ks < NG / 16; ++ks) {
+          __builtin_amdgcn_sched_barrier(0);  // one k-step's fragments live at a time
+          const float* grow = Gs + (rb * 32 + l31) * GP + ks * 16 + 8 * half;
+          const float4 lo = *reinterpret_cast<const float4*>(grow);
+          const float4 hi = *reinterpret_cast<const float4*>(grow + 4);
+          const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+          const Frag3 fg = split_frag(v);
+#pragma unroll
+          for (int t = 0; t < TPW; ++t) {
+            if (!on[t]) continue;  // uniform
+            const int ot = cg * TPW + t;
+            const int o = ot / KT, kt = ot - o * KT;
+            const unsigned short* wrow = Wimg + ((size_t)(o * 3) * KP + kt * 32 + l31) * WP + ks * 16 + 8 * half;
+            const u32x4 w1 = *reinterpret_cast<const u32x4*>(wrow);
+            const u32x4 w2 = *reinterpret_cast<const u32x4*>(wrow + (size_t)KP * WP);
+            const u32x4 w3 = *reinterpret_cast<const u32x4*>(wrow + (size_t)2 * KP * WP);
+            // rows of G x input columns: lane = input column, registers = rows; small terms first
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[2]), as_bf16x8(w1), acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[0]), as_bf16x8(w3), acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[1]), as_bf16x8(w2), acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[1]), as_bf16x8(w1), acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[0]), as_bf16x8(w2), acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[0]), as_bf16x8(w1), acc[t], 0, 0, 0);
+          }
+        }
+        // a store instruction writes 128 contiguous bytes of two rows
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          const int ot = cg * TPW + t;
+          const int o = ot / KT, kt = ot - o * KT;
+          const int col = kt * 32 + l31;
+          float* dst = a.dout[NOPS == 2 ? (o & 1) : 0];
+          const int64_t ldd = a.lddout[NOPS == 2 ? (o & 1) : 0];
+          if (col < a.k_in) {
+            float* op = dst + (int64_t)(row0 + rb * 32 + 4 * half) * ldd + col;
+            asm volatile("" : "+v"(op));
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+              const int r8 = (reg & 3) + 8 * (reg >> 2);
+              if (rb * 32 + 4 * half + r8 < valid) op[(int64_t)r8 * ldd] = acc[t][reg];
+            }
+          }
+        }
+      }
+    } else {
+      const bool on = t_w_s[NOPS == 2 ? wo : 0][seg] >= 0;
+      const float* irow = Ins + (NOPS == 2 ? wo : 0) * kFRows * IP;
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s) {
+        __builtin_amdgcn_sched_barrier(0);
+        float gv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) gv[u] = Gs[(16 * s + 8 * half + u) * GP + wj * 32 + l31];  // zero beyond `valid`
+        if (wo == 0) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) bsum += gv[u];
+        }
+        if (on) {  // uniform
+          const Frag3 fg = split_frag(gv);
+#pragma unroll
+          for (int t = 0; t < KT; ++t) {
+            if (t > 0) __builtin_amdgcn_sched_barrier(0);
+            float av[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) av[u] = irow[(16 * s + 8 * half + u) * IP + t * 32 + l31];
+            const Frag3 fa = split_frag(av);
+            const Frag3& L = TRANS ? fg : fa;
+            const Frag3& R = TRANS ? fa : fg;
+            wacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[2]), as_bf16x8(R.p[0]), wacc[t], 0, 0, 0);
+            wacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[0]), as_bf16x8(R.p[2]), wacc[t], 0, 0, 0);
+            wacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[1]), as_bf16x8(R.p[1]), wacc[t], 0, 0, 0);
+            wacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[1]), as_bf16x8(R.p[0]), wacc[t], 0, 0, 0);
+            wacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[0]), as_bf16x8(R.p[1]), wacc[t], 0, 0, 0);
+            wacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[0]), as_bf16x8(R.p[0]), wacc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if constexpr (RD) {
+#pragma unroll
+      for (int p = 0; p < GPASS; ++p) mem1[p] = mem2[p];
+    }
+    seg = nseg; row0 = nrow0; valid = nvalid;
+    nseg = n2seg; nrow0 = n2row0; nvalid = n2valid;
+  }
+  if (!is_dgrad) flush_w(cur_seg);
+}
+
+static bool fused_bwd_on() {
+  static const int env = getenv("GCMI_FUSED_BWD") ? atoi(getenv("GCMI_FUSED_BWD")) : 1;
+  return env != 0;
+}
+
+static std::atomic<int> g_fused_bwd{1};
+static std::atomic<int> g_fused_launches{0};
+int fused_bwd_launches() { return g_fused_launches.load(std::memory_order_relaxed); }
+void set_fused_bwd(int on) { g_fused_bwd.store(on ? 1 : 0, std::memory_order_relaxed); }
+int get_fused_bwd() { return g_fused_bwd.load(std::memory_order_relaxed); }
+bool fused_bwd_enabled() { return fused_bwd_on() && get_fused_bwd() != 0 && !gemm_exact_mode(); }
+
+template <int NG, int KT, int NOPS, bool TRANS, bool RD, bool DGRAD>
+static int launch_fused(const FusedTable& st, int n_tiles, const FusedArgs& a, hipStream_t sm) {
+  constexpr int KP = KT * 32;
+  size_t shmem = sizeof(float) * kFRows * (NG + 4) + sizeof(float) * (size_t)NOPS * kFRows * (KP + 4);
+  if (DGRAD) shmem += sizeof(unsigned short) * (size_t)NOPS * 3 * KP * (NG + 8);
+  auto kern = fused_bwd_kernel<NG, KT, NOPS, TRANS, RD, DGRAD>;
+  static bool attr_done = false;  // per instantiation
+  if (!attr_done) {
+    // exactly what is asked for: the kernel also has a few hundred bytes of static LDS (the segment table)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)shmem) != hipSuccess) {
+      (void)hipGetLastError();
+      return GCMI_ERR_UNSUPPORTED;
+    }
+    attr_done = true;
+  }
+  const int per_cu = DGRAD ? 1 : 2;
+  const int grid = std::min(n_tiles, 256 * per_cu);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(DGRAD ? 512 : 256), shmem, sm, st, n_tiles, a, next_sweep_direction());
+  GCMI_CHECK_LAUNCH("fused_bwd");
+  g_fused_launches.fetch_add(1, std::memory_order_relaxed);
+  return GCMI_OK;
+}
+
+static int make_table(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_end, const int64_t* w0_off,
+                      const int64_t* w1_off, const int64_t* db_off, FusedTable* st) {
+  memset(st, 0, sizeof(*st));
+  st->n_seg = n_seg;
+  int64_t tiles = 0;
+  for (int s = 0; s < kFMaxSeg; ++s) {
+    st->tile_start[s] = (int32_t)tiles;
+    st->w_off[0][s] = st->w_off[1][s] = st->db_off[s] = -1;
+    if (s < n_seg) {
+      st->seg_begin[s] = seg_begin[s];
+      st->seg_end[s] = seg_end[s];
+      st->w_off[0][s] = w0_off ? w0_off[s] : -1;
+      st->w_off[1][s] = w1_off ? w1_off[s] : -1;
+      st->db_off[s] = db_off ? db_off[s] : -1;
+      tiles += (seg_end[s] - seg_begin[s] + kFRows - 1) / kFRows;
+    }
+  }
+  st->tile_start[kFMaxSeg] = (int32_t)tiles;
+  return (int)tiles;
+}
+
+// GraphConv block: dW_rel += S^T G, dW_self += X^T G, dbsum += colsum G, and (d_ds != nullptr) dS = G W_rel^T,
+// dXs = G W_self^T.  GCMI_ERR_UNSUPPORTED = shape not covered (the caller runs the separate kernels).
+int fused_conv_bwd(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_end, const int64_t* w_rel,
+                   const int64_t* w_self, const int64_t* b_off, const float* d_dy, int64_t lddy, const float* d_gc,
+                   int64_t ldgc, const float* d_coef, int32_t width, const float* d_s, int64_t lds, const float* d_x,
+                   int64_t ldx, int32_t k_in, const float* d_w, float* d_dw, float* d_dbsum, float* d_ds_out,
+                   int64_t ldds, float* d_dxs_out, int64_t lddxs, hipStream_t sm) {
+  if (!fused_bwd_enabled() || n_seg > kFMaxSeg || width != 64) return GCMI_ERR_UNSUPPORTED;
+  if (!aligned16(d_dy) || lddy % 4 || !aligned16(d_gc) || ldgc % 4) return GCMI_ERR_UNSUPPORTED;
+  if (d_coef && !aligned16(d_coef)) return GCMI_ERR_UNSUPPORTED;
+  const bool dgrad = d_ds_out != nullptr;
+  FusedTable st;
+  const int tiles = make_table(n_seg, seg_begin, seg_end, w_rel, w_self, b_off, &st);
+  if (tiles == 0) return GCMI_OK;
+  FusedArgs a;
+  memset(&a, 0, sizeof(a));
+  a.dy = d_dy; a.lddy = lddy; a.x = d_gc; a.ldx = ldgc; a.coef = d_coef;
+  a.in[0] = d_s; a.ldin[0] = lds; a.in[1] = d_x; a.ldin[1] = ldx; a.k_in = k_in;
+  a.w = d_w; a.dw = d_dw; a.db = d_dbsum;
+  a.dout[0] = d_ds_out; a.lddout[0] = ldds; a.dout[1] = d_dxs_out; a.lddout[1] = lddxs;
+  if (dgrad) {
+    if (k_in > 32 && k_in <= 64) return launch_fused<64, 2, 2, false, false, true>(st, tiles, a, sm);
+    return GCMI_ERR_UNSUPPORTED;
+  }
+  if (k_in > 32 && k_in <= 64) return launch_fused<64, 2, 2, false, false, false>(st, tiles, a, sm);
+  if (k_in > 64 && k_in <= 96) return launch_fused<64, 3, 2, false, false, false>(st, tiles, a, sm);
+  return GCMI_ERR_UNSUPPORTED;
+}
+
+// Dense layer behind the GraphGather: dy recomputed from the per-molecule gradient, dW (n_out x k_in, nn.Linear
+// layout) += G^T P, db += colsum G, dP = G W.
+int fused_dense_bwd(int64_t n_rows, const int32_t* d_membership, const float* d_g2, int64_t ldg2,
+                    const int32_t* d_arg, const float* d_dense, int64_t ldd, const float* d_coef, int32_t width,
+                    const float* d_p, int64_t ldp, int32_t k_in, const float* d_w, float* d_dw, float* d_db,
+                    float* d_dp, int64_t lddp, hipStream_t sm) {
+  if (!fused_bwd_enabled() || width != 128 || k_in <= 32 || k_in > 64 || d_coef == nullptr) return GCMI_ERR_UNSUPPORTED;
+  if (!aligned16(d_g2) || ldg2 % 4 || !aligned16(d_arg) || !aligned16(d_dense) || ldd % 4 || !aligned16(d_coef))
+    return GCMI_ERR_UNSUPPORTED;
+  if (n_rows <= 0 || n_rows > INT32_MAX) return GCMI_ERR_UNSUPPORTED;
+  const int32_t zero = 0, nn = (int32_t)n_rows;
+  const int64_t off0 = 0;
+  FusedTable st;
+  const int tiles = make_table(1, &zero, &nn, &off0, nullptr, &off0, &st);
+  FusedArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = d_dense; a.ldx = ldd; a.coef = d_coef;
+  a.membership = d_membership; a.g2 = d_g2; a.ldg2 = ldg2; a.arg = d_arg;
+  a.in[0] = d_p; a.ldin[0] = ldp; a.k_in = k_in;
+  a.w = d_w; a.dw = d_dw; a.db = d_db;
+  a.dout[0] = d_dp; a.lddout[0] = lddp;
+  return launch_fused<128, 2, 1, true, true, true>(st, tiles, a, sm);
+}
+
+}  // namespace gcmi

@@ -104,6 +104,22 @@ int launch_seg_gemm4(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg
                      const int64_t* bias_off, int32_t n_out, int32_t trans_w, int32_t act, float* d_out,
                      int64_t ldo, hipStream_t sm, double* d_stats = nullptr);
 
+// bwd_fused.hip: BatchNorm-backward + weight gradients + input gradients of one block in one pass over the rows;
+// GCMI_ERR_UNSUPPORTED = switched off / exact mode / shape not covered (the caller runs the separate kernels)
+void set_fused_bwd(int on);
+int get_fused_bwd();
+bool fused_bwd_enabled();
+int fused_bwd_launches();  // launches of the one-pass kernel so far (tests)
+int fused_conv_bwd(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_end, const int64_t* w_rel,
+                   const int64_t* w_self, const int64_t* b_off, const float* d_dy, int64_t lddy, const float* d_gc,
+                   int64_t ldgc, const float* d_coef, int32_t width, const float* d_s, int64_t lds, const float* d_x,
+                   int64_t ldx, int32_t k_in, const float* d_w, float* d_dw, float* d_dbsum, float* d_ds_out,
+                   int64_t ldds, float* d_dxs_out, int64_t lddxs, hipStream_t sm);
+int fused_dense_bwd(int64_t n_rows, const int32_t* d_membership, const float* d_g2, int64_t ldg2,
+                    const int32_t* d_arg, const float* d_dense, int64_t ldd, const float* d_coef, int32_t width,
+                    const float* d_p, int64_t ldp, int32_t k_in, const float* d_w, float* d_dw, float* d_db,
+                    float* d_dp, int64_t lddp, hipStream_t sm);
+
 // accumulator replicas of the BatchNorm column sums (same-address fp64 atomics serialise); scratch layout in
 // doubles: [0, 2F) backward coefficient vectors, then kBnReplicas blocks of [sum(F) | sum of squares(F)]
 constexpr int kBnReplicas = 32;

@@ -567,18 +567,22 @@ using namespace gcmi;
 extern "C" {
 
 int gcmi_set_option(int32_t option, int32_t value) {
-  GCMI_CHECK_ARG(option == GCMI_OPT_GEMM_EXACT || option == GCMI_OPT_FUSED_BN_STATS, "set_option: unknown option %d",
-                 option);
+  GCMI_CHECK_ARG(option == GCMI_OPT_GEMM_EXACT || option == GCMI_OPT_FUSED_BN_STATS || option == GCMI_OPT_FUSED_BWD,
+                 "set_option: unknown option %d", option);
   if (option == GCMI_OPT_GEMM_EXACT) g_gemm_exact.store(value != 0 ? 1 : 0, std::memory_order_relaxed);
-  else g_fused_bn_stats.store(value != 0 ? 1 : 0, std::memory_order_relaxed);
+  else if (option == GCMI_OPT_FUSED_BN_STATS) g_fused_bn_stats.store(value != 0 ? 1 : 0, std::memory_order_relaxed);
+  else set_fused_bwd(value);
   return GCMI_OK;
 }
 
 int gcmi_get_option(int32_t option, int32_t* value) {
-  GCMI_CHECK_ARG((option == GCMI_OPT_GEMM_EXACT || option == GCMI_OPT_FUSED_BN_STATS) && value,
+  GCMI_CHECK_ARG((option == GCMI_OPT_GEMM_EXACT || option == GCMI_OPT_FUSED_BN_STATS || option == GCMI_OPT_FUSED_BWD ||
+                  option == GCMI_OPT_FUSED_BWD_LAUNCHES) && value,
                  "get_option: unknown option %d", option);
-  *value = option == GCMI_OPT_GEMM_EXACT ? g_gemm_exact.load(std::memory_order_relaxed)
-                                         : g_fused_bn_stats.load(std::memory_order_relaxed);
+  if (option == GCMI_OPT_GEMM_EXACT) *value = g_gemm_exact.load(std::memory_order_relaxed);
+  else if (option == GCMI_OPT_FUSED_BN_STATS) *value = g_fused_bn_stats.load(std::memory_order_relaxed);
+  else if (option == GCMI_OPT_FUSED_BWD) *value = get_fused_bwd();
+  else *value = fused_bwd_launches();
   return GCMI_OK;
 }
 

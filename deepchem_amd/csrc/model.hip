@@ -327,16 +327,37 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
   // ---- readout (+ folded BatchNorm of the dense layer, + its ReLU mask)
   float* dyD = ws + w.tA;   // grad w.r.t. the (normalised) readout input
   float* dxD = ws + w.tB;   // grad w.r.t. the dense pre-activation
+  const int Wl = m->conv_width[L - 1];
+  float* dpool = ws + w.tC;  // grad w.r.t. the output of the last GraphPool
+  const float* coef = ws + w.acc;  // [A | B | C] of the BatchNorm backward just computed (bn.hip: head of its scratch)
+  bool dense_done = false;
   if (m->batch_norm) {
     // GraphGather backward is recomputed inside the BatchNorm backward from the per-molecule
     // gradient (tanh derivative applied in place): the N x D gradient is never written or re-read
     RUN(readout_grad_prep(ws + w.dfp, 2 * D, io->d_fingerprint, 2 * D, B, D, st));
     const float* bnv = ws + w.bnv[L];
+    const bool try_fused = fused_bwd_enabled() && D == 128 && Wl > 32 && Wl <= 64;
     RUN(bn_bwd_readout_impl(g->d_membership, ws + w.dfp, 2 * D, reinterpret_cast<const int32_t*>(ws + w.arg_r),
                             ws + w.dense, D, N, D, d_params + m->off_bn_gamma[L], bnv, bnv + D,
-                            d_grads + m->off_bn_gamma[L], d_grads + m->off_bn_beta[L], dxD, D, 1,
+                            d_grads + m->off_bn_gamma[L], d_grads + m->off_bn_beta[L], try_fused ? nullptr : dxD, D, 1,
                             reinterpret_cast<double*>(ws + w.acc), true, stream, ws + w.rsum, g->d_mol_runs,
                             g->n_mols, g->max_deg + 1));
+    if (try_fused) {
+      // one pass: dxD formed per 64-row tile in LDS, dW_dense += dxD^T pool, db += colsum, dpool = dxD W_dense
+      TimedScope ts(GCMI_K_SEG_GEMM, st);
+      const int rc = fused_dense_bwd(N, g->d_membership, ws + w.dfp, 2 * D,
+                                     reinterpret_cast<const int32_t*>(ws + w.arg_r), ws + w.dense, D, coef, D,
+                                     ws + w.pool[L - 1], Wl, Wl, d_params + m->off_dense_w, d_grads + m->off_dense_w,
+                                     d_grads + m->off_dense_b, dpool, Wl, st);
+      if (rc == GCMI_OK) dense_done = true;
+      else if (rc != GCMI_ERR_UNSUPPORTED) return rc;
+      else  // not covered after all (misaligned buffers): the separate pass, with its sums once more
+        RUN(bn_bwd_readout_impl(g->d_membership, ws + w.dfp, 2 * D, reinterpret_cast<const int32_t*>(ws + w.arg_r),
+                                ws + w.dense, D, N, D, d_params + m->off_bn_gamma[L], bnv, bnv + D,
+                                d_grads + m->off_bn_gamma[L], d_grads + m->off_bn_beta[L], dxD, D, 1,
+                                reinterpret_cast<double*>(ws + w.acc), true, stream, ws + w.rsum, g->d_mol_runs,
+                                g->n_mols, g->max_deg + 1));
+    }
   } else {
     RUN(gcmi_readout_bwd(g, ws + w.dfp, 2 * D, io->d_fingerprint, 2 * D, D, 1,
                          reinterpret_cast<const int32_t*>(ws + w.arg_r), dyD, D, stream));
@@ -344,12 +365,12 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
     dxD = dyD;
   }
   // ---- dense layer
-  const int Wl = m->conv_width[L - 1];
-  RUN(gcmi_seg_gemm_wgrad(1, &zero32, &nN, ws + w.pool[L - 1], Wl, Wl, dxD, D, D, d_grads + m->off_dense_w,
-                          &zero64, d_grads + m->off_dense_b, &zero64, 1, stream));
-  float* dpool = ws + w.tC;  // grad w.r.t. the output of the last GraphPool
-  RUN(gcmi_seg_gemm(1, &zero32, &nN, dxD, D, D, d_params + m->off_dense_w, &zero64, nullptr, 0, 0, nullptr,
-                    nullptr, nullptr, nullptr, Wl, 0, 0, dpool, Wl, stream));
+  if (!dense_done) {
+    RUN(gcmi_seg_gemm_wgrad(1, &zero32, &nN, ws + w.pool[L - 1], Wl, Wl, dxD, D, D, d_grads + m->off_dense_w,
+                            &zero64, d_grads + m->off_dense_b, &zero64, 1, stream));
+    RUN(gcmi_seg_gemm(1, &zero32, &nN, dxD, D, D, d_params + m->off_dense_w, &zero64, nullptr, 0, 0, nullptr,
+                      nullptr, nullptr, nullptr, Wl, 0, 0, dpool, Wl, stream));
+  }
   // ---- GraphConv / BatchNorm / GraphPool blocks, last to first
   for (int l = L - 1; l >= 0; --l) {
     if (!full && !m->batch_norm) break;  // nothing trainable in front of the dense layer
@@ -359,38 +380,71 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
     if (!sym) RUN(zero(dy, sizeof(float) * (size_t)(N * W)));
     RUN(gcmi_gather_max_bwd(g, dpool, W, W, reinterpret_cast<const uint8_t*>(ws + w.arg[l]), dy, W, stream));
     float* dgc = ws + w.tA;  // grad w.r.t. the GraphConv pre-activation
+    const Segs sg = make_segs(g, K, W);
+    const float* xin = l == 0 ? io->d_atom_features : ws + w.pool[l - 1];
+    const int64_t ldx = l == 0 ? io->ld_features : m->conv_width[l - 1];
+    float* dS = ws + w.tE;
+    float* dX = ws + w.tC;
+    // the fused pass covers the default widths in split-bf16 mode; it wants 16-byte rows of every operand
+    const bool try_fused = full && fused_bwd_enabled() && W == 64 && ldx % 4 == 0 && aligned16(xin) &&
+                           ((l == 0 && K > 32 && K <= 96) || (l > 0 && K > 32 && K <= 64));
     if (m->batch_norm) {
       const float* bnv = ws + w.bnv[l];
       RUN(bn_bwd_impl(dy, W, ws + w.gc[l], W, N, W, d_params + m->off_bn_gamma[l], bnv, bnv + W,
-                      d_grads + m->off_bn_gamma[l], d_grads + m->off_bn_beta[l], full ? dgc : nullptr, W, 1,
-                      reinterpret_cast<double*>(ws + w.acc), true, stream));
-    } else if (full) {
+                      d_grads + m->off_bn_gamma[l], d_grads + m->off_bn_beta[l], (full && !try_fused) ? dgc : nullptr, W,
+                      1, reinterpret_cast<double*>(ws + w.acc), true, stream));
+    } else if (full && !try_fused) {
       RUN(gcmi_relu_bwd(dy, W, ws + w.gc[l], W, N, W, stream));
       dgc = dy;
     }
     if (!full) break;  // reference semantics: nothing in front of a GraphConv output trains
-    const Segs sg = make_segs(g, K, W);
-    const float* xin = l == 0 ? io->d_atom_features : ws + w.pool[l - 1];
-    const int64_t ldx = l == 0 ? io->ld_features : m->conv_width[l - 1];
-    RUN(gcmi_seg_gemm_wgrad(sg.n, sg.begin, sg.end, ws + w.S[l], w.ldS[l], K, dgc, W, W,
-                            d_grads + m->off_conv_w[l], sg.w_rel, nullptr, nullptr, 0, stream));
-    RUN(gcmi_seg_gemm_wgrad(sg.n, sg.begin, sg.end, xin, ldx, K, dgc, W, W, d_grads + m->off_conv_w[l],
-                            sg.w_self, ws + w.dbsum[l], sg.b_off, 0, stream));
+    bool fused_done = false;
+    if (try_fused) {
+      // one pass over the rows: dgc formed per tile in LDS; dW_rel, dW_self, dbsum; and for l > 0 dS = dgc W_rel^T
+      // and the self part of dX
+      TimedScope ts(GCMI_K_SEG_GEMM, st);
+      const int rc = fused_conv_bwd(sg.n, sg.begin, sg.end, sg.w_rel, sg.w_self, sg.b_off, dy, W, ws + w.gc[l], W,
+                                    m->batch_norm ? coef : nullptr, W, ws + w.S[l], w.ldS[l], xin, ldx, K,
+                                    d_params + m->off_conv_w[l], d_grads + m->off_conv_w[l], ws + w.dbsum[l],
+                                    l > 0 ? dS : nullptr, K, l > 0 ? dX : nullptr, K, st);
+      if (rc == GCMI_OK) fused_done = true;
+      else if (rc != GCMI_ERR_UNSUPPORTED) return rc;
+      else if (m->batch_norm) {  // not covered after all (misaligned buffers): the separate pass, sums once more
+        const float* bnv = ws + w.bnv[l];
+        RUN(bn_bwd_impl(dy, W, ws + w.gc[l], W, N, W, d_params + m->off_bn_gamma[l], bnv, bnv + W,
+                        d_grads + m->off_bn_gamma[l], d_grads + m->off_bn_beta[l], dgc, W, 1,
+                        reinterpret_cast<double*>(ws + w.acc), true, stream));
+      } else {
+        RUN(gcmi_relu_bwd(dy, W, ws + w.gc[l], W, N, W, stream));
+        dgc = dy;
+      }
+    }
+    if (!fused_done) {
+      RUN(gcmi_seg_gemm_wgrad(sg.n, sg.begin, sg.end, ws + w.S[l], w.ldS[l], K, dgc, W, W,
+                              d_grads + m->off_conv_w[l], sg.w_rel, nullptr, nullptr, 0, stream));
+      RUN(gcmi_seg_gemm_wgrad(sg.n, sg.begin, sg.end, xin, ldx, K, dgc, W, W, d_grads + m->off_conv_w[l],
+                              sg.w_self, ws + w.dbsum[l], sg.b_off, 0, stream));
+    }
     hipLaunchKernelGGL(bias_unpack_kernel, dim3(4), dim3(256), 0, st, ws + w.dbsum[l], m->max_deg, W,
                        d_grads + m->off_conv_b[l]);
     GCMI_CHECK_LAUNCH("bias_unpack");
     if (l == 0) break;  // the atom features need no gradient
     // dS = dgc . W_rel^T ; dX = dgc . W_self^T + (transposed gather of dS)
-    float* dS = ws + w.tE;
-    float* dX = ws + w.tC;
-    RUN(gcmi_seg_gemm(sg.n, sg.begin, sg.end, dgc, W, W, d_params + m->off_conv_w[l], sg.w_rel, nullptr, 0,
-                      0, nullptr, nullptr, nullptr, nullptr, K, 1, 0, dS, K, stream));
-    // bonds listed from both ends: the scatter of dS is a gather (LDS-window kernel), and the
-    // self term accumulates onto it in the GEMM epilogue
-    if (sym) RUN(gcmi_gather_sum_fwd(g, dS, K, K, dX, K, 0, stream));
-    RUN(gcmi_seg_gemm(sg.n, sg.begin, sg.end, dgc, W, W, d_params + m->off_conv_w[l], sg.w_self, nullptr, 0,
-                      0, nullptr, nullptr, nullptr, nullptr, K, 1, sym ? 2 : 0, dX, K, stream));
-    if (!sym) RUN(gcmi_scatter_add(g, dS, K, K, dX, K, stream));
+    if (fused_done) {
+      // dX holds the self part: the neighbour part is added onto it (bonds listed from both ends: the scatter
+      // of dS is a gather)
+      if (sym) RUN(gcmi_gather_sum_fwd(g, dS, K, K, dX, K, 1, stream));
+      else RUN(gcmi_scatter_add(g, dS, K, K, dX, K, stream));
+    } else {
+      RUN(gcmi_seg_gemm(sg.n, sg.begin, sg.end, dgc, W, W, d_params + m->off_conv_w[l], sg.w_rel, nullptr, 0,
+                        0, nullptr, nullptr, nullptr, nullptr, K, 1, 0, dS, K, stream));
+      // bonds listed from both ends: the scatter of dS is a gather (LDS-window kernel), and the
+      // self term accumulates onto it in the GEMM epilogue
+      if (sym) RUN(gcmi_gather_sum_fwd(g, dS, K, K, dX, K, 0, stream));
+      RUN(gcmi_seg_gemm(sg.n, sg.begin, sg.end, dgc, W, W, d_params + m->off_conv_w[l], sg.w_self, nullptr, 0,
+                        0, nullptr, nullptr, nullptr, nullptr, K, 1, sym ? 2 : 0, dX, K, stream));
+      if (!sym) RUN(gcmi_scatter_add(g, dS, K, K, dX, K, stream));
+    }
     dpool = dX;
   }
   return GCMI_OK;

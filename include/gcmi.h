@@ -111,7 +111,14 @@ enum {
   GCMI_OPT_GEMM_EXACT = 1,
   /* 1 (default): the training forward of the whole-model entry points takes the BatchNorm column sums from the
    * epilogue of the producing product; 0: separate column-sum launches (same statistics up to summation order) */
-  GCMI_OPT_FUSED_BN_STATS = 2
+  GCMI_OPT_FUSED_BN_STATS = 2,
+  /* 1 (default): the whole-model backward forms the gradient of a block's pre-activation in LDS and computes the
+   * weight gradients and the input gradients from it in one pass over the rows (bwd_fused.hip; split-bf16 mode,
+   * default widths); 0: separate BatchNorm-backward, weight-gradient and input-gradient launches (same arithmetic
+   * up to summation order).  Environment: GCMI_FUSED_BWD=0 before the library is loaded.                        */
+  GCMI_OPT_FUSED_BWD = 3,
+  /* read-only (gcmi_get_option): launches of the one-pass backward kernel in this process so far */
+  GCMI_OPT_FUSED_BWD_LAUNCHES = 4
 };
 int gcmi_set_option(int32_t option, int32_t value);
 int gcmi_get_option(int32_t option, int32_t* value);
