@@ -546,6 +546,17 @@ int bn_bwd_readout_impl(const int32_t* d_membership, const float* d_g2, int64_t 
                     lddx, relu_mask, d_acc, acc_clean, stream);
 }
 
+int bn_bwd_params_impl(int64_t n_rows, int32_t n_feat, const float* d_gamma, const float* d_mean,
+                       const float* d_invstd, float* d_dgamma, float* d_dbeta, double* d_acc, void* stream) {
+  GCMI_CHECK_ARG(n_feat > 0 && n_rows > 0 && d_mean && d_invstd && d_acc, "bn_bwd_params: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  TimedScope ts(GCMI_K_BATCHNORM, st);
+  hipLaunchKernelGGL(bn_bwd_params_kernel, dim3((n_feat + 255) / 256), dim3(256), 0, st, d_acc, n_rows, n_feat,
+                     d_gamma, d_mean, d_invstd, d_dgamma, d_dbeta, reinterpret_cast<float*>(d_acc));
+  GCMI_CHECK_LAUNCH("bn_bwd_params");
+  return GCMI_OK;
+}
+
 static int bn_bwd_any(const ReadoutGrad* rgp, const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx,
                       int64_t n_rows, int32_t n_feat, const float* d_gamma, const float* d_mean,
                       const float* d_invstd, float* d_dgamma, float* d_dbeta, float* d_dx, int64_t lddx,

@@ -39,25 +39,27 @@ struct FusedTable {
 
 struct FusedArgs {
   // sources of G
+  // (leading dimensions and element offsets are 32-bit: every array is < 4 GB, checked by the launchers; an
+  // address is then a scalar base plus one 32-bit register instead of a 64-bit register pair per load stream)
   const float* dy;       // incoming gradient rows (nullptr: recomputed from the readout gradient)
-  int64_t lddy;
+  int32_t lddy;
   const float* x;        // BatchNorm input = the block's ReLU output
-  int64_t ldx;
+  int32_t ldx;
   const float* coef;     // [A | B | C], 3 * NG floats; nullptr: G = relu'(x) * dy
   const int32_t* membership;
   const float* g2;       // n_mols x ldg2: [dsum | dmax]
-  int64_t ldg2;
+  int32_t ldg2;
   const int32_t* arg;    // n_mols x NG
   // weight-gradient operands
   const float* in[2];
-  int64_t ldin[2];
+  int32_t ldin[2];
   int32_t k_in;
   const float* w;
   float* dw;
   float* db;
   // input gradients (DGRAD)
   float* dout[2];
-  int64_t lddout[2];
+  int32_t lddout[2];
 };
 
 template <int NG, int KT, int NOPS, bool TRANS, bool RD, bool DGRAD>
@@ -77,6 +79,9 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
   constexpr int STEPS = kFRows / 16;          // k-steps of the weight-gradient contraction
   constexpr int OT = NOPS * KT;               // 32-column tiles of the input gradients
   constexpr int TPW = OT / 2;                 // ... per dgrad wave (two waves per 32-row block)
+  constexpr int OP = OT * 32 + 8;             // pitch of a row of the input-gradient tile in LDS (floats)
+  constexpr int OQ = OT * 8;                  // its 16-byte pieces
+  constexpr int OPASS = DGRAD ? kFRows * OQ / NT : 1;
   static_assert(NOPS * NJ == 4, "four weight-gradient waves: one (operand, column group) each");
   static_assert(!DGRAD || (OT % 2 == 0), "input-gradient tiles split over two waves per row block");
   static_assert(kFRows * IQ % NT == 0, "In tile loads divide evenly");
@@ -84,12 +89,14 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
   float* Gs = reinterpret_cast<float*>(lds_raw);
   float* Ins = Gs + kFRows * GP;                                   // [NOPS][64][IP]
   unsigned short* Wimg = reinterpret_cast<unsigned short*>(Ins + NOPS * kFRows * IP);
+  float* Outs = reinterpret_cast<float*>(Wimg + (DGRAD ? (size_t)NOPS * 3 * KP * WP : 0));  // [64][OP] (DGRAD)
   // the segment table, in LDS (indexing the by-value struct dynamically would go through scratch)
   __shared__ int t_begin_s[kFMaxSeg], t_end_s[kFMaxSeg], t_tile_s[kFMaxSeg + 1];
   __shared__ long long t_w_s[2][kFMaxSeg], t_db_s[kFMaxSeg];
+  __shared__ __attribute__((aligned(16))) float coef_s[3 * NG];  // [A | B | C] of the BatchNorm backward
 
   const int tid = threadIdx.x;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: role tests and table picks stay off the vector unit
   const int lane = tid & 63;
   const int half = lane >> 5;
   const int l31 = lane & 31;
@@ -111,13 +118,11 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
     }
   }
   const int n_seg = st.n_seg;
-  __syncthreads();
 
   const int b = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
   const int t_begin = (int)((int64_t)b * n_tiles / gridDim.x);
   const int t_end = (int)((int64_t)(b + 1) * n_tiles / gridDim.x);
-  const int my_tiles = t_end - t_begin;
-  if (my_tiles <= 0) return;
+  const int my_tiles = t_end - t_begin;  // >= 1: the grid is never larger than the tile count
   auto tile_at = [&](int i) { return rev ? t_end - 1 - i : t_begin + i; };
   auto tile_info = [&](int tile, int& seg, int& row0, int& valid) {
     int s = 0;
@@ -131,40 +136,34 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
   // ---- per-thread constants of the G phase: this thread's 16-byte column piece
   const int gq = tid % QPR;
   const int gr = tid / QPR;
-  float cA[4] = {1.f, 1.f, 1.f, 1.f}, cB[4] = {0.f, 0.f, 0.f, 0.f}, cC[4] = {0.f, 0.f, 0.f, 0.f};
-  if (a.coef != nullptr) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      cA[q] = a.coef[4 * gq + q];
-      cB[q] = a.coef[NG + 4 * gq + q];
-      cC[q] = a.coef[2 * NG + 4 * gq + q];
-    }
-  }
+  for (int c = tid; c < 3 * NG; c += NT) coef_s[c] = a.coef != nullptr ? a.coef[c] : (c < NG ? 1.f : 0.f);
+
+  __syncthreads();
 
   // ---- prefetch registers (one tile ahead; the molecule index two tiles ahead): all loads are 16 bytes per lane,
   // unconditional, from clamped addresses; what lies outside the tile is zeroed when it goes to LDS
   float4 pdy[GPASS], px[GPASS], pgm[RD ? GPASS : 1], pin[NOPS][IPASS];
   int4 parg[RD ? GPASS : 1];
-  int mem1[RD ? GPASS : 1], mem2[RD ? GPASS : 1];
+  int mem1[RD ? GPASS : 1];
   auto clampr = [](int r, int valid) { return r < valid ? r : valid - 1; };
   auto load_mem = [&](int row0, int valid, int (&mem)[RD ? GPASS : 1]) {
     if constexpr (RD) {
 #pragma unroll
-      for (int p = 0; p < GPASS; ++p) mem[p] = a.membership[row0 + clampr(gr + p * RPP, valid)];
+      for (int p = 0; p < GPASS; ++p) mem[p] = a.membership[(unsigned)(row0 + clampr(gr + p * RPP, valid))];
     }
   };
   auto load_src = [&](int row0, int valid) {
 #pragma unroll
     for (int p = 0; p < GPASS; ++p) {
-      const int64_t r = row0 + clampr(gr + p * RPP, valid);
-      px[p] = *reinterpret_cast<const float4*>(a.x + r * a.ldx + 4 * gq);
+      const unsigned r = (unsigned)(row0 + clampr(gr + p * RPP, valid));
+      px[p] = *reinterpret_cast<const float4*>(a.x + (r * (unsigned)a.ldx + 4u * gq));
       if constexpr (RD) {
-        const int64_t m = mem1[p];
-        pdy[p] = *reinterpret_cast<const float4*>(a.g2 + m * a.ldg2 + 4 * gq);
-        pgm[p] = *reinterpret_cast<const float4*>(a.g2 + m * a.ldg2 + NG + 4 * gq);
-        parg[p] = *reinterpret_cast<const int4*>(a.arg + m * NG + 4 * gq);
+        const unsigned m = (unsigned)mem1[p];
+        pdy[p] = *reinterpret_cast<const float4*>(a.g2 + (m * (unsigned)a.ldg2 + 4u * gq));
+        pgm[p] = *reinterpret_cast<const float4*>(a.g2 + (m * (unsigned)a.ldg2 + NG + 4u * gq));
+        parg[p] = *reinterpret_cast<const int4*>(a.arg + (m * (unsigned)NG + 4u * gq));
       } else {
-        pdy[p] = *reinterpret_cast<const float4*>(a.dy + r * a.lddy + 4 * gq);
+        pdy[p] = *reinterpret_cast<const float4*>(a.dy + (r * (unsigned)a.lddy + 4u * gq));
       }
     }
 #pragma unroll
@@ -173,9 +172,9 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
       for (int p = 0; p < IPASS; ++p) {
         const int slot = tid + p * NT;
         const int r = slot / IQ, q = slot - r * IQ;
-        const int64_t ld = a.ldin[o];
+        const int ld = a.ldin[o];
         const int qc = 4 * q + 4 <= ld ? 4 * q : 0;
-        pin[o][p] = *reinterpret_cast<const float4*>(a.in[o] + (int64_t)(row0 + clampr(r, valid)) * ld + qc);
+        pin[o][p] = *reinterpret_cast<const float4*>(a.in[o] + ((unsigned)(row0 + clampr(r, valid)) * (unsigned)ld + qc));
       }
     }
   };
@@ -190,11 +189,12 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
   auto flush_w = [&](int seg) {
     const int64_t woff = t_w_s[NOPS == 2 ? wo : 0][seg];
     if (woff >= 0) {
-      // this lane's first element; the pointer is made opaque so that the 32 addresses behind it are formed here
+      // this lane's first element; its offset is made opaque so that the 32 addresses behind it are formed here
       // and not hoisted out of the tile loop into 64 registers
-      float* wp = a.dw + woff + (TRANS ? (int64_t)(wj * 32 + 4 * half) * a.k_in + l31
-                                       : (int64_t)(4 * half) * NG + wj * 32 + l31);
-      asm volatile("" : "+v"(wp));
+      int64_t woff_lane = woff + (TRANS ? (int64_t)(wj * 32 + 4 * half) * a.k_in + l31
+                                        : (int64_t)(4 * half) * NG + wj * 32 + l31);
+      asm volatile("" : "+v"(woff_lane));  // (an offset, not the pointer: the pointer keeps its address space)
+      float* wp = a.dw + woff_lane;
 #pragma unroll
       for (int t = 0; t < KT; ++t) {
 #pragma unroll
@@ -220,6 +220,27 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
     bsum = 0.f;
   };
 
+  // The input-gradient tile leaves through LDS: the waves that computed it hold (column, 16 rows) per lane, which as
+  // global stores would be 32 dword stores per lane -- and, issued behind the next tile's loads, every wave's wait
+  // for those loads (one instruction stream for both roles: the wait cannot tell which role it is in) would also
+  // wait for the store acknowledgements.  Written out by all threads at the start of the next tile instead: whole
+  // rows, 16 bytes per lane, and in program order BEFORE the loads that follow.
+  auto store_out = [&](int prow0, int pvalid) {
+    if constexpr (DGRAD) {
+#pragma unroll
+      for (int p = 0; p < OPASS; ++p) {
+        const int slot = tid + p * NT;
+        const int r = slot / OQ, q = slot - r * OQ;
+        const int o = q / (KT * 8), qq = q - o * (KT * 8);
+        float* dst = (NOPS == 2 && o == 1) ? a.dout[1] : a.dout[0];
+        const int ldd = (NOPS == 2 && o == 1) ? a.lddout[1] : a.lddout[0];
+        if (r < pvalid && 4 * qq < a.k_in)  // k_in % 4 == 0 (launcher)
+          *reinterpret_cast<float4*>(dst + ((unsigned)(prow0 + r) * (unsigned)ldd + 4u * qq)) =
+              *reinterpret_cast<const float4*>(Outs + r * OP + 4 * q);
+      }
+    }
+  };
+
   // ---- prologue: sources of the first tile, molecule indices of the first two
   int seg, row0, valid;
   tile_info(tile_at(0), seg, row0, valid);
@@ -229,6 +250,7 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
   load_src(row0, valid);
   load_mem(nrow0, nvalid, mem1);  // mem1 now describes tile 1: its sources are requested in phase (b) of tile 0
   int cur_seg = -1;
+  int prow0 = row0, pvalid = 0;
 
   for (int i = 0; i < my_tiles; ++i) {
     if (seg != cur_seg) {
@@ -277,6 +299,11 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) dyv[q] = dyv[q] + (av[q] == rg ? gm[q] : 0.f);
       }
+      const float4 cA4 = *reinterpret_cast<const float4*>(coef_s + 4 * gq);
+      const float4 cB4 = *reinterpret_cast<const float4*>(coef_s + NG + 4 * gq);
+      const float4 cC4 = *reinterpret_cast<const float4*>(coef_s + 2 * NG + 4 * gq);
+      const float cA[4] = {cA4.x, cA4.y, cA4.z, cA4.w}, cB[4] = {cB4.x, cB4.y, cB4.z, cB4.w};
+      const float cC[4] = {cC4.x, cC4.y, cC4.z, cC4.w};
       float o[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -301,13 +328,14 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
         *reinterpret_cast<float4*>(Ins + (o * kFRows + r) * IP + 4 * q) = v;
       }
     }
+    if (i > 0) store_out(prow0, pvalid);  // the previous tile's input gradients (written before the last barrier)
     __syncthreads();
 
     // ---- phase (b): next tile's sources in flight, products from LDS
     int n2seg = nseg, n2row0 = nrow0, n2valid = nvalid;
     if (i + 2 < my_tiles) tile_info(tile_at(i + 2), n2seg, n2row0, n2valid);
-    load_src(nrow0, nvalid);             // uses mem1 = molecule indices of the next tile
-    load_mem(n2row0, n2valid, mem2);     // and the indices of the tile after it
+    load_src(nrow0, nvalid);             // uses mem1 = molecule indices of the next tile (read when the loads issue)
+    load_mem(n2row0, n2valid, mem1);     // ... which the indices of the tile after it then replace
     if (is_dgrad) {
       if constexpr (DGRAD) {
         f32x16 acc[TPW];
@@ -347,23 +375,12 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[0]), as_bf16x8(w1), acc[t], 0, 0, 0);
           }
         }
-        // a store instruction writes 128 contiguous bytes of two rows
+        // -> LDS, [row][tile * 32 + column]: 32 consecutive banks per half-wave, the halves 32 banks apart
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
-          const int ot = cg * TPW + t;
-          const int o = ot / KT, kt = ot - o * KT;
-          const int col = kt * 32 + l31;
-          float* dst = a.dout[NOPS == 2 ? (o & 1) : 0];
-          const int64_t ldd = a.lddout[NOPS == 2 ? (o & 1) : 0];
-          if (col < a.k_in) {
-            float* op = dst + (int64_t)(row0 + rb * 32 + 4 * half) * ldd + col;
-            asm volatile("" : "+v"(op));
+          float* orow = Outs + (rb * 32 + 4 * half) * OP + (cg * TPW + t) * 32 + l31;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-              const int r8 = (reg & 3) + 8 * (reg >> 2);
-              if (rb * 32 + 4 * half + r8 < valid) op[(int64_t)r8 * ldd] = acc[t][reg];
-            }
-          }
+          for (int reg = 0; reg < 16; ++reg) orow[((reg & 3) + 8 * (reg >> 2)) * OP] = acc[t][reg];
         }
       }
     } else {
@@ -401,13 +418,11 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
       }
     }
     __syncthreads();
-    if constexpr (RD) {
-#pragma unroll
-      for (int p = 0; p < GPASS; ++p) mem1[p] = mem2[p];
-    }
+    prow0 = row0; pvalid = valid;
     seg = nseg; row0 = nrow0; valid = nvalid;
     nseg = n2seg; nrow0 = n2row0; nvalid = n2valid;
   }
+  store_out(prow0, pvalid);
   if (!is_dgrad) flush_w(cur_seg);
 }
 
@@ -427,7 +442,7 @@ template <int NG, int KT, int NOPS, bool TRANS, bool RD, bool DGRAD>
 static int launch_fused(const FusedTable& st, int n_tiles, const FusedArgs& a, hipStream_t sm) {
   constexpr int KP = KT * 32;
   size_t shmem = sizeof(float) * kFRows * (NG + 4) + sizeof(float) * (size_t)NOPS * kFRows * (KP + 4);
-  if (DGRAD) shmem += sizeof(unsigned short) * (size_t)NOPS * 3 * KP * (NG + 8);
+  if (DGRAD) shmem += sizeof(unsigned short) * (size_t)NOPS * 3 * KP * (NG + 8) + sizeof(float) * kFRows * (NOPS * KT * 32 + 8);
   auto kern = fused_bwd_kernel<NG, KT, NOPS, TRANS, RD, DGRAD>;
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
@@ -476,6 +491,12 @@ int fused_conv_bwd(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
                    int64_t ldx, int32_t k_in, const float* d_w, float* d_dw, float* d_dbsum, float* d_ds_out,
                    int64_t ldds, float* d_dxs_out, int64_t lddxs, hipStream_t sm) {
   if (!fused_bwd_enabled() || n_seg > kFMaxSeg || width != 64) return GCMI_ERR_UNSUPPORTED;
+  {  // 32-bit element offsets inside the kernel: every array below 2^30 elements
+    int64_t rows = 0;
+    for (int sgi = 0; sgi < n_seg; ++sgi) rows = std::max<int64_t>(rows, seg_end[sgi]);
+    const int64_t ldmax = std::max(std::max(lddy, ldgc), std::max(std::max(lds, ldx), std::max(ldds, lddxs)));
+    if (rows * ldmax >= (int64_t)1 << 30) return GCMI_ERR_UNSUPPORTED;
+  }
   if (!aligned16(d_dy) || lddy % 4 || !aligned16(d_gc) || ldgc % 4) return GCMI_ERR_UNSUPPORTED;
   if (d_coef && !aligned16(d_coef)) return GCMI_ERR_UNSUPPORTED;
   const bool dgrad = d_ds_out != nullptr;
@@ -484,11 +505,12 @@ int fused_conv_bwd(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
   if (tiles == 0) return GCMI_OK;
   FusedArgs a;
   memset(&a, 0, sizeof(a));
-  a.dy = d_dy; a.lddy = lddy; a.x = d_gc; a.ldx = ldgc; a.coef = d_coef;
-  a.in[0] = d_s; a.ldin[0] = lds; a.in[1] = d_x; a.ldin[1] = ldx; a.k_in = k_in;
+  a.dy = d_dy; a.lddy = (int32_t)lddy; a.x = d_gc; a.ldx = (int32_t)ldgc; a.coef = d_coef;
+  a.in[0] = d_s; a.ldin[0] = (int32_t)lds; a.in[1] = d_x; a.ldin[1] = (int32_t)ldx; a.k_in = k_in;
   a.w = d_w; a.dw = d_dw; a.db = d_dbsum;
-  a.dout[0] = d_ds_out; a.lddout[0] = ldds; a.dout[1] = d_dxs_out; a.lddout[1] = lddxs;
+  a.dout[0] = d_ds_out; a.lddout[0] = (int32_t)ldds; a.dout[1] = d_dxs_out; a.lddout[1] = (int32_t)lddxs;
   if (dgrad) {
+    if (k_in % 4 || ldds % 4 || lddxs % 4 || !aligned16(d_ds_out) || !aligned16(d_dxs_out)) return GCMI_ERR_UNSUPPORTED;
     if (k_in > 32 && k_in <= 64) return launch_fused<64, 2, 2, false, false, true>(st, tiles, a, sm);
     return GCMI_ERR_UNSUPPORTED;
   }
@@ -506,18 +528,19 @@ int fused_dense_bwd(int64_t n_rows, const int32_t* d_membership, const float* d_
   if (!fused_bwd_enabled() || width != 128 || k_in <= 32 || k_in > 64 || d_coef == nullptr) return GCMI_ERR_UNSUPPORTED;
   if (!aligned16(d_g2) || ldg2 % 4 || !aligned16(d_arg) || !aligned16(d_dense) || ldd % 4 || !aligned16(d_coef))
     return GCMI_ERR_UNSUPPORTED;
-  if (n_rows <= 0 || n_rows > INT32_MAX) return GCMI_ERR_UNSUPPORTED;
+  if (n_rows <= 0 || n_rows > INT32_MAX || k_in % 4 || lddp % 4 || !aligned16(d_dp)) return GCMI_ERR_UNSUPPORTED;
+  if (n_rows * std::max<int64_t>(std::max(ldd, ldg2), std::max(ldp, lddp)) >= (int64_t)1 << 30) return GCMI_ERR_UNSUPPORTED;
   const int32_t zero = 0, nn = (int32_t)n_rows;
   const int64_t off0 = 0;
   FusedTable st;
   const int tiles = make_table(1, &zero, &nn, &off0, nullptr, &off0, &st);
   FusedArgs a;
   memset(&a, 0, sizeof(a));
-  a.x = d_dense; a.ldx = ldd; a.coef = d_coef;
-  a.membership = d_membership; a.g2 = d_g2; a.ldg2 = ldg2; a.arg = d_arg;
-  a.in[0] = d_p; a.ldin[0] = ldp; a.k_in = k_in;
+  a.x = d_dense; a.ldx = (int32_t)ldd; a.coef = d_coef;
+  a.membership = d_membership; a.g2 = d_g2; a.ldg2 = (int32_t)ldg2; a.arg = d_arg;
+  a.in[0] = d_p; a.ldin[0] = (int32_t)ldp; a.k_in = k_in;
   a.w = d_w; a.dw = d_dw; a.db = d_db;
-  a.dout[0] = d_dp; a.lddout[0] = lddp;
+  a.dout[0] = d_dp; a.lddout[0] = (int32_t)lddp;
   return launch_fused<128, 2, 1, true, true, true>(st, tiles, a, sm);
 }
 

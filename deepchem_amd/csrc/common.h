@@ -68,11 +68,19 @@ int check_graph(const gcmi_graph* g, bool need_cols);
 bool win_usable(const gcmi_graph* g, int n_feat, bool aux);
 bool win_has_width(int n_feat);
 int win_gather_sum(const gcmi_graph* g, const float* d_x, int64_t ldx, int n_feat, float* d_s,
-                   int64_t lds, hipStream_t st);
+                   int64_t lds, hipStream_t st, bool accumulate = false);
 int win_gather_max(const gcmi_graph* g, const float* d_x, int64_t ldx, int n_feat, const float* d_scale,
                    const float* d_shift, float* d_out, int64_t ldo, uint8_t* d_arg, hipStream_t st);
 int win_gather_max_bwd(const gcmi_graph* g, const float* d_dout, int64_t lddo, int n_feat,
                        const uint8_t* d_arg, float* d_dx, int64_t lddx, hipStream_t st);
+// the same, also adding the column sums of the BatchNorm backward (sum dx, sum dx*xhat; bn.hip scratch layout)
+bool win_stats_usable(const gcmi_graph* g, int n_feat);
+int win_gather_max_bwd_stats(const gcmi_graph* g, const float* d_dout, int64_t lddo, int n_feat, const uint8_t* d_arg,
+                             float* d_dx, int64_t lddx, const float* d_x, int64_t ldx, const float* d_mean,
+                             const float* d_invstd, double* d_sums, hipStream_t st);
+// the part of the BatchNorm backward after its column sums (dgamma, dbeta, coefficient vectors at the head of d_acc)
+int bn_bwd_params_impl(int64_t n_rows, int32_t n_feat, const float* d_gamma, const float* d_mean,
+                       const float* d_invstd, float* d_dgamma, float* d_dbeta, double* d_acc, void* stream);
 
 bool gemm_exact_mode();  // gcmi_set_option(GCMI_OPT_GEMM_EXACT)
 

@@ -364,9 +364,9 @@ int gcmi_gather_sum_fwd(const gcmi_graph* g, const float* d_x, int64_t ldx, int3
   if (g->n_atoms == 0) return GCMI_OK;
   hipStream_t st = (hipStream_t)stream;
   const int V = (vec_width(d_x, ldx, n_feat) == 4 && vec_width(d_s, lds, n_feat) == 4) ? 4 : 1;
-  if (V == 4 && !accumulate && win_has_width(n_feat) && win_usable(g, n_feat, false)) {
+  if (V == 4 && win_has_width(n_feat) && win_usable(g, n_feat, false)) {
     TimedScope ts(GCMI_K_GATHER_SUM, st);
-    return win_gather_sum(g, d_x, ldx, n_feat, d_s, lds, st);
+    return win_gather_sum(g, d_x, ldx, n_feat, d_s, lds, st, accumulate != 0);
   }
   const int lpr = n_feat / V;
   TileTable tt;

@@ -132,28 +132,59 @@ __device__ __forceinline__ void stage(char* buf, const Layout& L, const WinMeta&
 }
 
 // ---------------------------------------------------------------- per-window compute phases
+// Rows this thread also needs from HBM in the compute phase (the old value of an accumulated output, the BatchNorm
+// input of the statistics) are requested for up to kPre elements up front, unconditionally from clamped addresses,
+// and used after the LDS work of all of them: the wait for them is also a wait for the LDS-DMA of the next window
+// (one counter, in order), which the loop would wait for at its top anyway.
+constexpr int kPre = 4;
+
+struct NoState {};
+
+// ACC: s += sum of the neighbours' rows (the transposed gather of a backward pass onto the self term)
+template <bool ACC>
 struct SumOp {
   float* __restrict__ s;
   int64_t lds;
+  using State = NoState;
   template <int WT>
-  __device__ __forceinline__ void init(float*, int) const {}
+  __device__ __forceinline__ void init(float*, int, State&) const {}
+  template <int WT>
+  __device__ __forceinline__ void finish(char*, int, State&) const {}
   template <int WT, int LPR>
-  __device__ __forceinline__ void run(const char* buf, const Layout& L, const WinMeta& m, const float*) const {
+  __device__ __forceinline__ void run(const char* buf, const Layout& L, const WinMeta& m, const float*, State&) const {
     const float4* tile = reinterpret_cast<const float4*>(buf);
     const uint16_t* ent = reinterpret_cast<const uint16_t*>(buf + L.tile_bytes + L.aux_bytes);
     const int n16 = m.sb[kND] * LPR;
-    for (int e = threadIdx.x; e < n16; e += WT) {
-      const int slot = e / LPR;
-      const int c = e - slot * LPR;
-      int d, row, eloc;
-      locate(m, L.maxd, slot, d, row, eloc);
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);  // lone atoms: zero
-      for (int j = 0; j < d; ++j) {
-        const int sl = ent[eloc + j] & GCMI_WIN_MAX_SLOTS;
-        const float4 v = tile[sl * LPR + c];
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    for (int e0 = threadIdx.x; e0 < n16; e0 += kPre * WT) {
+      float4 old[kPre];
+      if constexpr (ACC) {
+#pragma unroll
+        for (int k = 0; k < kPre; ++k) {
+          const int e = e0 + k * WT < n16 ? e0 + k * WT : n16 - 1;
+          const int slot = e / LPR;
+          const int c = e - slot * LPR;
+          old[k] = *reinterpret_cast<const float4*>(s + (int64_t)row_of_slot(m, L.maxd, slot) * lds + c * 4);
+        }
       }
-      *reinterpret_cast<float4*>(s + (int64_t)row * lds + c * 4) = acc;
+#pragma unroll
+      for (int k = 0; k < kPre; ++k) {
+        const int e = e0 + k * WT;
+        if (e >= n16) break;
+        const int slot = e / LPR;
+        const int c = e - slot * LPR;
+        int d, row, eloc;
+        locate(m, L.maxd, slot, d, row, eloc);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);  // lone atoms: zero
+        for (int j = 0; j < d; ++j) {
+          const int sl = ent[eloc + j] & GCMI_WIN_MAX_SLOTS;
+          const float4 v = tile[sl * LPR + c];
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        if constexpr (ACC) {
+          acc.x += old[k].x; acc.y += old[k].y; acc.z += old[k].z; acc.w += old[k].w;
+        }
+        *reinterpret_cast<float4*>(s + (int64_t)row * lds + c * 4) = acc;
+      }
     }
   }
 };
@@ -167,17 +198,20 @@ struct MaxOp {
   uint8_t* __restrict__ arg;
   // the folded BatchNorm vectors live in LDS: a global load in the compute phase would make the
   // compiler wait for the LDS-DMA in flight as well
+  using State = NoState;
   template <int WT>
-  __device__ __forceinline__ void init(float* sh_lds, int n_feat) const {
+  __device__ __forceinline__ void init(float* sh_lds, int n_feat, State&) const {
     if (BN)
       for (int i = threadIdx.x; i < n_feat; i += WT) {
         sh_lds[i] = scale[i];
         sh_lds[256 + i] = shift[i];
       }
   }
+  template <int WT>
+  __device__ __forceinline__ void finish(char*, int, State&) const {}
   template <int WT, int LPR>
   __device__ __forceinline__ void run(const char* buf, const Layout& L, const WinMeta& m,
-                                      const float* sh_lds) const {
+                                      const float* sh_lds, State&) const {
     const float4* tile = reinterpret_cast<const float4*>(buf);
     const uint16_t* ent = reinterpret_cast<const uint16_t*>(buf + L.tile_bytes + L.aux_bytes);
     const int n16 = m.sb[kND] * LPR;
@@ -218,41 +252,113 @@ struct MaxOp {
 
 // dx[k] = dout[k]*[arg[k]==0] + sum_j dout[i_j]*[arg[i_j] == rev_pos(k,j)+1]: tile = dout rows,
 // aux = arg rows of the window.
+// STATS: dx is the gradient w.r.t. a BatchNorm output; the column sums its backward needs (sum dx, sum dx*xhat with
+// xhat = (x - mean)*invstd of the BatchNorm input x, col_sums_kernel MODE 1 of bn.hip: same fp32 xhat, same fp64
+// products and sums) are taken here from the values about to be stored, so dx is not read again for them.  A
+// thread's column piece is the same for all its elements (WT % LPR == 0): eight fp64 accumulators per thread,
+// combined per workgroup at the end and added to the replicated accumulators with one atomic per column.
+template <bool STATS>
 struct MaxBwdOp {
   float* __restrict__ dx;
   int64_t lddx;
+  const float* __restrict__ x;      // STATS: BatchNorm input rows
+  int64_t ldx;
+  const float* __restrict__ mean;
+  const float* __restrict__ invstd;
+  double* __restrict__ sums;        // bn.hip scratch layout: [coef 2F][replica][sum F | sum of products F]
+  struct State {
+    double s1[STATS ? 4 : 1], s2[STATS ? 4 : 1];
+  };
   template <int WT>
-  __device__ __forceinline__ void init(float*, int) const {}
+  __device__ __forceinline__ void init(float* sh_lds, int n_feat, State& acc_) const {
+    if constexpr (STATS) {
+      for (int i = threadIdx.x; i < n_feat; i += WT) {
+        sh_lds[i] = mean[i];
+        sh_lds[256 + i] = invstd[i];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc_.s1[q] = acc_.s2[q] = 0.0;
+    }
+  }
   template <int WT, int LPR>
-  __device__ __forceinline__ void run(const char* buf, const Layout& L, const WinMeta& m, const float*) const {
+  __device__ __forceinline__ void run(const char* buf, const Layout& L, const WinMeta& m, const float* sh_lds,
+                                      State& acc_) const {
     const float4* tile = reinterpret_cast<const float4*>(buf);
     const uchar4* atile = reinterpret_cast<const uchar4*>(buf + L.tile_bytes);
     const uint16_t* ent = reinterpret_cast<const uint16_t*>(buf + L.tile_bytes + L.aux_bytes);
     const int n16 = m.sb[kND] * LPR;
-    for (int e = threadIdx.x; e < n16; e += WT) {
-      const int slot = e / LPR;
-      const int c = e - slot * LPR;
-      int d, row, eloc;
-      locate(m, L.maxd, slot, d, row, eloc);
-      float4 g = tile[e];
-      uchar4 a = atile[e];
-      float4 acc;
-      acc.x = a.x == 0 ? g.x : 0.f;
-      acc.y = a.y == 0 ? g.y : 0.f;
-      acc.z = a.z == 0 ? g.z : 0.f;
-      acc.w = a.w == 0 ? g.w : 0.f;
-      for (int j = 0; j < d; ++j) {
-        const int en = ent[eloc + j];
-        const int sl = en & GCMI_WIN_MAX_SLOTS;
-        const unsigned char want = (unsigned char)((en >> GCMI_WIN_SLOT_BITS) + 1);
-        g = tile[sl * LPR + c];
-        a = atile[sl * LPR + c];
-        acc.x += a.x == want ? g.x : 0.f;
-        acc.y += a.y == want ? g.y : 0.f;
-        acc.z += a.z == want ? g.z : 0.f;
-        acc.w += a.w == want ? g.w : 0.f;
+    for (int e0 = threadIdx.x; e0 < n16; e0 += kPre * WT) {
+      float4 xr[kPre];
+      if constexpr (STATS) {
+#pragma unroll
+        for (int k = 0; k < kPre; ++k) {
+          const int e = e0 + k * WT < n16 ? e0 + k * WT : n16 - 1;
+          const int slot = e / LPR;
+          const int c = e - slot * LPR;
+          xr[k] = *reinterpret_cast<const float4*>(x + (int64_t)row_of_slot(m, L.maxd, slot) * ldx + c * 4);
+        }
       }
-      *reinterpret_cast<float4*>(dx + (int64_t)row * lddx + c * 4) = acc;
+#pragma unroll
+      for (int k = 0; k < kPre; ++k) {
+        const int e = e0 + k * WT;
+        if (e >= n16) break;
+        const int slot = e / LPR;
+        const int c = e - slot * LPR;
+        int d, row, eloc;
+        locate(m, L.maxd, slot, d, row, eloc);
+        float4 g = tile[e];
+        uchar4 a = atile[e];
+        float4 acc;
+        acc.x = a.x == 0 ? g.x : 0.f;
+        acc.y = a.y == 0 ? g.y : 0.f;
+        acc.z = a.z == 0 ? g.z : 0.f;
+        acc.w = a.w == 0 ? g.w : 0.f;
+        for (int j = 0; j < d; ++j) {
+          const int en = ent[eloc + j];
+          const int sl = en & GCMI_WIN_MAX_SLOTS;
+          const unsigned char want = (unsigned char)((en >> GCMI_WIN_SLOT_BITS) + 1);
+          g = tile[sl * LPR + c];
+          a = atile[sl * LPR + c];
+          acc.x += a.x == want ? g.x : 0.f;
+          acc.y += a.y == want ? g.y : 0.f;
+          acc.z += a.z == want ? g.z : 0.f;
+          acc.w += a.w == want ? g.w : 0.f;
+        }
+        *reinterpret_cast<float4*>(dx + (int64_t)row * lddx + c * 4) = acc;
+        if constexpr (STATS) {
+          const float4 mu = *reinterpret_cast<const float4*>(sh_lds + c * 4);
+          const float4 is = *reinterpret_cast<const float4*>(sh_lds + 256 + c * 4);
+          acc_.s1[0] += (double)acc.x; acc_.s2[0] += (double)acc.x * (double)((xr[k].x - mu.x) * is.x);
+          acc_.s1[1] += (double)acc.y; acc_.s2[1] += (double)acc.y * (double)((xr[k].y - mu.y) * is.y);
+          acc_.s1[2] += (double)acc.z; acc_.s2[2] += (double)acc.z * (double)((xr[k].z - mu.z) * is.z);
+          acc_.s1[3] += (double)acc.w; acc_.s2[3] += (double)acc.w * (double)((xr[k].w - mu.w) * is.w);
+        }
+      }
+    }
+  }
+  // after the last window (every thread of the workgroup arrives here): wave partials by shuffles over the lanes
+  // that share a column piece, the waves' partials meet in the (now idle) window buffers, one fp64 atomic per column
+  template <int WT>
+  __device__ __forceinline__ void finish(char* smem, int lpr, State& acc_) const {
+    if constexpr (STATS) {
+      const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+      double v[8] = {acc_.s1[0], acc_.s1[1], acc_.s1[2], acc_.s1[3], acc_.s2[0], acc_.s2[1], acc_.s2[2], acc_.s2[3]};
+      for (int o = lpr; o < 64; o <<= 1)  // lpr is 16 or 32: lanes l, l + lpr, ... hold the same piece
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += __shfl_xor(v[i], o, 64);
+      __syncthreads();  // the window buffers are no longer read
+      double* red = reinterpret_cast<double*>(smem);  // [wave][piece][8]
+      if (lane < lpr)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) red[(wave * lpr + lane) * 8 + i] = v[i];
+      __syncthreads();
+      const int n_feat = lpr * 4;
+      for (int t = tid; t < 2 * n_feat; t += WT) {
+        const int which = t / n_feat, col = t - which * n_feat;
+        double tot = 0.0;
+        for (int w = 0; w < WT / 64; ++w) tot += red[(w * lpr + (col >> 2)) * 8 + which * 4 + (col & 3)];
+        atomicAdd(sums + (size_t)2 * n_feat * (1 + (blockIdx.x % kBnReplicas)) + (size_t)which * n_feat + col, tot);
+      }
     }
   }
 };
@@ -271,7 +377,8 @@ win_kernel(const int32_t* __restrict__ meta, const uint16_t* __restrict__ edges,
   int(*ring)[GCMI_WIN_META_INTS] = reinterpret_cast<int(*)[GCMI_WIN_META_INTS]>(smem_all);
   float* op_lds = reinterpret_cast<float*>(smem_all + kRingBytes);
   char* smem = smem_all + kHeadBytes;
-  op.template init<WT>(op_lds, LPR * 4);
+  typename Op::State ost;
+  op.template init<WT>(op_lds, LPR * 4, ost);
   const int t = threadIdx.x;
   if ((int)blockIdx.x >= g_norm) {  // oversized windows: stage, wait, compute
     const int G = gridDim.x - g_norm;
@@ -282,9 +389,10 @@ win_kernel(const int32_t* __restrict__ meta, const uint16_t* __restrict__ edges,
       stage<WT, LPR, AUX>(smem, Lbig, m, x, ldx, aux, edges);
       wait_dma();
       __syncthreads();
-      op.template run<WT, LPR>(smem, Lbig, m, op_lds);
+      op.template run<WT, LPR>(smem, Lbig, m, op_lds, ost);
       __syncthreads();
     }
+    op.template finish<WT>(smem, LPR, ost);
     return;
   }
   const int G = g_norm;
@@ -312,11 +420,12 @@ win_kernel(const int32_t* __restrict__ meta, const uint16_t* __restrict__ edges,
     }
     if (has_next)
       stage<WT, LPR, AUX>(smem + ((it + 1) & 1) * bb, L, read_meta(ring[(it + 1) % 3]), x, ldx, aux, edges);
-    op.template run<WT, LPR>(smem + (it & 1) * bb, L, read_meta(ring[it % 3]), op_lds);
+    op.template run<WT, LPR>(smem + (it & 1) * bb, L, read_meta(ring[it % 3]), op_lds, ost);
     if (!has_next) break;
     w += G;
     ++it;
   }
+  op.template finish<WT>(smem, LPR, ost);
 }
 
 // ------------------------------------------------------------------ host-side dispatch helpers
@@ -425,8 +534,12 @@ static int launch(const gcmi_graph* g, int n_feat, const float* x, int64_t ldx, 
 bool win_has_width(int n_feat) { return n_feat == 64 || n_feat == 76 || n_feat == 128; }
 
 int win_gather_sum(const gcmi_graph* g, const float* d_x, int64_t ldx, int n_feat, float* d_s,
-                   int64_t lds, hipStream_t st) {
-  SumOp op{d_s, lds};
+                   int64_t lds, hipStream_t st, bool accumulate) {
+  if (accumulate) {
+    SumOp<true> op{d_s, lds};
+    return launch<false>(g, n_feat, d_x, ldx, nullptr, op, st, "win_gather_sum (accumulate)");
+  }
+  SumOp<false> op{d_s, lds};
   return launch<false>(g, n_feat, d_x, ldx, nullptr, op, st, "win_gather_sum");
 }
 
@@ -442,8 +555,20 @@ int win_gather_max(const gcmi_graph* g, const float* d_x, int64_t ldx, int n_fea
 
 int win_gather_max_bwd(const gcmi_graph* g, const float* d_dout, int64_t lddo, int n_feat,
                        const uint8_t* d_arg, float* d_dx, int64_t lddx, hipStream_t st) {
-  MaxBwdOp op{d_dx, lddx};
+  MaxBwdOp<false> op{d_dx, lddx, nullptr, 0, nullptr, nullptr, nullptr};
   return launch<true>(g, n_feat, d_dout, lddo, d_arg, op, st, "win_gather_max_bwd");
+}
+
+// threads per workgroup of the window kernels must be a multiple of the row's 16-byte pieces for the statistics form
+bool win_stats_usable(const gcmi_graph* g, int n_feat) {
+  return (n_feat == 64 || n_feat == 128) && win_usable(g, n_feat, true);
+}
+
+int win_gather_max_bwd_stats(const gcmi_graph* g, const float* d_dout, int64_t lddo, int n_feat, const uint8_t* d_arg,
+                             float* d_dx, int64_t lddx, const float* d_x, int64_t ldx, const float* d_mean,
+                             const float* d_invstd, double* d_sums, hipStream_t st) {
+  MaxBwdOp<true> op{d_dx, lddx, d_x, ldx, d_mean, d_invstd, d_sums};
+  return launch<true>(g, n_feat, d_dout, lddo, d_arg, op, st, "win_gather_max_bwd (statistics)");
 }
 
 }  // namespace gcmi

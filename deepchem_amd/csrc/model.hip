@@ -377,8 +377,6 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
     const int W = m->conv_width[l];
     const int K = l == 0 ? m->n_feat_in : m->conv_width[l - 1];
     float* dy = ws + w.tD;  // grad w.r.t. the (normalised) pool input
-    if (!sym) RUN(zero(dy, sizeof(float) * (size_t)(N * W)));
-    RUN(gcmi_gather_max_bwd(g, dpool, W, W, reinterpret_cast<const uint8_t*>(ws + w.arg[l]), dy, W, stream));
     float* dgc = ws + w.tA;  // grad w.r.t. the GraphConv pre-activation
     const Segs sg = make_segs(g, K, W);
     const float* xin = l == 0 ? io->d_atom_features : ws + w.pool[l - 1];
@@ -388,14 +386,32 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
     // the fused pass covers the default widths in split-bf16 mode; it wants 16-byte rows of every operand
     const bool try_fused = full && fused_bwd_enabled() && W == 64 && ldx % 4 == 0 && aligned16(xin) &&
                            ((l == 0 && K > 32 && K <= 96) || (l > 0 && K > 32 && K <= 64));
-    if (m->batch_norm) {
+    // GraphPool backward; when nothing needs the elementwise BatchNorm pass afterwards, the window kernel also
+    // takes the column sums of the BatchNorm backward from the rows it stores (dy is then not read again for them)
+    static const bool stats_env = getenv("GCMI_STATS_IN_GATHER") && atoi(getenv("GCMI_STATS_IN_GATHER")) != 0;
+    const bool stats_in_gather = stats_env && m->batch_norm && sym && fused_bwd_enabled() && (try_fused || !full) &&
+                                 win_stats_usable(g, W) && aligned16(dpool) && aligned16(dy) && aligned16(ws + w.gc[l]);
+    if (!sym) RUN(zero(dy, sizeof(float) * (size_t)(N * W)));
+    if (stats_in_gather) {
       const float* bnv = ws + w.bnv[l];
-      RUN(bn_bwd_impl(dy, W, ws + w.gc[l], W, N, W, d_params + m->off_bn_gamma[l], bnv, bnv + W,
-                      d_grads + m->off_bn_gamma[l], d_grads + m->off_bn_beta[l], (full && !try_fused) ? dgc : nullptr, W,
-                      1, reinterpret_cast<double*>(ws + w.acc), true, stream));
-    } else if (full && !try_fused) {
-      RUN(gcmi_relu_bwd(dy, W, ws + w.gc[l], W, N, W, stream));
-      dgc = dy;
+      {
+        TimedScope ts(GCMI_K_GATHER_MAX_BWD, st);
+        RUN(win_gather_max_bwd_stats(g, dpool, W, W, reinterpret_cast<const uint8_t*>(ws + w.arg[l]), dy, W,
+                                     ws + w.gc[l], W, bnv, bnv + W, reinterpret_cast<double*>(ws + w.acc), st));
+      }
+      RUN(bn_bwd_params_impl(N, W, d_params + m->off_bn_gamma[l], bnv, bnv + W, d_grads + m->off_bn_gamma[l],
+                             d_grads + m->off_bn_beta[l], reinterpret_cast<double*>(ws + w.acc), stream));
+    } else {
+      RUN(gcmi_gather_max_bwd(g, dpool, W, W, reinterpret_cast<const uint8_t*>(ws + w.arg[l]), dy, W, stream));
+      if (m->batch_norm) {
+        const float* bnv = ws + w.bnv[l];
+        RUN(bn_bwd_impl(dy, W, ws + w.gc[l], W, N, W, d_params + m->off_bn_gamma[l], bnv, bnv + W,
+                        d_grads + m->off_bn_gamma[l], d_grads + m->off_bn_beta[l], (full && !try_fused) ? dgc : nullptr,
+                        W, 1, reinterpret_cast<double*>(ws + w.acc), true, stream));
+      } else if (full && !try_fused) {
+        RUN(gcmi_relu_bwd(dy, W, ws + w.gc[l], W, N, W, stream));
+        dgc = dy;
+      }
     }
     if (!full) break;  // reference semantics: nothing in front of a GraphConv output trains
     bool fused_done = false;
