@@ -60,10 +60,12 @@ struct FusedArgs {
   // input gradients (DGRAD)
   float* dout[2];
   int32_t lddout[2];
+  // diagnostics (GCMI_FUSED_DIAG=1): 100 MHz ticks spent per phase by wave 0 and wave 4 (or 3) of workgroup 0
+  unsigned long long* diag;
 };
 
 template <int NG, int KT, int NOPS, bool TRANS, bool RD, bool DGRAD>
-__global__ void __launch_bounds__(DGRAD ? 512 : 256)
+__global__ void __launch_bounds__(DGRAD ? 512 : 256) __attribute__((amdgpu_waves_per_eu(2)))
 fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
   constexpr int NT = DGRAD ? 512 : 256;
   constexpr int NJ = NG / 32;                 // 32-column groups of G
@@ -71,6 +73,7 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
   constexpr int GP = NG + 4;                  // pitch of a G row in LDS (floats): 16-byte rows
   constexpr int IP = KP + 4;                  // pitch of an In row in LDS
   constexpr int WP = NG + 8;                  // pitch of a weight-image row (bf16): conflict-free b128 reads
+  constexpr size_t kWBytes = !DGRAD ? 0 : sizeof(unsigned short) * (size_t)NOPS * 3 * KP * WP;
   constexpr int QPR = NG / 4;                 // 16-byte pieces of a G row
   constexpr int RPP = NT / QPR;               // rows per pass of the tile loads
   constexpr int GPASS = kFRows / RPP;         // passes
@@ -89,7 +92,7 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
   float* Gs = reinterpret_cast<float*>(lds_raw);
   float* Ins = Gs + kFRows * GP;                                   // [NOPS][64][IP]
   unsigned short* Wimg = reinterpret_cast<unsigned short*>(Ins + NOPS * kFRows * IP);
-  float* Outs = reinterpret_cast<float*>(Wimg + (DGRAD ? (size_t)NOPS * 3 * KP * WP : 0));  // [64][OP] (DGRAD)
+  float* Outs = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(Wimg) + kWBytes);  // [64][OP] (DGRAD)
   // the segment table, in LDS (indexing the by-value struct dynamically would go through scratch)
   __shared__ int t_begin_s[kFMaxSeg], t_end_s[kFMaxSeg], t_tile_s[kFMaxSeg + 1];
   __shared__ long long t_w_s[2][kFMaxSeg], t_db_s[kFMaxSeg];
@@ -180,11 +183,14 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
   };
 
   // ---- weight-gradient state
-  f32x16 wacc[KT];
+  // one set of accumulator registers for both roles: a weight-gradient wave keeps dW in it across the tiles of a
+  // segment, an input-gradient wave starts every tile from zero
+  constexpr int NACC = (DGRAD && TPW > KT) ? TPW : KT;
+  f32x16 accs[NACC];
 #pragma unroll
-  for (int t = 0; t < KT; ++t)
+  for (int t = 0; t < NACC; ++t)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) wacc[t][i] = 0.f;
+    for (int i = 0; i < 16; ++i) accs[t][i] = 0.f;
   float bsum = 0.f;
   auto flush_w = [&](int seg) {
     const int64_t woff = t_w_s[NOPS == 2 ? wo : 0][seg];
@@ -201,9 +207,9 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
         for (int reg = 0; reg < 16; ++reg) {
           const int r8 = (reg & 3) + 8 * (reg >> 2);  // + 4 * half: row of the accumulator tile
           if constexpr (TRANS) {  // dW stored NG x k_in: the accumulator holds (column of G) x (column of In)
-            if (t * 32 + l31 < a.k_in) atomicAdd(wp + (int64_t)r8 * a.k_in + t * 32, wacc[t][reg]);
+            if (t * 32 + l31 < a.k_in) atomicAdd(wp + (int64_t)r8 * a.k_in + t * 32, accs[t][reg]);
           } else {                // dW stored k_in x NG
-            if (t * 32 + r8 + 4 * half < a.k_in) atomicAdd(wp + (t * 32 + r8) * NG, wacc[t][reg]);
+            if (t * 32 + r8 + 4 * half < a.k_in) atomicAdd(wp + (t * 32 + r8) * NG, accs[t][reg]);
           }
         }
       }
@@ -211,7 +217,7 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
 #pragma unroll
     for (int t = 0; t < KT; ++t)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) wacc[t][i] = 0.f;
+      for (int i = 0; i < 16; ++i) accs[t][i] = 0.f;
     if (wo == 0) {
       const int64_t boff = t_db_s[seg];
       const float s = bsum + __shfl_xor(bsum, 32);
@@ -252,7 +258,10 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
   int cur_seg = -1;
   int prow0 = row0, pvalid = 0;
 
+  const bool stamp = a.diag != nullptr && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == NT / 64 - 1);
+  unsigned long long d_a = 0, d_w1 = 0, d_b = 0, d_w2 = 0, t0 = 0, t1 = 0;
   for (int i = 0; i < my_tiles; ++i) {
+    if (stamp) t0 = wall_clock64();
     if (seg != cur_seg) {
       if (cur_seg >= 0 && !is_dgrad) flush_w(cur_seg);
       cur_seg = seg;
@@ -329,7 +338,9 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
       }
     }
     if (i > 0) store_out(prow0, pvalid);  // the previous tile's input gradients (written before the last barrier)
+    if (stamp) { t1 = wall_clock64(); d_a += t1 - t0; }
     __syncthreads();
+    if (stamp) { t0 = wall_clock64(); d_w1 += t0 - t1; }
 
     // ---- phase (b): next tile's sources in flight, products from LDS
     int n2seg = nseg, n2row0 = nrow0, n2valid = nvalid;
@@ -338,92 +349,126 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
     load_mem(n2row0, n2valid, mem1);     // ... which the indices of the tile after it then replace
     if (is_dgrad) {
       if constexpr (DGRAD) {
-        f32x16 acc[TPW];
+        // input gradients of this tile: `accs` starts from zero (the weight-gradient waves keep theirs across tiles)
 #pragma unroll
         for (int t = 0; t < TPW; ++t)
 #pragma unroll
-          for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+          for (int k = 0; k < 16; ++k) accs[t][k] = 0.f;
         bool on[TPW];
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
           const int ot = cg * TPW + t;
           on[t] = t_w_s[NOPS == 2 ? ((ot / KT) & 1) : 0][seg] >= 0;
         }
-#pragma unroll
-        for (int ks = 0; ks < NG / 16; ++ks) {
-          __builtin_amdgcn_sched_barrier(0);  // one k-step's fragments live at a time
+        // units (k-step, output tile), the LDS reads of unit u + 1 issued before the split and the MFMAs of unit u:
+        // with two waves per SIMD nobody else hides a read's latency
+        constexpr int NKS = NG / 16, NU = NKS * TPW;
+        float4 glo, ghi;
+        u32x4 wv[2][3];
+        auto read_g = [&](int ks) {
           const float* grow = Gs + (rb * 32 + l31) * GP + ks * 16 + 8 * half;
-          const float4 lo = *reinterpret_cast<const float4*>(grow);
-          const float4 hi = *reinterpret_cast<const float4*>(grow + 4);
-          const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-          const Frag3 fg = split_frag(v);
+          glo = *reinterpret_cast<const float4*>(grow);
+          ghi = *reinterpret_cast<const float4*>(grow + 4);
+        };
+        auto read_w = [&](int u) {
+          const int ks = u / TPW, t = u - ks * TPW;
+          const int ot = cg * TPW + t;
+          const int o = ot / KT, kt = ot - o * KT;
+          const unsigned short* wrow = Wimg + ((size_t)(o * 3) * KP + kt * 32 + l31) * WP + ks * 16 + 8 * half;
+          wv[u & 1][0] = *reinterpret_cast<const u32x4*>(wrow);
+          wv[u & 1][1] = *reinterpret_cast<const u32x4*>(wrow + (size_t)KP * WP);
+          wv[u & 1][2] = *reinterpret_cast<const u32x4*>(wrow + (size_t)2 * KP * WP);
+        };
+        read_g(0);
+        read_w(0);
+        Frag3 fg;
 #pragma unroll
-          for (int t = 0; t < TPW; ++t) {
-            if (!on[t]) continue;  // uniform
-            const int ot = cg * TPW + t;
-            const int o = ot / KT, kt = ot - o * KT;
-            const unsigned short* wrow = Wimg + ((size_t)(o * 3) * KP + kt * 32 + l31) * WP + ks * 16 + 8 * half;
-            const u32x4 w1 = *reinterpret_cast<const u32x4*>(wrow);
-            const u32x4 w2 = *reinterpret_cast<const u32x4*>(wrow + (size_t)KP * WP);
-            const u32x4 w3 = *reinterpret_cast<const u32x4*>(wrow + (size_t)2 * KP * WP);
-            // rows of G x input columns: lane = input column, registers = rows; small terms first
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[2]), as_bf16x8(w1), acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[0]), as_bf16x8(w3), acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[1]), as_bf16x8(w2), acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[1]), as_bf16x8(w1), acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[0]), as_bf16x8(w2), acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[0]), as_bf16x8(w1), acc[t], 0, 0, 0);
+        for (int u = 0; u < NU; ++u) {
+          const int ks = u / TPW, t = u - ks * TPW;
+          if (t == 0) {  // this k-step's rows of G: split, then its registers take the next k-step's
+            const float v[8] = {glo.x, glo.y, glo.z, glo.w, ghi.x, ghi.y, ghi.z, ghi.w};
+            fg = split_frag(v);
           }
+          if (u + 1 < NU) {
+            read_w(u + 1);
+            if (t == TPW - 1) read_g(ks + 1);
+          }
+          if (on[t]) {  // uniform
+            const u32x4 w1 = wv[u & 1][0], w2 = wv[u & 1][1], w3 = wv[u & 1][2];
+            // rows of G x input columns: lane = input column, registers = rows; small terms first
+            accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[2]), as_bf16x8(w1), accs[t], 0, 0, 0);
+            accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[0]), as_bf16x8(w3), accs[t], 0, 0, 0);
+            accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[1]), as_bf16x8(w2), accs[t], 0, 0, 0);
+            accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[1]), as_bf16x8(w1), accs[t], 0, 0, 0);
+            accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[0]), as_bf16x8(w2), accs[t], 0, 0, 0);
+            accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[0]), as_bf16x8(w1), accs[t], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);  // units stay in order: one set of fragments live besides the one in flight
         }
         // -> LDS, [row][tile * 32 + column]: 32 consecutive banks per half-wave, the halves 32 banks apart
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
           float* orow = Outs + (rb * 32 + 4 * half) * OP + (cg * TPW + t) * 32 + l31;
 #pragma unroll
-          for (int reg = 0; reg < 16; ++reg) orow[((reg & 3) + 8 * (reg >> 2)) * OP] = acc[t][reg];
+          for (int reg = 0; reg < 16; ++reg) orow[((reg & 3) + 8 * (reg >> 2)) * OP] = accs[t][reg];
         }
       }
     } else {
       const bool on = t_w_s[NOPS == 2 ? wo : 0][seg] >= 0;
       const float* irow = Ins + (NOPS == 2 ? wo : 0) * kFRows * IP;
+      // Fragments in order: per 16-row step the G columns, then the KT column groups of In.  The eight LDS reads of
+      // fragment f + 1 are issued before fragment f is split and multiplied: with two waves per SIMD nobody else
+      // hides their latency.
+      constexpr int FPS = 1 + KT, NF = STEPS * FPS;
+      float raw[2][8];
+      auto read_frag = [&](int f) {
+        const int st_ = f / FPS, w_ = f - st_ * FPS;
+        const float* src = w_ == 0 ? Gs + (16 * st_ + 8 * half) * GP + wj * 32 + l31            // zero beyond `valid`
+                                   : irow + (16 * st_ + 8 * half) * IP + (w_ - 1) * 32 + l31;
+        const int pitch = w_ == 0 ? GP : IP;
 #pragma unroll
-      for (int s = 0; s < STEPS; ++s) {
-        __builtin_amdgcn_sched_barrier(0);
-        float gv[8];
+        for (int u = 0; u < 8; ++u) raw[f & 1][u] = src[u * pitch];
+      };
+      read_frag(0);
+      Frag3 fg;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) gv[u] = Gs[(16 * s + 8 * half + u) * GP + wj * 32 + l31];  // zero beyond `valid`
-        if (wo == 0) {
+      for (int f = 0; f < NF; ++f) {
+        const int w_ = f % FPS;
+        if (f + 1 < NF) read_frag(f + 1);
+        if (w_ == 0) {
+          if (wo == 0) {
 #pragma unroll
-          for (int u = 0; u < 8; ++u) bsum += gv[u];
-        }
-        if (on) {  // uniform
-          const Frag3 fg = split_frag(gv);
-#pragma unroll
-          for (int t = 0; t < KT; ++t) {
-            if (t > 0) __builtin_amdgcn_sched_barrier(0);
-            float av[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) av[u] = irow[(16 * s + 8 * half + u) * IP + t * 32 + l31];
-            const Frag3 fa = split_frag(av);
-            const Frag3& L = TRANS ? fg : fa;
-            const Frag3& R = TRANS ? fa : fg;
-            wacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[2]), as_bf16x8(R.p[0]), wacc[t], 0, 0, 0);
-            wacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[0]), as_bf16x8(R.p[2]), wacc[t], 0, 0, 0);
-            wacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[1]), as_bf16x8(R.p[1]), wacc[t], 0, 0, 0);
-            wacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[1]), as_bf16x8(R.p[0]), wacc[t], 0, 0, 0);
-            wacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[0]), as_bf16x8(R.p[1]), wacc[t], 0, 0, 0);
-            wacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[0]), as_bf16x8(R.p[0]), wacc[t], 0, 0, 0);
+            for (int u = 0; u < 8; ++u) bsum += raw[f & 1][u];
           }
+          fg = split_frag(raw[f & 1]);
+        } else if (on) {  // uniform
+          const int t = w_ - 1;
+          const Frag3 fa = split_frag(raw[f & 1]);
+          const Frag3& L = TRANS ? fg : fa;
+          const Frag3& R = TRANS ? fa : fg;
+          accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[2]), as_bf16x8(R.p[0]), accs[t], 0, 0, 0);
+          accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[0]), as_bf16x8(R.p[2]), accs[t], 0, 0, 0);
+          accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[1]), as_bf16x8(R.p[1]), accs[t], 0, 0, 0);
+          accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[1]), as_bf16x8(R.p[0]), accs[t], 0, 0, 0);
+          accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[0]), as_bf16x8(R.p[1]), accs[t], 0, 0, 0);
+          accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[0]), as_bf16x8(R.p[0]), accs[t], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if (stamp) { t1 = wall_clock64(); d_b += t1 - t0; }
     __syncthreads();
+    if (stamp) { t0 = wall_clock64(); d_w2 += t0 - t1; }
     prow0 = row0; pvalid = valid;
     seg = nseg; row0 = nrow0; valid = nvalid;
     nseg = n2seg; nrow0 = n2row0; nvalid = n2valid;
   }
   store_out(prow0, pvalid);
   if (!is_dgrad) flush_w(cur_seg);
+  if (stamp) {
+    unsigned long long* d = a.diag + (wave == 0 ? 0 : 5);
+    d[0] = d_a; d[1] = d_w1; d[2] = d_b; d[3] = d_w2; d[4] = (unsigned long long)my_tiles;
+  }
 }
 
 static bool fused_bwd_on() {
@@ -442,7 +487,8 @@ template <int NG, int KT, int NOPS, bool TRANS, bool RD, bool DGRAD>
 static int launch_fused(const FusedTable& st, int n_tiles, const FusedArgs& a, hipStream_t sm) {
   constexpr int KP = KT * 32;
   size_t shmem = sizeof(float) * kFRows * (NG + 4) + sizeof(float) * (size_t)NOPS * kFRows * (KP + 4);
-  if (DGRAD) shmem += sizeof(unsigned short) * (size_t)NOPS * 3 * KP * (NG + 8) + sizeof(float) * kFRows * (NOPS * KT * 32 + 8);
+  if (DGRAD)
+    shmem += sizeof(unsigned short) * (size_t)NOPS * 3 * KP * (NG + 8) + sizeof(float) * kFRows * (NOPS * KT * 32 + 8);
   auto kern = fused_bwd_kernel<NG, KT, NOPS, TRANS, RD, DGRAD>;
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
@@ -456,8 +502,24 @@ static int launch_fused(const FusedTable& st, int n_tiles, const FusedArgs& a, h
   }
   const int per_cu = DGRAD ? 1 : 2;
   const int grid = std::min(n_tiles, 256 * per_cu);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(DGRAD ? 512 : 256), shmem, sm, st, n_tiles, a, next_sweep_direction());
+  static const bool diag_on = getenv("GCMI_FUSED_DIAG") && atoi(getenv("GCMI_FUSED_DIAG")) != 0;
+  static unsigned long long* d_diag = nullptr;
+  FusedArgs aa = a;
+  if (diag_on) {
+    if (!d_diag && hipMalloc(&d_diag, 10 * sizeof(unsigned long long)) != hipSuccess) d_diag = nullptr;
+    if (d_diag) (void)hipMemsetAsync(d_diag, 0, 10 * sizeof(unsigned long long), sm);
+    aa.diag = d_diag;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(DGRAD ? 512 : 256), shmem, sm, st, n_tiles, aa, next_sweep_direction());
   GCMI_CHECK_LAUNCH("fused_bwd");
+  if (diag_on && d_diag) {  // serialises the stream: diagnostics only
+    unsigned long long h[10];
+    if (hipStreamSynchronize(sm) == hipSuccess && hipMemcpy(h, d_diag, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
+      fprintf(stderr, "fused_bwd<%d,%d,%d> tiles %llu | first wave: G phase %.2f us, wait %.2f, products %.2f, wait %.2f "
+                      "| last wave: %.2f %.2f %.2f %.2f (per tile)\n", NG, KT, (int)DGRAD, h[4],
+              h[0] * 0.01 / h[4], h[1] * 0.01 / h[4], h[2] * 0.01 / h[4], h[3] * 0.01 / h[4], h[5] * 0.01 / h[4],
+              h[6] * 0.01 / h[4], h[7] * 0.01 / h[4], h[8] * 0.01 / h[4]);
+  }
   g_fused_launches.fetch_add(1, std::memory_order_relaxed);
   return GCMI_OK;
 }
