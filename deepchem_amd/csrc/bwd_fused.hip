@@ -80,6 +80,9 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
   constexpr int IQ = KP / 4;                  // 16-byte pieces of an In row
   constexpr int IPASS = kFRows * IQ / NT;     // passes of the In loads, per operand
   constexpr int STEPS = kFRows / 16;          // k-steps of the weight-gradient contraction
+  // the weight-gradient waves interleave the split of the next fragment with the MFMAs of the current one; the
+  // dense-layer form has no registers left for that (80 hold its prefetched rows) and only reads a fragment ahead
+  constexpr bool INTERLEAVE = !RD;
   constexpr int OT = NOPS * KT;               // 32-column tiles of the input gradients
   constexpr int TPW = OT / 2;                 // ... per dgrad wave (two waves per 32-row block)
   constexpr int OP = OT * 32 + 8;             // pitch of a row of the input-gradient tile in LDS (floats)
@@ -420,6 +423,84 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
       // fragment f + 1 are issued before fragment f is split and multiplied: with two waves per SIMD nobody else
       // hides their latency.
       constexpr int FPS = 1 + KT, NF = STEPS * FPS;
+      if constexpr (INTERLEAVE) {
+      float raw[8];
+      auto read_frag = [&](int f) {
+        const int st_ = f / FPS, w_ = f - st_ * FPS;
+        const float* src = w_ == 0 ? Gs + (16 * st_ + 8 * half) * GP + wj * 32 + l31            // zero beyond `valid`
+                                   : irow + (16 * st_ + 8 * half) * IP + (w_ - 1) * 32 + l31;
+        const int pitch = w_ == 0 ? GP : IP;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) raw[u] = src[u * pitch];
+      };
+      // Software pipeline over fragments: in iteration f the split of fragment f + 1 (vector unit) is interleaved
+      // with the six MFMAs of fragment f (a wave issues in order: behind a chain of dependent MFMAs nothing of its
+      // own would issue for 6 x 32 cycles), and the LDS reads of fragment f + 2 follow the split that frees `raw`.
+      read_frag(0);
+      Frag3 fg, cur, nxt;
+      {
+        if (wo == 0) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) bsum += raw[u];
+        }
+        nxt = split_frag(raw);  // fragment 0 is a G fragment
+        if (NF > 1) read_frag(1);
+      }
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const int w_ = f % FPS;
+        cur = nxt;
+        if (w_ == 0) fg = cur;
+        const bool more = f + 1 < NF;
+        if (more && (f + 1) % FPS == 0 && wo == 0) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) bsum += raw[u];
+        }
+        unsigned q[3][4];
+        auto pair_split = [&](int i) {
+          if (more) split3_pair(raw[2 * i], raw[2 * i + 1], q[0][i], q[1][i], q[2][i]);
+        };
+        if (w_ != 0 && on) {  // uniform
+          const int t = w_ - 1;
+          const Frag3& L = TRANS ? fg : cur;
+          const Frag3& R = TRANS ? cur : fg;
+          // MFMA, a quarter of the next fragment's split, MFMA, ...: the order is pinned (the scheduler would put the
+          // six dependent MFMAs back to back)
+          accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[2]), as_bf16x8(R.p[0]), accs[t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          pair_split(0);
+          __builtin_amdgcn_sched_barrier(0);
+          accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[0]), as_bf16x8(R.p[2]), accs[t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          pair_split(1);
+          __builtin_amdgcn_sched_barrier(0);
+          accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[1]), as_bf16x8(R.p[1]), accs[t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          pair_split(2);
+          __builtin_amdgcn_sched_barrier(0);
+          accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[1]), as_bf16x8(R.p[0]), accs[t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          pair_split(3);
+          __builtin_amdgcn_sched_barrier(0);
+          accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[0]), as_bf16x8(R.p[1]), accs[t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (more && f + 2 < NF) read_frag(f + 2);  // `raw` is free: the reads of the fragment after next
+          __builtin_amdgcn_sched_barrier(0);
+          accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[0]), as_bf16x8(R.p[0]), accs[t], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pair_split(i);
+          if (more && f + 2 < NF) read_frag(f + 2);
+        }
+        if (more) {
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) {
+            nxt.p[pc].x = q[pc][0]; nxt.p[pc].y = q[pc][1]; nxt.p[pc].z = q[pc][2]; nxt.p[pc].w = q[pc][3];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      } else {
       float raw[2][8];
       auto read_frag = [&](int f) {
         const int st_ = f / FPS, w_ = f - st_ * FPS;
@@ -454,6 +535,7 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
           accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[0]), as_bf16x8(R.p[0]), accs[t], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+      }
       }
     }
     if (stamp) { t1 = wall_clock64(); d_b += t1 - t0; }
