@@ -64,7 +64,10 @@ __global__ void __launch_bounds__(kBBlock)
 col_sums_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ x, int64_t ldx,
                 const float* __restrict__ mean, const float* __restrict__ invstd, int64_t n_rows,
                 int64_t rows_per_block, int n_feat, int lpr, int lx, double* __restrict__ sums, ReadoutGrad rg,
-                int rev) {
+                int rev, const float* __restrict__ only_if_gamma = nullptr,
+                const float* __restrict__ only_if_beta = nullptr) {
+  // (bn_bwd_pool_impl) needed only where the pooled sums are ill-conditioned: otherwise gone before the first load
+  if (only_if_gamma != nullptr && !bn_pool_ill_conditioned(only_if_gamma, only_if_beta, n_feat)) return;
   __shared__ double red[2 * kBBlock * 4];
   const int ry = kBBlock / lx;  // row lanes
   const int ty = threadIdx.x / lx;
@@ -327,7 +330,8 @@ bn_bwd_dx_kernel(const float* __restrict__ dy, int64_t lddy, const float* __rest
 
 static int launch_col_sums(int mode, const float* a, int64_t lda, const float* x, int64_t ldx,
                            const float* mean, const float* invstd, int64_t n_rows, int n_feat,
-                           double* sums, bool acc_clean, hipStream_t st, const ReadoutGrad* rgp = nullptr) {
+                           double* sums, bool acc_clean, hipStream_t st, const ReadoutGrad* rgp = nullptr,
+                           const float* only_if_gamma = nullptr, const float* only_if_beta = nullptr) {
   if (!acc_clean &&
       hipMemsetAsync(sums, 0, sizeof(double) * 2 * n_feat * (1 + kReplicas), st) != hipSuccess) {
     set_error("bn: memset failed");
@@ -356,7 +360,7 @@ static int launch_col_sums(int mode, const float* a, int64_t lda, const float* x
   const int rev = next_sweep_direction();
 #define LAUNCH_CS(VV, MM)                                                                     \
   hipLaunchKernelGGL((col_sums_kernel<VV, MM>), dim3(blocks), dim3(kBBlock), 0, st, a, lda, x, \
-                     ldx, mean, invstd, n_rows, rpb, n_feat, lpr, lx, sums, rg, rev)
+                     ldx, mean, invstd, n_rows, rpb, n_feat, lpr, lx, sums, rg, rev, only_if_gamma, only_if_beta)
   if (V == 4) {
     if (mode == 0) LAUNCH_CS(4, 0); else if (mode == 1) LAUNCH_CS(4, 1); else LAUNCH_CS(4, 2);
   } else {
@@ -544,6 +548,52 @@ int bn_bwd_readout_impl(const int32_t* d_membership, const float* d_g2, int64_t 
   rg.n_deg = n_deg;
   return bn_bwd_any(&rg, nullptr, 0, d_x, ldx, n_rows, n_feat, d_gamma, d_mean, d_invstd, d_dgamma, d_dbeta, d_dx,
                     lddx, relu_mask, d_acc, acc_clean, stream);
+}
+
+// dbeta = sum dy, dgamma = sum dy * xhat and the coefficient vectors, from the pooled sums (psums) or, where those
+// are ill-conditioned, from the direct sums (sums); both accumulators are left clean
+__global__ void bn_bwd_params_pool_kernel(double* __restrict__ psums, double* __restrict__ sums, int64_t n_rows,
+                                          int n_feat, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                          float* __restrict__ coef) {
+  const bool direct = bn_pool_ill_conditioned(gamma, beta, n_feat);
+  const double inv_n = 1.0 / (double)n_rows;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_feat; c += gridDim.x * blockDim.x) {
+    double p1, p2, d1, d2;
+    take_sums(psums, n_feat, c, p1, p2);
+    take_sums(sums, n_feat, c, d1, d2);
+    const double gm = (double)(gamma ? gamma[c] : 1.f), bt = (double)(beta ? beta[c] : 0.f);
+    const double db = direct ? d1 : p1;
+    const double dg = direct ? d2 : (p2 - bt * p1) / gm;
+    if (dbeta) dbeta[c] = (float)db;
+    if (dgamma) dgamma[c] = (float)dg;
+    const double is = (double)invstd[c];
+    const double A = gm * is;
+    const double B = -A * is * dg * inv_n;
+    const double C = -A * db * inv_n - B * (double)mean[c];
+    coef[c] = (float)A;
+    coef[n_feat + c] = (float)B;
+    coef[2 * n_feat + c] = (float)C;
+  }
+}
+
+int bn_bwd_pool_impl(const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat,
+                     const float* d_gamma, const float* d_beta, const float* d_mean, const float* d_invstd,
+                     float* d_dgamma, float* d_dbeta, double* d_psums, double* d_acc, void* stream) {
+  GCMI_CHECK_ARG(n_feat > 0 && n_rows > 0 && d_mean && d_invstd && d_acc && d_psums && d_x && d_gamma && d_beta,
+                 "bn_bwd_pool: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  TimedScope ts(GCMI_K_BATCHNORM, st);
+  if (d_dy != nullptr) {
+    const int rc = launch_col_sums(1, d_dy, lddy, d_x, ldx, d_mean, d_invstd, n_rows, n_feat, d_acc, true, st, nullptr,
+                                   d_gamma, d_beta);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(bn_bwd_params_pool_kernel, dim3(1), dim3(256), 0, st, d_psums, d_acc, n_rows, n_feat, d_gamma,
+                     d_beta, d_mean, d_invstd, d_dgamma, d_dbeta, reinterpret_cast<float*>(d_acc));
+  GCMI_CHECK_LAUNCH("bn_bwd_params_pool");
+  return GCMI_OK;
 }
 
 int bn_bwd_params_impl(int64_t n_rows, int32_t n_feat, const float* d_gamma, const float* d_mean,

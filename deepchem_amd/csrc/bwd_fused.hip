@@ -60,6 +60,12 @@ struct FusedArgs {
   // input gradients (DGRAD)
   float* dout[2];
   int32_t lddout[2];
+  // DGRAD, optional: column sums for the BatchNorm backward of the block BELOW this one, whose output P is this
+  // block's input.  With dP this block's input gradient, sum dP and sum dP * P give that BatchNorm's sum dy and
+  // sum dy * y without a pass over dy (bn.hip: bn_bwd_params_pool_kernel).  For a GraphConv block
+  // dP = dXs + gather(dS), and over a symmetric adjacency sum gather(dS) * P = sum dS * gather(P) = sum dS * S:
+  // both tiles and both operands are in LDS here.  Scratch layout of bn.hip: [2F unused][replica][F | F] doubles.
+  double* psums;
   // diagnostics (GCMI_FUSED_DIAG=1): 100 MHz ticks spent per phase by wave 0 and wave 4 (or 3) of workgroup 0
   unsigned long long* diag;
 };
@@ -100,6 +106,7 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
   __shared__ int t_begin_s[kFMaxSeg], t_end_s[kFMaxSeg], t_tile_s[kFMaxSeg + 1];
   __shared__ long long t_w_s[2][kFMaxSeg], t_db_s[kFMaxSeg];
   __shared__ __attribute__((aligned(16))) float coef_s[3 * NG];  // [A | B | C] of the BatchNorm backward
+  __shared__ double stat_s[2][DGRAD ? KP : 1];                   // sum dP | sum dP * P per input column (psums)
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: role tests and table picks stay off the vector unit
@@ -143,6 +150,8 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
   const int gq = tid % QPR;
   const int gr = tid / QPR;
   for (int c = tid; c < 3 * NG; c += NT) coef_s[c] = a.coef != nullptr ? a.coef[c] : (c < NG ? 1.f : 0.f);
+  if constexpr (DGRAD)
+    for (int c = tid; c < 2 * KP; c += NT) stat_s[c / KP][c % KP] = 0.0;
 
   __syncthreads();
 
@@ -229,23 +238,50 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
     bsum = 0.f;
   };
 
+  static_assert(!DGRAD || NT % IQ == 0, "a thread keeps its column piece over the passes");
   // The input-gradient tile leaves through LDS: the waves that computed it hold (column, 16 rows) per lane, which as
   // global stores would be 32 dword stores per lane -- and, issued behind the next tile's loads, every wave's wait
   // for those loads (one instruction stream for both roles: the wait cannot tell which role it is in) would also
   // wait for the store acknowledgements.  Written out by all threads at the start of the next tile instead: whole
   // rows, 16 bytes per lane, and in program order BEFORE the loads that follow.
-  auto store_out = [&](int prow0, int pvalid) {
+  // (thread -> element mapping = that of the In tile loads: a thread reads here exactly the In elements it is about
+  // to overwrite with the next tile's, so no barrier is needed between the two)
+  auto store_out = [&](int prow0, int pvalid, int pseg) {
     if constexpr (DGRAD) {
+      static_assert(OQ == NOPS * IQ, "one input-gradient row piece per In row piece");
+      double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+      const float deg = (float)pseg;  // segment = degree block: a row of dS is gathered by `deg` neighbours
 #pragma unroll
-      for (int p = 0; p < OPASS; ++p) {
-        const int slot = tid + p * NT;
-        const int r = slot / OQ, q = slot - r * OQ;
-        const int o = q / (KT * 8), qq = q - o * (KT * 8);
-        float* dst = (NOPS == 2 && o == 1) ? a.dout[1] : a.dout[0];
-        const int ldd = (NOPS == 2 && o == 1) ? a.lddout[1] : a.lddout[0];
-        if (r < pvalid && 4 * qq < a.k_in)  // k_in % 4 == 0 (launcher)
-          *reinterpret_cast<float4*>(dst + ((unsigned)(prow0 + r) * (unsigned)ldd + 4u * qq)) =
-              *reinterpret_cast<const float4*>(Outs + r * OP + 4 * q);
+      for (int o = 0; o < NOPS; ++o) {
+        float* dst = o == 1 ? a.dout[1] : a.dout[0];
+        const int ldd = o == 1 ? a.lddout[1] : a.lddout[0];
+#pragma unroll
+        for (int p = 0; p < IPASS; ++p) {
+          const int slot = tid + p * NT;
+          const int r = slot / IQ, q = slot - r * IQ;
+          if (r < pvalid && 4 * q < a.k_in) {  // k_in % 4 == 0 (launcher)
+            const float4 v = *reinterpret_cast<const float4*>(Outs + r * OP + o * KP + 4 * q);
+            *reinterpret_cast<float4*>(dst + ((unsigned)(prow0 + r) * (unsigned)ldd + 4u * q)) = v;
+            if (a.psums != nullptr) {
+              const float4 in = *reinterpret_cast<const float4*>(Ins + (o * kFRows + r) * IP + 4 * q);
+              const float wgt = (NOPS == 2 && o == 0) ? deg : 1.f;
+              s1[0] += (double)(wgt * v.x); s1[1] += (double)(wgt * v.y);
+              s1[2] += (double)(wgt * v.z); s1[3] += (double)(wgt * v.w);
+              s2[0] += (double)v.x * (double)in.x; s2[1] += (double)v.y * (double)in.y;
+              s2[2] += (double)v.z * (double)in.z; s2[3] += (double)v.w * (double)in.w;
+            }
+          }
+        }
+      }
+      if (a.psums != nullptr) {
+        const int q = tid % IQ;  // NT % IQ == 0: the same column piece in every pass
+        if (4 * q < a.k_in) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            atomicAdd(&stat_s[0][4 * q + i], s1[i]);
+            atomicAdd(&stat_s[1][4 * q + i], s2[i]);
+          }
+        }
       }
     }
   };
@@ -259,7 +295,7 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
   load_src(row0, valid);
   load_mem(nrow0, nvalid, mem1);  // mem1 now describes tile 1: its sources are requested in phase (b) of tile 0
   int cur_seg = -1;
-  int prow0 = row0, pvalid = 0;
+  int prow0 = row0, pvalid = 0, pseg = 0;
 
   const bool stamp = a.diag != nullptr && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == NT / 64 - 1);
   unsigned long long d_a = 0, d_w1 = 0, d_b = 0, d_w2 = 0, t0 = 0, t1 = 0;
@@ -298,7 +334,9 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
       }
     }
 
-    // ---- phase (a): G and the In rows of this tile -> LDS
+    // ---- phase (a): the previous tile's input gradients out (they were written before the last barrier; this also
+    // reads the previous In rows, so it comes first), then G and the In rows of this tile -> LDS
+    if (i > 0) store_out(prow0, pvalid, pseg);
 #pragma unroll
     for (int p = 0; p < GPASS; ++p) {
       const int r = gr + p * RPP;
@@ -340,7 +378,6 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
         *reinterpret_cast<float4*>(Ins + (o * kFRows + r) * IP + 4 * q) = v;
       }
     }
-    if (i > 0) store_out(prow0, pvalid);  // the previous tile's input gradients (written before the last barrier)
     if (stamp) { t1 = wall_clock64(); d_a += t1 - t0; }
     __syncthreads();
     if (stamp) { t0 = wall_clock64(); d_w1 += t0 - t1; }
@@ -541,12 +578,23 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
     if (stamp) { t1 = wall_clock64(); d_b += t1 - t0; }
     __syncthreads();
     if (stamp) { t0 = wall_clock64(); d_w2 += t0 - t1; }
-    prow0 = row0; pvalid = valid;
+    prow0 = row0; pvalid = valid; pseg = seg;
     seg = nseg; row0 = nrow0; valid = nvalid;
     nseg = n2seg; nrow0 = n2row0; nvalid = n2valid;
   }
-  store_out(prow0, pvalid);
+  store_out(prow0, pvalid, pseg);
   if (!is_dgrad) flush_w(cur_seg);
+  if constexpr (DGRAD) {
+    if (a.psums != nullptr) {
+      __syncthreads();
+      for (int c = tid; c < 2 * KP; c += NT) {
+        const int which = c / KP, col = c - which * KP;
+        if (col < a.k_in)
+          atomicAdd(a.psums + (size_t)2 * a.k_in * (1 + (blockIdx.x % kBnReplicas)) + (size_t)which * a.k_in + col,
+                    stat_s[which][col]);
+      }
+    }
+  }
   if (stamp) {
     unsigned long long* d = a.diag + (wave == 0 ? 0 : 5);
     d[0] = d_a; d[1] = d_w1; d[2] = d_b; d[3] = d_w2; d[4] = (unsigned long long)my_tiles;
@@ -633,7 +681,7 @@ int fused_conv_bwd(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
                    const int64_t* w_self, const int64_t* b_off, const float* d_dy, int64_t lddy, const float* d_gc,
                    int64_t ldgc, const float* d_coef, int32_t width, const float* d_s, int64_t lds, const float* d_x,
                    int64_t ldx, int32_t k_in, const float* d_w, float* d_dw, float* d_dbsum, float* d_ds_out,
-                   int64_t ldds, float* d_dxs_out, int64_t lddxs, hipStream_t sm) {
+                   int64_t ldds, float* d_dxs_out, int64_t lddxs, double* d_psums, hipStream_t sm) {
   if (!fused_bwd_enabled() || n_seg > kFMaxSeg || width != 64) return GCMI_ERR_UNSUPPORTED;
   {  // 32-bit element offsets inside the kernel: every array below 2^30 elements
     int64_t rows = 0;
@@ -653,6 +701,7 @@ int fused_conv_bwd(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
   a.in[0] = d_s; a.ldin[0] = (int32_t)lds; a.in[1] = d_x; a.ldin[1] = (int32_t)ldx; a.k_in = k_in;
   a.w = d_w; a.dw = d_dw; a.db = d_dbsum;
   a.dout[0] = d_ds_out; a.lddout[0] = (int32_t)ldds; a.dout[1] = d_dxs_out; a.lddout[1] = (int32_t)lddxs;
+  a.psums = dgrad ? d_psums : nullptr;
   if (dgrad) {
     if (k_in % 4 || ldds % 4 || lddxs % 4 || !aligned16(d_ds_out) || !aligned16(d_dxs_out)) return GCMI_ERR_UNSUPPORTED;
     if (k_in > 32 && k_in <= 64) return launch_fused<64, 2, 2, false, false, true>(st, tiles, a, sm);
@@ -668,7 +717,7 @@ int fused_conv_bwd(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
 int fused_dense_bwd(int64_t n_rows, const int32_t* d_membership, const float* d_g2, int64_t ldg2,
                     const int32_t* d_arg, const float* d_dense, int64_t ldd, const float* d_coef, int32_t width,
                     const float* d_p, int64_t ldp, int32_t k_in, const float* d_w, float* d_dw, float* d_db,
-                    float* d_dp, int64_t lddp, hipStream_t sm) {
+                    float* d_dp, int64_t lddp, double* d_psums, hipStream_t sm) {
   if (!fused_bwd_enabled() || width != 128 || k_in <= 32 || k_in > 64 || d_coef == nullptr) return GCMI_ERR_UNSUPPORTED;
   if (!aligned16(d_g2) || ldg2 % 4 || !aligned16(d_arg) || !aligned16(d_dense) || ldd % 4 || !aligned16(d_coef))
     return GCMI_ERR_UNSUPPORTED;
@@ -685,6 +734,7 @@ int fused_dense_bwd(int64_t n_rows, const int32_t* d_membership, const float* d_
   a.in[0] = d_p; a.ldin[0] = (int32_t)ldp; a.k_in = k_in;
   a.w = d_w; a.dw = d_dw; a.db = d_db;
   a.dout[0] = d_dp; a.lddout[0] = (int32_t)lddp;
+  a.psums = d_psums;
   return launch_fused<128, 2, 1, true, true, true>(st, tiles, a, sm);
 }
 

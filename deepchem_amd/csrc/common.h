@@ -78,6 +78,17 @@ bool win_stats_usable(const gcmi_graph* g, int n_feat);
 int win_gather_max_bwd_stats(const gcmi_graph* g, const float* d_dout, int64_t lddo, int n_feat, const uint8_t* d_arg,
                              float* d_dx, int64_t lddx, const float* d_x, int64_t ldx, const float* d_mean,
                              const float* d_invstd, double* d_sums, hipStream_t st);
+// BatchNorm backward from the sums sum dP, sum dP * P over the rows of the block ABOVE (bwd_fused.hip: psums), with
+// P = max over neighbours of the BatchNorm output y = gamma * xhat + beta: sum dy = sum dP and
+// sum dy * xhat = (sum dP * P - beta * sum dP) / gamma, no pass over dy.  Where that division is ill-conditioned
+// (|beta| > 64 |gamma| in some column) the direct column sums are taken instead: the kernels that are only needed
+// for them (column sums; in reference mode also the GraphPool backward) are launched every time and return at once
+// unless the test below says so.  d_dy may be NULL when the caller never produces it (then the direct sums are too).
+int bn_bwd_pool_impl(const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat,
+                     const float* d_gamma, const float* d_beta, const float* d_mean, const float* d_invstd,
+                     float* d_dgamma, float* d_dbeta, double* d_psums, double* d_acc, void* stream);
+int win_gather_max_bwd_if_ill(const gcmi_graph* g, const float* d_dout, int64_t lddo, int n_feat, const uint8_t* d_arg,
+                              float* d_dx, int64_t lddx, const float* d_gamma, const float* d_beta, hipStream_t st);
 // the part of the BatchNorm backward after its column sums (dgamma, dbeta, coefficient vectors at the head of d_acc)
 int bn_bwd_params_impl(int64_t n_rows, int32_t n_feat, const float* d_gamma, const float* d_mean,
                        const float* d_invstd, float* d_dgamma, float* d_dbeta, double* d_acc, void* stream);
@@ -122,11 +133,11 @@ int fused_conv_bwd(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
                    const int64_t* w_self, const int64_t* b_off, const float* d_dy, int64_t lddy, const float* d_gc,
                    int64_t ldgc, const float* d_coef, int32_t width, const float* d_s, int64_t lds, const float* d_x,
                    int64_t ldx, int32_t k_in, const float* d_w, float* d_dw, float* d_dbsum, float* d_ds_out,
-                   int64_t ldds, float* d_dxs_out, int64_t lddxs, hipStream_t sm);
+                   int64_t ldds, float* d_dxs_out, int64_t lddxs, double* d_psums, hipStream_t sm);
 int fused_dense_bwd(int64_t n_rows, const int32_t* d_membership, const float* d_g2, int64_t ldg2,
                     const int32_t* d_arg, const float* d_dense, int64_t ldd, const float* d_coef, int32_t width,
                     const float* d_p, int64_t ldp, int32_t k_in, const float* d_w, float* d_dw, float* d_db,
-                    float* d_dp, int64_t lddp, hipStream_t sm);
+                    float* d_dp, int64_t lddp, double* d_psums, hipStream_t sm);
 
 // accumulator replicas of the BatchNorm column sums (same-address fp64 atomics serialise); scratch layout in
 // doubles: [0, 2F) backward coefficient vectors, then kBnReplicas blocks of [sum(F) | sum of squares(F)]
@@ -175,6 +186,17 @@ __device__ __forceinline__ int degree_of_row(const DegTable& t, int i) {
 #pragma unroll
   for (int k = 1; k <= GCMI_MAX_DEG; ++k) d += (k <= t.max_deg && i >= t.deg_start[k]) ? 1 : 0;
   return d;
+}
+
+// wave-uniform: some column has |beta| > 64 |gamma| (or a NaN): (y - beta) / gamma does not recover xhat well there
+__device__ __forceinline__ bool bn_pool_ill_conditioned(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        int n_feat) {
+  bool bad = false;
+  for (int c = threadIdx.x & 63; c < n_feat; c += 64) {
+    const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+    bad = bad || !(fabsf(bt) <= 64.f * fabsf(gm));
+  }
+  return __ballot(bad) != 0ull;
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -146,6 +146,7 @@ struct SumOp {
   float* __restrict__ s;
   int64_t lds;
   using State = NoState;
+  __device__ __forceinline__ bool skip(int) const { return false; }
   template <int WT>
   __device__ __forceinline__ void init(float*, int, State&) const {}
   template <int WT>
@@ -199,6 +200,7 @@ struct MaxOp {
   // the folded BatchNorm vectors live in LDS: a global load in the compute phase would make the
   // compiler wait for the LDS-DMA in flight as well
   using State = NoState;
+  __device__ __forceinline__ bool skip(int) const { return false; }
   template <int WT>
   __device__ __forceinline__ void init(float* sh_lds, int n_feat, State&) const {
     if (BN)
@@ -266,6 +268,12 @@ struct MaxBwdOp {
   const float* __restrict__ mean;
   const float* __restrict__ invstd;
   double* __restrict__ sums;        // bn.hip scratch layout: [coef 2F][replica][sum F | sum of products F]
+  // optional (bn_bwd_pool_impl): dx is needed only where the pooled BatchNorm sums are ill-conditioned
+  const float* __restrict__ only_if_gamma;
+  const float* __restrict__ only_if_beta;
+  __device__ __forceinline__ bool skip(int n_feat) const {
+    return only_if_gamma != nullptr && !bn_pool_ill_conditioned(only_if_gamma, only_if_beta, n_feat);
+  }
   struct State {
     double s1[STATS ? 4 : 1], s2[STATS ? 4 : 1];
   };
@@ -377,6 +385,7 @@ win_kernel(const int32_t* __restrict__ meta, const uint16_t* __restrict__ edges,
   int(*ring)[GCMI_WIN_META_INTS] = reinterpret_cast<int(*)[GCMI_WIN_META_INTS]>(smem_all);
   float* op_lds = reinterpret_cast<float*>(smem_all + kRingBytes);
   char* smem = smem_all + kHeadBytes;
+  if (op.skip(LPR * 4)) return;  // uniform over the grid
   typename Op::State ost;
   op.template init<WT>(op_lds, LPR * 4, ost);
   const int t = threadIdx.x;
@@ -555,8 +564,14 @@ int win_gather_max(const gcmi_graph* g, const float* d_x, int64_t ldx, int n_fea
 
 int win_gather_max_bwd(const gcmi_graph* g, const float* d_dout, int64_t lddo, int n_feat,
                        const uint8_t* d_arg, float* d_dx, int64_t lddx, hipStream_t st) {
-  MaxBwdOp<false> op{d_dx, lddx, nullptr, 0, nullptr, nullptr, nullptr};
+  MaxBwdOp<false> op{d_dx, lddx, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
   return launch<true>(g, n_feat, d_dout, lddo, d_arg, op, st, "win_gather_max_bwd");
+}
+
+int win_gather_max_bwd_if_ill(const gcmi_graph* g, const float* d_dout, int64_t lddo, int n_feat, const uint8_t* d_arg,
+                              float* d_dx, int64_t lddx, const float* d_gamma, const float* d_beta, hipStream_t st) {
+  MaxBwdOp<false> op{d_dx, lddx, nullptr, 0, nullptr, nullptr, nullptr, d_gamma, d_beta};
+  return launch<true>(g, n_feat, d_dout, lddo, d_arg, op, st, "win_gather_max_bwd (conditional)");
 }
 
 // threads per workgroup of the window kernels must be a multiple of the row's 16-byte pieces for the statistics form
@@ -567,7 +582,7 @@ bool win_stats_usable(const gcmi_graph* g, int n_feat) {
 int win_gather_max_bwd_stats(const gcmi_graph* g, const float* d_dout, int64_t lddo, int n_feat, const uint8_t* d_arg,
                              float* d_dx, int64_t lddx, const float* d_x, int64_t ldx, const float* d_mean,
                              const float* d_invstd, double* d_sums, hipStream_t st) {
-  MaxBwdOp<true> op{d_dx, lddx, d_x, ldx, d_mean, d_invstd, d_sums};
+  MaxBwdOp<true> op{d_dx, lddx, d_x, ldx, d_mean, d_invstd, d_sums, nullptr, nullptr};
   return launch<true>(g, n_feat, d_dout, lddo, d_arg, op, st, "win_gather_max_bwd (statistics)");
 }
 

@@ -48,7 +48,7 @@ struct Ws {
   int64_t ldS[kMaxL], ngather[kMaxL];
   int64_t dense, arg_r, rsum, dfp, tA, tB, tC, tD, tE, total;
   // one region the backward zeroes with a single memset: [dlogits | dbsum per layer | lacc | acc]
-  int64_t dlogits, dbsum[kMaxL], lacc, acc, z_end;
+  int64_t dlogits, dbsum[kMaxL], lacc, acc, acc2, z_end;
 };
 
 static Ws carve(const gcmi_model_desc* m, int64_t N, int64_t B, int64_t ld_features) {
@@ -94,6 +94,7 @@ static Ws carve(const gcmi_model_desc* m, int64_t N, int64_t B, int64_t ld_featu
   for (int l = 0; l < L; ++l) w.dbsum[l] = take((int64_t)(m->max_deg + 1) * m->conv_width[l]);
   w.lacc = take(4);
   w.acc = take(2 * GCMI_BN_ACC_DOUBLES(wmax));
+  w.acc2 = take(2 * GCMI_BN_ACC_DOUBLES(wmax));  // pooled BatchNorm-backward sums of the block below (bwd_fused.hip)
   w.z_end = off;
   w.total = off;
   return w;
@@ -331,6 +332,7 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
   float* dpool = ws + w.tC;  // grad w.r.t. the output of the last GraphPool
   const float* coef = ws + w.acc;  // [A | B | C] of the BatchNorm backward just computed (bn.hip: head of its scratch)
   bool dense_done = false;
+  bool have_psums = false;  // acc2 holds sum dP, sum dP * P for the BatchNorm below the block just processed
   if (m->batch_norm) {
     // GraphGather backward is recomputed inside the BatchNorm backward from the per-molecule
     // gradient (tanh derivative applied in place): the N x D gradient is never written or re-read
@@ -348,8 +350,8 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
       const int rc = fused_dense_bwd(N, g->d_membership, ws + w.dfp, 2 * D,
                                      reinterpret_cast<const int32_t*>(ws + w.arg_r), ws + w.dense, D, coef, D,
                                      ws + w.pool[L - 1], Wl, Wl, d_params + m->off_dense_w, d_grads + m->off_dense_w,
-                                     d_grads + m->off_dense_b, dpool, Wl, st);
-      if (rc == GCMI_OK) dense_done = true;
+                                     d_grads + m->off_dense_b, dpool, Wl, reinterpret_cast<double*>(ws + w.acc2), st);
+      if (rc == GCMI_OK) dense_done = have_psums = true;
       else if (rc != GCMI_ERR_UNSUPPORTED) return rc;
       else  // not covered after all (misaligned buffers): the separate pass, with its sums once more
         RUN(bn_bwd_readout_impl(g->d_membership, ws + w.dfp, 2 * D, reinterpret_cast<const int32_t*>(ws + w.arg_r),
@@ -392,7 +394,25 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
     const bool stats_in_gather = stats_env && m->batch_norm && sym && fused_bwd_enabled() && (try_fused || !full) &&
                                  win_stats_usable(g, W) && aligned16(dpool) && aligned16(dy) && aligned16(ws + w.gc[l]);
     if (!sym) RUN(zero(dy, sizeof(float) * (size_t)(N * W)));
-    if (stats_in_gather) {
+    const bool pool_sums = have_psums && m->batch_norm && sym && (try_fused || !full) && win_usable(g, W, true) &&
+                           win_has_width(W);
+    have_psums = false;
+    if (pool_sums) {
+      // The block above left sum dP and sum dP * P: this BatchNorm's backward needs no pass over dy (bn.hip,
+      // bn_bwd_pool_impl).  dy itself is needed when the GraphConv below trains; otherwise only by the
+      // ill-conditioned fallback, and the kernel returns at once unless that applies.
+      const float* bnv = ws + w.bnv[l];
+      if (full) {
+        RUN(gcmi_gather_max_bwd(g, dpool, W, W, reinterpret_cast<const uint8_t*>(ws + w.arg[l]), dy, W, stream));
+      } else {
+        TimedScope ts(GCMI_K_GATHER_MAX_BWD, st);
+        RUN(win_gather_max_bwd_if_ill(g, dpool, W, W, reinterpret_cast<const uint8_t*>(ws + w.arg[l]), dy, W,
+                                      d_params + m->off_bn_gamma[l], d_params + m->off_bn_beta[l], st));
+      }
+      RUN(bn_bwd_pool_impl(dy, W, ws + w.gc[l], W, N, W, d_params + m->off_bn_gamma[l], d_params + m->off_bn_beta[l], bnv,
+                           bnv + W, d_grads + m->off_bn_gamma[l], d_grads + m->off_bn_beta[l],
+                           reinterpret_cast<double*>(ws + w.acc2), reinterpret_cast<double*>(ws + w.acc), stream));
+    } else if (stats_in_gather) {
       const float* bnv = ws + w.bnv[l];
       {
         TimedScope ts(GCMI_K_GATHER_MAX_BWD, st);
@@ -422,8 +442,12 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
       const int rc = fused_conv_bwd(sg.n, sg.begin, sg.end, sg.w_rel, sg.w_self, sg.b_off, dy, W, ws + w.gc[l], W,
                                     m->batch_norm ? coef : nullptr, W, ws + w.S[l], w.ldS[l], xin, ldx, K,
                                     d_params + m->off_conv_w[l], d_grads + m->off_conv_w[l], ws + w.dbsum[l],
-                                    l > 0 ? dS : nullptr, K, l > 0 ? dX : nullptr, K, st);
-      if (rc == GCMI_OK) fused_done = true;
+                                    l > 0 ? dS : nullptr, K, l > 0 ? dX : nullptr, K,
+                                    (l > 0 && sym && m->batch_norm) ? reinterpret_cast<double*>(ws + w.acc2) : nullptr, st);
+      if (rc == GCMI_OK) {
+        fused_done = true;
+        have_psums = l > 0 && sym && m->batch_norm;
+      }
       else if (rc != GCMI_ERR_UNSUPPORTED) return rc;
       else if (m->batch_norm) {  // not covered after all (misaligned buffers): the separate pass, sums once more
         const float* bnv = ws + w.bnv[l];

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
 
 
-def _step(packed, y, w, tasks, grad_mode, fused, batch_norm=True, state=None, widths=(64, 64), dense=128):
+def _step(packed, y, w, tasks, grad_mode, fused, batch_norm=True, state=None, widths=(64, 64), dense=128, tweak=None):
     """forward + loss + backward of the whole-model entry points on one collated batch; returns the loss, the
     gradient arena and the parameter names with their slices."""
     import deepchem_amd as dc
@@ -27,6 +27,9 @@ def _step(packed, y, w, tasks, grad_mode, fused, batch_norm=True, state=None, wi
                                                   device=DEV)
     if state is not None:
         model.model.load_state_dict({k: v.clone() for k, v in state.items()})
+    if tweak is not None:
+        with torch.no_grad():
+            tweak(model.model)
     native = model.model._native_net()
     assert native is not None
     g = dbatch.graph
@@ -127,3 +130,28 @@ def test_fused_backward_against_the_oracle():
         assert np.abs(a - b).max() <= 1e-4 * scale + 1e-7, (name, np.abs(a - b).max(), scale)
         checked += 1
     assert checked > 40
+
+
+@pytest.mark.parametrize("grad_mode", ["full", "reference"])
+def test_pooled_batchnorm_sums_fall_back_when_ill_conditioned(grad_mode):
+    """The BatchNorm backward of a GraphConv block takes sum dy and sum dy * xhat from sums over the POOLED rows that
+    the block above leaves behind, (sum dP * P - beta sum dP) / gamma.  A column with |beta| > 64 |gamma| makes that
+    division ill-conditioned: the direct column sums take over (kernels launched every step that return at once
+    otherwise).  Both regimes against the separate kernels: a tiny gamma under a large beta, and a gamma of zero."""
+    from deepchem_amd.utils.synthetic import synthetic_labels, synthetic_molecules
+    packed = synthetic_molecules(400, seed=13, max_atoms=30)
+    y, w = synthetic_labels(400, 2, "classification", 13, pos_rate=0.4)
+
+    def tweak(module):
+        for i in (0, 1):
+            bn = module.batch_norms[i]
+            bn.weight[3] = 1e-3
+            bn.bias[3] = 0.7
+            bn.weight[9] = 0.0
+            bn.bias[9] = -0.2
+            bn.bias[20] = 30.0  # |beta| = 30 |gamma|: still the pooled sums
+
+    l1, g1, sl, r1, _ = _step(packed, y, w, 2, grad_mode, True, tweak=tweak)
+    l0, g0, _, r0, _ = _step(packed, y, w, 2, grad_mode, False, tweak=tweak)
+    assert r0 == r1 and abs(l1 - l0) <= 1e-6 * max(abs(l0), 1.0)
+    _compare(g1, g0, sl, r1, 2e-5)
