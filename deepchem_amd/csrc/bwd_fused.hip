@@ -246,10 +246,25 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
   // rows, 16 bytes per lane, and in program order BEFORE the loads that follow.
   // (thread -> element mapping = that of the In tile loads: a thread reads here exactly the In elements it is about
   // to overwrite with the next tile's, so no barrier is needed between the two)
+  // (the sums: fp32 partials per thread over a few tiles -- a thread keeps its column piece --, then fp64 in LDS:
+  // per-element fp64 products and LDS atomics cost a microsecond per tile)
+  float ps1[4] = {0.f, 0.f, 0.f, 0.f}, ps2[4] = {0.f, 0.f, 0.f, 0.f};
+  auto flush_psums = [&]() {
+    if constexpr (DGRAD) {
+      const int q = tid % IQ;  // NT % IQ == 0: the same column piece in every pass
+      if (4 * q < a.k_in) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          atomicAdd(&stat_s[0][4 * q + i], (double)ps1[i]);
+          atomicAdd(&stat_s[1][4 * q + i], (double)ps2[i]);
+          ps1[i] = ps2[i] = 0.f;
+        }
+      }
+    }
+  };
   auto store_out = [&](int prow0, int pvalid, int pseg) {
     if constexpr (DGRAD) {
       static_assert(OQ == NOPS * IQ, "one input-gradient row piece per In row piece");
-      double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
       const float deg = (float)pseg;  // segment = degree block: a row of dS is gathered by `deg` neighbours
 #pragma unroll
       for (int o = 0; o < NOPS; ++o) {
@@ -265,21 +280,11 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
             if (a.psums != nullptr) {
               const float4 in = *reinterpret_cast<const float4*>(Ins + (o * kFRows + r) * IP + 4 * q);
               const float wgt = (NOPS == 2 && o == 0) ? deg : 1.f;
-              s1[0] += (double)(wgt * v.x); s1[1] += (double)(wgt * v.y);
-              s1[2] += (double)(wgt * v.z); s1[3] += (double)(wgt * v.w);
-              s2[0] += (double)v.x * (double)in.x; s2[1] += (double)v.y * (double)in.y;
-              s2[2] += (double)v.z * (double)in.z; s2[3] += (double)v.w * (double)in.w;
+              ps1[0] = fmaf(wgt, v.x, ps1[0]); ps1[1] = fmaf(wgt, v.y, ps1[1]);
+              ps1[2] = fmaf(wgt, v.z, ps1[2]); ps1[3] = fmaf(wgt, v.w, ps1[3]);
+              ps2[0] = fmaf(v.x, in.x, ps2[0]); ps2[1] = fmaf(v.y, in.y, ps2[1]);
+              ps2[2] = fmaf(v.z, in.z, ps2[2]); ps2[3] = fmaf(v.w, in.w, ps2[3]);
             }
-          }
-        }
-      }
-      if (a.psums != nullptr) {
-        const int q = tid % IQ;  // NT % IQ == 0: the same column piece in every pass
-        if (4 * q < a.k_in) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            atomicAdd(&stat_s[0][4 * q + i], s1[i]);
-            atomicAdd(&stat_s[1][4 * q + i], s2[i]);
           }
         }
       }
@@ -336,7 +341,10 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
 
     // ---- phase (a): the previous tile's input gradients out (they were written before the last barrier; this also
     // reads the previous In rows, so it comes first), then G and the In rows of this tile -> LDS
-    if (i > 0) store_out(prow0, pvalid, pseg);
+    if (i > 0) {
+      store_out(prow0, pvalid, pseg);
+      if (a.psums != nullptr && (i & 7) == 0) flush_psums();
+    }
 #pragma unroll
     for (int p = 0; p < GPASS; ++p) {
       const int r = gr + p * RPP;
@@ -586,6 +594,7 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
   if (!is_dgrad) flush_w(cur_seg);
   if constexpr (DGRAD) {
     if (a.psums != nullptr) {
+      flush_psums();
       __syncthreads();
       for (int c = tid; c < 2 * KP; c += NT) {
         const int which = c / KP, col = c - which * KP;

@@ -333,6 +333,7 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
   const float* coef = ws + w.acc;  // [A | B | C] of the BatchNorm backward just computed (bn.hip: head of its scratch)
   bool dense_done = false;
   bool have_psums = false;  // acc2 holds sum dP, sum dP * P for the BatchNorm below the block just processed
+  static const bool psums_env = !(getenv("GCMI_FUSED_PSUMS") && atoi(getenv("GCMI_FUSED_PSUMS")) == 0);
   if (m->batch_norm) {
     // GraphGather backward is recomputed inside the BatchNorm backward from the per-molecule
     // gradient (tanh derivative applied in place): the N x D gradient is never written or re-read
@@ -350,8 +351,12 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
       const int rc = fused_dense_bwd(N, g->d_membership, ws + w.dfp, 2 * D,
                                      reinterpret_cast<const int32_t*>(ws + w.arg_r), ws + w.dense, D, coef, D,
                                      ws + w.pool[L - 1], Wl, Wl, d_params + m->off_dense_w, d_grads + m->off_dense_w,
-                                     d_grads + m->off_dense_b, dpool, Wl, reinterpret_cast<double*>(ws + w.acc2), st);
-      if (rc == GCMI_OK) dense_done = have_psums = true;
+                                     d_grads + m->off_dense_b, dpool, Wl,
+                                     psums_env ? reinterpret_cast<double*>(ws + w.acc2) : nullptr, st);
+      if (rc == GCMI_OK) {
+        dense_done = true;
+        have_psums = psums_env;
+      }
       else if (rc != GCMI_ERR_UNSUPPORTED) return rc;
       else  // not covered after all (misaligned buffers): the separate pass, with its sums once more
         RUN(bn_bwd_readout_impl(g->d_membership, ws + w.dfp, 2 * D, reinterpret_cast<const int32_t*>(ws + w.arg_r),
@@ -443,10 +448,11 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
                                     m->batch_norm ? coef : nullptr, W, ws + w.S[l], w.ldS[l], xin, ldx, K,
                                     d_params + m->off_conv_w[l], d_grads + m->off_conv_w[l], ws + w.dbsum[l],
                                     l > 0 ? dS : nullptr, K, l > 0 ? dX : nullptr, K,
-                                    (l > 0 && sym && m->batch_norm) ? reinterpret_cast<double*>(ws + w.acc2) : nullptr, st);
+                                    (psums_env && l > 0 && sym && m->batch_norm) ? reinterpret_cast<double*>(ws + w.acc2)
+                                                                                 : nullptr, st);
       if (rc == GCMI_OK) {
         fused_done = true;
-        have_psums = l > 0 && sym && m->batch_norm;
+        have_psums = psums_env && l > 0 && sym && m->batch_norm;
       }
       else if (rc != GCMI_ERR_UNSUPPORTED) return rc;
       else if (m->batch_norm) {  // not covered after all (misaligned buffers): the separate pass, sums once more
