@@ -323,7 +323,7 @@ def main():
     import deepchem_amd
     from deepchem_amd import ops
     deepchem_amd.set_gemm_mode(args.gemm_mode)
-    from deepchem_amd._lib import (K_BATCHNORM, K_GATHER_MAX, K_GATHER_MAX_BWD, K_GATHER_SUM, K_READOUT,
+    from deepchem_amd._lib import (K_BATCHNORM, K_FUSED_BWD, K_GATHER_MAX, K_GATHER_MAX_BWD, K_GATHER_SUM, K_READOUT,
                                    K_SEG_GEMM, K_WGRAD)
 
     model, dbatch, labels, weights = make_workload(args, rank, device, args.batch)
@@ -333,7 +333,8 @@ def main():
     run_steps(model, dbatch, labels, weights, max(args.warmup, 1))
 
     kernel_ids = {"gather_sum": K_GATHER_SUM, "gather_max": K_GATHER_MAX, "gather_max_bwd": K_GATHER_MAX_BWD,
-                  "readout": K_READOUT, "seg_gemm": K_SEG_GEMM, "wgrad": K_WGRAD, "batchnorm": K_BATCHNORM}
+                  "readout": K_READOUT, "seg_gemm": K_SEG_GEMM, "wgrad": K_WGRAD, "batchnorm": K_BATCHNORM,
+                  "fused_bwd": K_FUSED_BWD}
     # Inside the timed region only the roofline kernel is event-timed: every timed launch is
     # bracketed by two event records on the launch stream, which costs ~10 us of queue time each.
     # The other kernel families are measured in a second, untimed pass.
@@ -369,13 +370,13 @@ def main():
     g = dbatch.graph
     n0 = g.deg_counts[0]
     # gather-sum launches of one step: forward layer 0 (F=75), forward layer 1 (F=64) and, in
-    # "full" mode, the backward of layer 1 as a gather of dS (F=64; the self term is added by the
-    # epilogue of the following GEMM)
+    # "full" mode, the backward of layer 1 as a gather of dS accumulated onto the self term the one-pass
+    # block kernel left in dX (F=64, read-modify-write of the destination)
     per_step = gather_sum_bytes(g.n_atoms, g.n_edges, n0, 75, False) + \
         gather_sum_bytes(g.n_atoms, g.n_edges, n0, 64, False)
     launches_per_step = 2
     if args.grad_mode == "full":
-        per_step += gather_sum_bytes(g.n_atoms, g.n_edges, n0, 64, False)
+        per_step += gather_sum_bytes(g.n_atoms, g.n_edges, n0, 64, True)
         launches_per_step = 3
     n_launch, ms = gather_time
     achieved = (per_step * args.steps) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -406,8 +407,8 @@ def main():
             "parallelism": "dp%d (molecules sharded by rank, one flat all-reduce per step)" % world,
         },
         "roofline": {
-            "kernel": "win_kernel<512, {16|19}, false, SumOp> (gather_lds.hip: GraphConv.sum_neigh over LDS molecule "
-                      "windows, forward of both layers and the backward of layer 1)",
+            "kernel": "win_kernel<512, {16|19}, false, SumOp<false|true>> (gather_lds.hip: GraphConv.sum_neigh over LDS "
+                      "molecule windows, forward of both layers and, accumulating, the backward of layer 1)",
             "bound": "hbm",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
@@ -434,15 +435,16 @@ def main():
         "gather_max_bwd": 2 * (E * (5 * 64 + 5) + 2 * N * 4 * 64 + N * 64) if args.grad_mode == "full" else
         (E * (5 * 64 + 5) + 2 * N * 4 * 64 + N * 64),
         "readout": N * (4 * 128 + 4) + B * 8 * 128,
-        # forward: GraphConv 0/1, dense, head; backward: head, dense, GraphConv 1 (self + neighbour terms)
-        "seg_gemm": 4 * (N * (75 + 75 + 64) + N * (64 + 64 + 64) + N * (64 + 128) + B * (256 + 24) +
-                         B * (24 + 256) + N * (128 + 64) +
-                         (N * (64 + 64) + N * (64 + 64 + 64) if args.grad_mode == "full" else 0)),
-        # dW = A^T dY per operand: head, dense, GraphConv 1 (S and X), GraphConv 0 (S and X)
-        "wgrad": 4 * (B * (256 + 24) + N * (64 + 128) + 2 * N * (64 + 64) + 2 * N * (75 + 64)),
-        # forward statistics ride in the epilogue of the producing product (no bytes of their own); backward: dy and
-        # y read for the sums, read again and dx written by the second pass (the 128-wide dy is recomputed, not read)
-        "batchnorm": 4 * N * (5 * 64 + 5 * 64 + 3 * 128),
+        # forward: GraphConv 0/1, dense, head; backward: head (the blocks' backward products: fused_bwd)
+        "seg_gemm": 4 * (N * (75 + 75 + 64) + N * (64 + 64 + 64) + N * (64 + 128) + B * (256 + 24) + B * (24 + 256)),
+        # dW = A^T dY of the head (the blocks' weight gradients: fused_bwd)
+        "wgrad": 4 * B * (256 + 24),
+        # forward statistics ride in the epilogue of the producing product, the backward sums come from per-molecule
+        # data (dense layer) or from the block above (GraphConv layers): what is left reads B x 640 floats
+        "batchnorm": 4 * B * (256 + 128 + 256),
+        # one pass per block: dense (reads dense 128 + pool 64, writes dpool 64; + ~77 floats per atom of per-molecule
+        # gradient rows fetched once per degree run), GraphConv 1 (dy, gc, S, x -> dS, dXs), GraphConv 0 (dy, gc, S, x)
+        "fused_bwd": 4 * (N * (128 + 64 + 64) + (N * (6 * 64) + N * (64 + 64 + 76 + 76) if args.grad_mode == "full" else 0)),
     }
     out["roofline_by_kernel"] = {
         k: {"ms": round(ktimes[k][1] / breakdown_steps, 4), "algorithmic_bytes": int(fam_bytes[k]),

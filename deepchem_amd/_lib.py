@@ -16,7 +16,7 @@ BN_ACC_REPLICAS = 32
 
 def bn_acc_doubles(n_feat: int) -> int:
     return 66 * n_feat
-K_GATHER_SUM, K_GATHER_MAX, K_READOUT, K_SEG_GEMM, K_WGRAD, K_GATHER_MAX_BWD, K_BATCHNORM = 0, 1, 2, 3, 4, 5, 6
+K_GATHER_SUM, K_GATHER_MAX, K_READOUT, K_SEG_GEMM, K_WGRAD, K_GATHER_MAX_BWD, K_BATCHNORM, K_FUSED_BWD = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 GCMI_OPT_GEMM_EXACT = 1

@@ -347,7 +347,7 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
                             g->n_mols, g->max_deg + 1));
     if (try_fused) {
       // one pass: dxD formed per 64-row tile in LDS, dW_dense += dxD^T pool, db += colsum, dpool = dxD W_dense
-      TimedScope ts(GCMI_K_SEG_GEMM, st);
+      TimedScope ts(GCMI_K_FUSED_BWD, st);
       const int rc = fused_dense_bwd(N, g->d_membership, ws + w.dfp, 2 * D,
                                      reinterpret_cast<const int32_t*>(ws + w.arg_r), ws + w.dense, D, coef, D,
                                      ws + w.pool[L - 1], Wl, Wl, d_params + m->off_dense_w, d_grads + m->off_dense_w,
@@ -443,7 +443,7 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
     if (try_fused) {
       // one pass over the rows: dgc formed per tile in LDS; dW_rel, dW_self, dbsum; and for l > 0 dS = dgc W_rel^T
       // and the self part of dX
-      TimedScope ts(GCMI_K_SEG_GEMM, st);
+      TimedScope ts(GCMI_K_FUSED_BWD, st);
       const int rc = fused_conv_bwd(sg.n, sg.begin, sg.end, sg.w_rel, sg.w_self, sg.b_off, dy, W, ws + w.gc[l], W,
                                     m->batch_norm ? coef : nullptr, W, ws + w.S[l], w.ldS[l], xin, ldx, K,
                                     d_params + m->off_conv_w[l], d_grads + m->off_conv_w[l], ws + w.dbsum[l],

@@ -592,6 +592,7 @@ enum {
   GCMI_K_WGRAD = 4,
   GCMI_K_GATHER_MAX_BWD = 5,
   GCMI_K_BATCHNORM = 6, /* column sums, finalize, backward (statistics and dx) */
+  GCMI_K_FUSED_BWD = 7, /* the one-pass backward of a GraphConv / dense block (bwd_fused.hip) */
   GCMI_K_COUNT = 8
 };
 int gcmi_timing_enable(int32_t kernel_id, int32_t on);

@@ -414,10 +414,15 @@ def test_packed_dataset_pipeline_equals_python_collation():
         model.fit(ds, nb_epoch=2, deterministic=True, checkpoint_interval=0,
                   callbacks=[lambda m, s, iteration_loss=None: losses.append(float(iteration_loss))])
         outs.append((losses, model.predict(ds), model.predict_embedding(ds)))
+    # The python arm trains on the per-batch path (one-pass block kernels, split-bf16 products), the other two on the
+    # small-batch engine (fp32 MFMA): same batches, gradients equal to ~5e-7 of each tensor's scale (summation order),
+    # and Adam's first steps move every entry by lr * sign(g) -- entries at that noise level go either way.  Six
+    # optimizer steps later the outputs agree to a few 1e-5; the losses, which see the parameters before the
+    # differences have grown, to 1e-5 relative.  A batch that differed would be off by O(1).
     for losses, pred, emb in outs[1:]:
         assert np.allclose(losses, outs[0][0], rtol=1e-5, atol=1e-7)
-        assert np.allclose(pred, outs[0][1], atol=1e-6) and pred.shape == outs[0][1].shape
-        assert np.allclose(emb, outs[0][2], atol=1e-6) and emb.shape == outs[0][2].shape
+        assert pred.shape == outs[0][1].shape and np.abs(pred - outs[0][1]).max() <= 1e-4, np.abs(pred - outs[0][1]).max()
+        assert emb.shape == outs[0][2].shape and np.abs(emb - outs[0][2]).max() <= 1e-4, np.abs(emb - outs[0][2]).max()
     # shuffled epochs draw the same permutations as NumpyDataset.iterbatches
     np.random.seed(3)
     a = [i.tolist() for i, _ in PackedDataset(packed, y, w).iter_index_batches(10, 2, False, True)]
@@ -453,7 +458,8 @@ def test_disk_dataset_fast_path_equals_python_collation(tmp_path):
         outs.append((losses, model.predict(ds)))
     assert len(outs[0][0]) == len(outs[1][0]) > 0
     assert np.allclose(outs[1][0], outs[0][0], rtol=1e-5, atol=1e-7)
-    assert np.allclose(outs[1][1], outs[0][1], atol=1e-6) and outs[1][1].shape[0] == n
+    # (per-batch path against the small-batch engine: see test_packed_dataset_pipeline_equals_python_collation)
+    assert np.abs(outs[1][1] - outs[0][1]).max() <= 1e-4 and outs[1][1].shape[0] == n
 
 
 def test_pcba_like_head_128_tasks():
