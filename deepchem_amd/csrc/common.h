@@ -139,6 +139,14 @@ int fused_dense_bwd(int64_t n_rows, const int32_t* d_membership, const float* d_
                     const float* d_p, int64_t ldp, int32_t k_in, const float* d_w, float* d_dw, float* d_db,
                     float* d_dp, int64_t lddp, double* d_psums, hipStream_t sm);
 
+// fwd_fused.hip: the forward product of a block as persistent workgroups with resident weight images (default widths,
+// split-bf16 mode); GCMI_ERR_UNSUPPORTED = shape not covered
+int fwd_fused_gemm(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_end, const float* d_a1, int64_t lda1,
+                   int32_t k1, const float* d_w1, const int64_t* w1_off, const float* d_a2, int64_t lda2, int32_t k2,
+                   const float* d_w2, const int64_t* w2_off, const float* d_bias, const int64_t* bias_off,
+                   int32_t n_out, int32_t trans_w, int32_t act, float* d_out, int64_t ldo, double* d_stats,
+                   hipStream_t sm);
+
 // accumulator replicas of the BatchNorm column sums (same-address fp64 atomics serialise); scratch layout in
 // doubles: [0, 2F) backward coefficient vectors, then kBnReplicas blocks of [sum(F) | sum of squares(F)]
 constexpr int kBnReplicas = 32;

@@ -811,6 +811,18 @@ int seg_gemm_stats(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
                          (d_a1 || d_a2) && (d_a1 == nullptr || (d_w1 && w1_off && k1 > 0 && lda1 >= k1)) &&
                          (d_a2 == nullptr || (d_w2 && w2_off && k2 > 0 && lda2 >= k2)) &&
                          (d_bias == nullptr || bias_off != nullptr) && (act == 0 || act == 1);
+  if (shapes_ok && v4 && !v3 && !gemm_exact_mode()) {
+    // the persistent form (fwd_fused.hip) for the shapes it covers
+    hipStream_t sm = (hipStream_t)stream;
+    TimedScope ts(GCMI_K_SEG_GEMM, sm);
+    double* stats = (allow && d_stats) ? d_stats : nullptr;
+    const int rc = fwd_fused_gemm(n_seg, seg_begin, seg_end, d_a1, lda1, k1, d_w1, w1_off, d_a2, lda2, k2, d_w2, w2_off,
+                                  d_bias, bias_off, n_out, trans_w, act, d_out, ldo, stats, sm);
+    if (rc != GCMI_ERR_UNSUPPORTED) {
+      *fused = rc == GCMI_OK && stats != nullptr;
+      return rc;
+    }
+  }
   if (allow && d_stats && shapes_ok && v4 && !v3 && !gemm_exact_mode()) {
     hipStream_t sm = (hipStream_t)stream;
     TimedScope ts(GCMI_K_SEG_GEMM, sm);

@@ -43,7 +43,7 @@ def _step(packed, y, w, tasks, grad_mode, fused, batch_norm=True, state=None, wi
     try:
         model.model.train()
         before = launches()
-        native.forward(dbatch.atom_features, g, True, want_probs=False)
+        logits, _, fp = native.forward(dbatch.atom_features, g, True, want_probs=False)
         loss = native.loss_backward(labels, weights, n)
         torch.cuda.synchronize()
         # the one-pass kernel really ran (dense layer; plus one per GraphConv layer when everything trains) / did not
@@ -52,6 +52,9 @@ def _step(packed, y, w, tasks, grad_mode, fused, batch_norm=True, state=None, wi
     finally:
         _lib.call("gcmi_set_option", _lib.GCMI_OPT_FUSED_BWD, 1)
     names = [k for k, _ in model.model.named_parameters()]
+    model.forward_results = (logits.clone(), fp.clone(),
+                             [(bn.running_mean.clone(), bn.running_var.clone()) for bn in model.model.batch_norms
+                              if hasattr(bn, "running_mean")])
     return float(loss), native.grad_flat.clone(), list(zip(names, native._slices)), native.grad_range, model
 
 
@@ -84,12 +87,20 @@ def test_fused_backward_equals_separate_kernels(grad_mode, n_mols):
     packed = concat_packed([synthetic_molecules(n_mols, seed=5, max_atoms=40), single_atom_and_edge_cases(75, seed=2)])
     tasks = 3
     y, w = synthetic_labels(packed.n_mols, tasks, "classification", 5, pos_rate=0.4)
-    l1, g1, sl, r1, _ = _step(packed, y, w, tasks, grad_mode, True)
-    l0, g0, _, r0, _ = _step(packed, y, w, tasks, grad_mode, False)
+    l1, g1, sl, r1, m1 = _step(packed, y, w, tasks, grad_mode, True)
+    l0, g0, _, r0, m0 = _step(packed, y, w, tasks, grad_mode, False)
     assert r0 == r1
     assert abs(l1 - l0) <= 1e-6 * max(abs(l0), 1.0)
     worst = _compare(g1, g0, sl, r1, 2e-5)
     print("worst relative difference", worst)
+    # the forward products of the same switch (fwd_fused.hip against seg_gemm4_kernel): outputs and the BatchNorm
+    # statistics taken in their epilogues
+    (lg1, fp1, bn1), (lg0, fp0, bn0) = m1.forward_results, m0.forward_results
+    assert (lg1 - lg0).abs().max() <= 2e-5 * max(float(lg0.abs().max()), 1.0)
+    assert (fp1 - fp0).abs().max() <= 2e-5
+    for (rm1, rv1), (rm0, rv0) in zip(bn1, bn0):
+        assert (rm1 - rm0).abs().max() <= 1e-6 * max(float(rm0.abs().max()), 1e-3)
+        assert (rv1 - rv0).abs().max() <= 1e-6 * max(float(rv0.abs().max()), 1e-3)
 
 
 def test_fused_backward_without_batchnorm():
