@@ -80,7 +80,7 @@ def measured_traffic():
     over THIS command with --profile-only) -- counters cannot be read from inside the process.  Returns
     (bytes per launch, file name) or (None, None)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")))
     files = [f for f in files if "R1" not in os.path.basename(f)]
     for path in reversed(files):
         try:
@@ -95,8 +95,21 @@ def measured_traffic():
                 tot += rec["hbm_bytes_per_launch"] * k
                 n += k
         if n:
+            # the whole step: every kernel's bytes per launch x its launches, over the profiled steps (the readout
+            # runs once per step)
+            steps = max((rec.get("fetch_launches", 0) for name, rec in kernels.items() if "readout_fwd" in name),
+                        default=0)
+            step_bytes = None
+            if steps:
+                step_bytes = int(sum(rec.get("hbm_bytes_per_launch", 0) *
+                                     max(rec.get("fetch_launches", 0), rec.get("write_launches", 0))
+                                     for rec in kernels.values()) / steps)
+            measured_traffic.step_bytes = step_bytes
             return int(tot / n), os.path.basename(path)
     return None, None
+
+
+measured_traffic.step_bytes = None
 
 
 def make_workload(args, rank, device, batch):
@@ -426,6 +439,12 @@ def main():
         },
         "kernel_ms_per_step": {k: round(v[1] / breakdown_steps, 4) for k, v in ktimes.items()},
     }
+    if measured_traffic.step_bytes:
+        # all kernels of the step together: measured bytes (same counter passes) over the measured step time
+        sb = measured_traffic.step_bytes
+        out["step_traffic"] = {"hbm_bytes_per_step": sb, "source": traffic_file,
+                               "achieved": round(sb / (wall / args.steps) / 1e9, 1), "unit": "GB/s",
+                               "frac_of_hbm_peak": round(sb / (wall / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
     # Every event-timed kernel family against the same HBM peak (second, untimed pass): algorithmic bytes per
     # step = operands read once + results written once (DESIGN.md section 7 lists the terms).
     N, E, B = g.n_atoms, g.n_edges, args.batch
