@@ -11,7 +11,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libgcmi.so")
-SOURCES = ["core.cpp", "collate.cpp", "featurize.cpp", "gather.hip", "gather_lds.hip", "readout.hip", "bn.hip", "gemm.hip", "gemm_split.hip", "bwd_fused.hip", "fwd_fused.hip", "loss.hip", "weave.hip", "mpnn.hip", "model.hip", "smallstep.hip"]
+SOURCES = ["core.cpp", "collate.cpp", "featurize.cpp", "gather.hip", "gather_lds.hip", "readout.hip", "bn.hip", "gemm.hip", "gemm_split.hip", "bwd_fused.hip", "fwd_fused.hip", "head_bwd.hip", "loss.hip", "weave.hip", "mpnn.hip", "model.hip", "smallstep.hip"]
 ARCH = "gfx950"
 
 

@@ -147,6 +147,15 @@ int fwd_fused_gemm(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
                    int32_t n_out, int32_t trans_w, int32_t act, float* d_out, int64_t ldo, double* d_stats,
                    hipStream_t sm);
 
+// head_bwd.hip: loss + d logits + task-head gradients + tanh' of the readout + the dense BatchNorm's backward sums in
+// one kernel over the molecules; GCMI_ERR_UNSUPPORTED = shape not covered (256-column fingerprint, <= 32 outputs)
+int head_bwd_fused(int32_t kind, const float* d_logits, const float* d_labels, const float* d_weights, int64_t n_rows,
+                   int32_t n_tasks, int32_t n_classes, int64_t n_mols, const float* d_fp, int64_t ldfp,
+                   const float* d_w, float* d_dw, float* d_db, float* d_g2, int64_t ldg2, double* d_loss_acc,
+                   const int32_t* d_runs, int32_t n_deg, const int32_t* d_arg, const float* d_rawsum,
+                   const float* d_mean, const float* d_invstd, double* d_sums, int32_t dense_width, hipStream_t st);
+int loss_finalize_impl(double* d_acc, float inv_count, float* d_loss, void* stream);
+
 // accumulator replicas of the BatchNorm column sums (same-address fp64 atomics serialise); scratch layout in
 // doubles: [0, 2F) backward coefficient vectors, then kBnReplicas blocks of [sum(F) | sum of squares(F)]
 constexpr int kBnReplicas = 32;

@@ -129,6 +129,13 @@ int loss_impl(int32_t kind, const float* d_logits, const float* d_labels, const 
   return GCMI_OK;
 }
 
+// *d_loss = *d_acc * inv_count, and the accumulator is left clean (head_bwd.hip adds to it itself)
+int loss_finalize_impl(double* d_acc, float inv_count, float* d_loss, void* stream) {
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_acc, inv_count, d_loss);
+  GCMI_CHECK_LAUNCH("loss_finalize");
+  return GCMI_OK;
+}
+
 }  // namespace gcmi
 
 using namespace gcmi;

@@ -312,18 +312,44 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
   RUN(zero(d_grads + lo, sizeof(float) * (size_t)(hi - lo)));
   // dlogits (rows beyond n_rows carry no gradient), the bias-gradient sums and every accumulator
   RUN(zero(ws + w.dlogits, sizeof(float) * (size_t)(w.z_end - w.dlogits)));
-  // ---- loss on the first n_rows molecules
-  RUN(loss_impl(m->mode == 0 ? 0 : 1, io->d_logits, d_labels, d_weights, n_rows, m->n_tasks,
-                m->n_classes, io->d_loss, ws + w.dlogits, nullptr,
-                reinterpret_cast<double*>(ws + w.lacc), true, stream));
   const int32_t zero32 = 0;
   const int64_t zero64 = 0;
   const int32_t nB = (int32_t)B, nN = (int32_t)N;
-  // ---- head
-  RUN(gcmi_seg_gemm_wgrad(1, &zero32, &nB, io->d_fingerprint, 2 * D, 2 * D, ws + w.dlogits, TC, TC,
-                          d_grads + m->off_head_w, &zero64, d_grads + m->off_head_b, &zero64, 1, stream));
-  RUN(gcmi_seg_gemm(1, &zero32, &nB, ws + w.dlogits, TC, TC, d_params + m->off_head_w, &zero64, nullptr, 0,
-                    0, nullptr, nullptr, nullptr, nullptr, 2 * D, 0, 0, ws + w.dfp, 2 * D, stream));
+  // ---- per-molecule part in one kernel where the shapes allow (head_bwd.hip): loss, d logits, head gradients, the
+  // gradient w.r.t. GraphGather's pre-activation (tanh derivative applied), and -- when the one-pass dense block
+  // follows -- the BatchNorm backward sums of the dense layer
+  const bool dense_fused_next = m->batch_norm && N > 0 && fused_bwd_enabled() && D == 128 &&
+                                m->conv_width[L - 1] > 32 && m->conv_width[L - 1] <= 64;
+  bool head_done = false, head_sums = false;
+  if (m->batch_norm) {  // (without BatchNorm the readout backward applies the tanh derivative itself)
+    const float* bnvL = ws + w.bnv[L];
+    const int rc = head_bwd_fused(m->mode == 0 ? 0 : 1, io->d_logits, d_labels, d_weights, n_rows, m->n_tasks,
+                                  m->n_classes, B, io->d_fingerprint, 2 * D, d_params + m->off_head_w,
+                                  d_grads + m->off_head_w, d_grads + m->off_head_b, ws + w.dfp, 2 * D,
+                                  reinterpret_cast<double*>(ws + w.lacc), g->d_mol_runs, g->max_deg + 1,
+                                  reinterpret_cast<const int32_t*>(ws + w.arg_r), ws + w.rsum, bnvL, bnvL + D,
+                                  (dense_fused_next && g->d_mol_runs) ? reinterpret_cast<double*>(ws + w.acc) : nullptr, D,
+                                  st);
+    if (rc == GCMI_OK) {
+      head_done = true;
+      head_sums = dense_fused_next && g->d_mol_runs != nullptr;
+      RUN(loss_finalize_impl(reinterpret_cast<double*>(ws + w.lacc), 1.f / (float)(n_rows * m->n_tasks), io->d_loss,
+                             stream));
+    } else if (rc != GCMI_ERR_UNSUPPORTED) {
+      return rc;
+    }
+  }
+  if (!head_done) {
+    // ---- loss on the first n_rows molecules
+    RUN(loss_impl(m->mode == 0 ? 0 : 1, io->d_logits, d_labels, d_weights, n_rows, m->n_tasks,
+                  m->n_classes, io->d_loss, ws + w.dlogits, nullptr,
+                  reinterpret_cast<double*>(ws + w.lacc), true, stream));
+    // ---- head
+    RUN(gcmi_seg_gemm_wgrad(1, &zero32, &nB, io->d_fingerprint, 2 * D, 2 * D, ws + w.dlogits, TC, TC,
+                            d_grads + m->off_head_w, &zero64, d_grads + m->off_head_b, &zero64, 1, stream));
+    RUN(gcmi_seg_gemm(1, &zero32, &nB, ws + w.dlogits, TC, TC, d_params + m->off_head_w, &zero64, nullptr, 0,
+                      0, nullptr, nullptr, nullptr, nullptr, 2 * D, 0, 0, ws + w.dfp, 2 * D, stream));
+  }
   if (N == 0) return GCMI_OK;
   // ---- readout (+ folded BatchNorm of the dense layer, + its ReLU mask)
   float* dyD = ws + w.tA;   // grad w.r.t. the (normalised) readout input
@@ -337,14 +363,20 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
   if (m->batch_norm) {
     // GraphGather backward is recomputed inside the BatchNorm backward from the per-molecule
     // gradient (tanh derivative applied in place): the N x D gradient is never written or re-read
-    RUN(readout_grad_prep(ws + w.dfp, 2 * D, io->d_fingerprint, 2 * D, B, D, st));
+    if (!head_done) RUN(readout_grad_prep(ws + w.dfp, 2 * D, io->d_fingerprint, 2 * D, B, D, st));
     const float* bnv = ws + w.bnv[L];
     const bool try_fused = fused_bwd_enabled() && D == 128 && Wl > 32 && Wl <= 64;
-    RUN(bn_bwd_readout_impl(g->d_membership, ws + w.dfp, 2 * D, reinterpret_cast<const int32_t*>(ws + w.arg_r),
-                            ws + w.dense, D, N, D, d_params + m->off_bn_gamma[L], bnv, bnv + D,
-                            d_grads + m->off_bn_gamma[L], d_grads + m->off_bn_beta[L], try_fused ? nullptr : dxD, D, 1,
-                            reinterpret_cast<double*>(ws + w.acc), true, stream, ws + w.rsum, g->d_mol_runs,
-                            g->n_mols, g->max_deg + 1));
+    if (head_sums && try_fused) {
+      // the sums are in place (head_bwd.hip): dgamma, dbeta and the coefficient vectors
+      RUN(bn_bwd_params_impl(N, D, d_params + m->off_bn_gamma[L], bnv, bnv + D, d_grads + m->off_bn_gamma[L],
+                             d_grads + m->off_bn_beta[L], reinterpret_cast<double*>(ws + w.acc), stream));
+    } else {
+      RUN(bn_bwd_readout_impl(g->d_membership, ws + w.dfp, 2 * D, reinterpret_cast<const int32_t*>(ws + w.arg_r),
+                              ws + w.dense, D, N, D, d_params + m->off_bn_gamma[L], bnv, bnv + D,
+                              d_grads + m->off_bn_gamma[L], d_grads + m->off_bn_beta[L], try_fused ? nullptr : dxD, D, 1,
+                              reinterpret_cast<double*>(ws + w.acc), true, stream, ws + w.rsum, g->d_mol_runs,
+                              g->n_mols, g->max_deg + 1));
+    }
     if (try_fused) {
       // one pass: dxD formed per 64-row tile in LDS, dW_dense += dxD^T pool, db += colsum, dpool = dxD W_dense
       TimedScope ts(GCMI_K_FUSED_BWD, st);
