@@ -559,10 +559,24 @@ __global__ void bn_bwd_params_pool_kernel(double* __restrict__ psums, double* __
                                           float* __restrict__ coef) {
   const bool direct = bn_pool_ill_conditioned(gamma, beta, n_feat);
   const double inv_n = 1.0 / (double)n_rows;
-  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_feat; c += gridDim.x * blockDim.x) {
-    double p1, p2, d1, d2;
-    take_sums(psums, n_feat, c, p1, p2);
-    take_sums(sums, n_feat, c, d1, d2);
+  // 32 lanes per column, one accumulator replica each (kReplicas == 32), combined by shuffles: a serial walk over the
+  // replicas of both accumulators is 128 dependent loads per column
+  const int c = blockIdx.x * (blockDim.x / kReplicas) + threadIdx.x / kReplicas;
+  const int r = threadIdx.x % kReplicas;
+  const bool ok = c < n_feat;
+  double p1 = 0.0, p2 = 0.0, d1 = 0.0, d2 = 0.0;
+  if (ok) {
+    double* rp = psums + (size_t)2 * n_feat * (1 + r);
+    double* rd = sums + (size_t)2 * n_feat * (1 + r);
+    p1 = rp[c]; p2 = rp[n_feat + c]; d1 = rd[c]; d2 = rd[n_feat + c];
+    rp[c] = 0.0; rp[n_feat + c] = 0.0; rd[c] = 0.0; rd[n_feat + c] = 0.0;
+  }
+#pragma unroll
+  for (int o = kReplicas / 2; o > 0; o >>= 1) {
+    p1 += __shfl_xor(p1, o, kReplicas); p2 += __shfl_xor(p2, o, kReplicas);
+    d1 += __shfl_xor(d1, o, kReplicas); d2 += __shfl_xor(d2, o, kReplicas);
+  }
+  if (ok && r == 0) {
     const double gm = (double)(gamma ? gamma[c] : 1.f), bt = (double)(beta ? beta[c] : 0.f);
     const double db = direct ? d1 : p1;
     const double dg = direct ? d2 : (p2 - bt * p1) / gm;
@@ -590,7 +604,8 @@ int bn_bwd_pool_impl(const float* d_dy, int64_t lddy, const float* d_x, int64_t 
                                    d_gamma, d_beta);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(bn_bwd_params_pool_kernel, dim3(1), dim3(256), 0, st, d_psums, d_acc, n_rows, n_feat, d_gamma,
+  static_assert(kReplicas == 32, "bn_bwd_params_pool_kernel: one lane per replica");
+  hipLaunchKernelGGL(bn_bwd_params_pool_kernel, dim3((n_feat + 7) / 8), dim3(256), 0, st, d_psums, d_acc, n_rows, n_feat, d_gamma,
                      d_beta, d_mean, d_invstd, d_dgamma, d_dbeta, reinterpret_cast<float*>(d_acc));
   GCMI_CHECK_LAUNCH("bn_bwd_params_pool");
   return GCMI_OK;
