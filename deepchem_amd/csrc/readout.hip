@@ -59,31 +59,9 @@ readout_fwd_kernel(int n_mols, int n_deg, const int32_t* __restrict__ runs,
   const int grp = threadIdx.x / gl;
   const int lane = threadIdx.x - grp * gl;
   if (grp >= mpb) return;
-  // persistent: a lane group walks molecules b, b + stride, ...; the run bounds of its NEXT molecule are requested
-  // before the current one is walked (they head the chain bounds -> rows -> bounds of every molecule)
-  const int stride = gridDim.x * mpb;
-  int rbn[2 * (GCMI_MAX_DEG + 1)];
-  {
-    const int b0 = blockIdx.x * mpb + grp;
-    if (b0 >= n_mols) return;
-#pragma unroll
-    for (int d = 0; d <= GCMI_MAX_DEG; ++d) {
-      rbn[2 * d] = d < n_deg ? runs[((int64_t)b0 * n_deg + d) * 2] : 0;
-      rbn[2 * d + 1] = d < n_deg ? runs[((int64_t)b0 * n_deg + d) * 2 + 1] : 0;
-    }
-  }
-  for (int b = blockIdx.x * mpb + grp; b < n_mols; b += stride) {
-  int rb[2 * (GCMI_MAX_DEG + 1)];
-#pragma unroll
-  for (int d = 0; d < 2 * (GCMI_MAX_DEG + 1); ++d) rb[d] = rbn[d];
-  {
-    const int bn_ = b + stride < n_mols ? b + stride : b;
-#pragma unroll
-    for (int d = 0; d <= GCMI_MAX_DEG; ++d) {
-      rbn[2 * d] = d < n_deg ? runs[((int64_t)bn_ * n_deg + d) * 2] : 0;
-      rbn[2 * d + 1] = d < n_deg ? runs[((int64_t)bn_ * n_deg + d) * 2 + 1] : 0;
-    }
-  }
+  const int b = blockIdx.x * mpb + grp;
+  if (b >= n_mols) return;
+  const int32_t* rb = runs + (int64_t)b * n_deg * 2;
   for (int cc = lane; cc < lpr; cc += gl) {
     const int c = cc * V;
     float sc[V], sh[V], sum[V], mx[V], raw[V], rawmx[V];
@@ -98,8 +76,7 @@ readout_fwd_kernel(int n_mols, int n_deg, const int32_t* __restrict__ runs,
       mx[q] = -INFINITY;
       am[q] = -1;
     }
-#pragma unroll
-    for (int d = 0; d <= GCMI_MAX_DEG; ++d) {
+    for (int d = 0; d < n_deg; ++d) {
       const int r0 = rb[2 * d], r1 = rb[2 * d + 1];
       // four rows of the run per round, loads issued together, consumed in row order
       for (int rr = r0; rr < r1; rr += 4) {
@@ -160,7 +137,6 @@ readout_fwd_kernel(int n_mols, int n_deg, const int32_t* __restrict__ runs,
         rawsum[(int64_t)b * 2 * n_feat + n_feat + c + q] = rawmx[q];
       }
     }
-  }
   }
 }
 
@@ -299,7 +275,7 @@ int readout_fwd_impl(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t
   const int lpr = n_feat / V;
   const int gl = lpr < kRBlock ? lpr : kRBlock;
   const int mpb = kRBlock / gl;
-  const int blocks = std::min((g->n_mols + mpb - 1) / mpb, 256 * 8);  // persistent lane groups
+  const int blocks = (g->n_mols + mpb - 1) / mpb;
   const bool bn = d_scale != nullptr;
   const int n_deg = g->max_deg + 1;
   const int vec_out = (n_feat % 4 == 0 && ldo % 4 == 0 && aligned16(d_out) && (d_arg == nullptr || aligned16(d_arg)) &&
