@@ -9,7 +9,8 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
 
 
-def _step(packed, y, w, tasks, grad_mode, fused, batch_norm=True, state=None, widths=(64, 64), dense=128, tweak=None):
+def _step(packed, y, w, tasks, grad_mode, fused, batch_norm=True, state=None, widths=(64, 64), dense=128, tweak=None,
+          mode="classification"):
     """forward + loss + backward of the whole-model entry points on one collated batch; returns the loss, the
     gradient arena and the parameter names with their slices."""
     import deepchem_amd as dc
@@ -18,12 +19,15 @@ def _step(packed, y, w, tasks, grad_mode, fused, batch_norm=True, state=None, wi
     from deepchem_amd.metrics import to_one_hot
     n = packed.n_mols
     dbatch = collate_to_device(packed, None, DEV)
-    labels = torch.as_tensor(to_one_hot(y.flatten(), 2).reshape(-1, tasks, 2).astype(np.float32), device=DEV)
+    if mode == "classification":
+        labels = torch.as_tensor(to_one_hot(y.flatten(), 2).reshape(-1, tasks, 2).astype(np.float32), device=DEV)
+    else:
+        labels = torch.as_tensor(np.asarray(y, np.float32).reshape(-1, tasks), device=DEV)
     weights = torch.as_tensor(w.astype(np.float32), device=DEV)
     torch.manual_seed(11)
     model = dc.models.torch_models.GraphConvModel(tasks, graph_conv_layers=list(widths), dense_layer_size=dense,
                                                   number_input_features=[75] + list(widths[:-1]), batch_size=n,
-                                                  mode="classification", grad_mode=grad_mode, batch_normalize=batch_norm,
+                                                  mode=mode, grad_mode=grad_mode, batch_normalize=batch_norm,
                                                   device=DEV)
     if state is not None:
         model.model.load_state_dict({k: v.clone() for k, v in state.items()})
@@ -164,5 +168,18 @@ def test_pooled_batchnorm_sums_fall_back_when_ill_conditioned(grad_mode):
 
     l1, g1, sl, r1, _ = _step(packed, y, w, 2, grad_mode, True, tweak=tweak)
     l0, g0, _, r0, _ = _step(packed, y, w, 2, grad_mode, False, tweak=tweak)
+    assert r0 == r1 and abs(l1 - l0) <= 1e-6 * max(abs(l0), 1.0)
+    _compare(g1, g0, sl, r1, 2e-5)
+
+
+def test_fused_backward_regression_head():
+    """L2Loss through the per-molecule kernel (head_bwd.hip, kind 1): loss and every gradient against the separate
+    launches, with per-molecule weights and a padded tail (n_rows < batch is covered by the fit tests)."""
+    from deepchem_amd.utils.synthetic import synthetic_labels, synthetic_molecules
+    n, tasks = 500, 3
+    packed = synthetic_molecules(n, seed=31, max_atoms=30)
+    y, w = synthetic_labels(n, tasks, "regression", 31)
+    l1, g1, sl, r1, _ = _step(packed, y, w, tasks, "full", True, mode="regression")
+    l0, g0, _, r0, _ = _step(packed, y, w, tasks, "full", False, mode="regression")
     assert r0 == r1 and abs(l1 - l0) <= 1e-6 * max(abs(l0), 1.0)
     _compare(g1, g0, sl, r1, 2e-5)
