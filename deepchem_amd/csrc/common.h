@@ -73,6 +73,10 @@ int win_gather_max(const gcmi_graph* g, const float* d_x, int64_t ldx, int n_fea
                    const float* d_shift, float* d_out, int64_t ldo, uint8_t* d_arg, hipStream_t st);
 int win_gather_max_bwd(const gcmi_graph* g, const float* d_dout, int64_t lddo, int n_feat,
                        const uint8_t* d_arg, float* d_dx, int64_t lddx, hipStream_t st);
+// SumOp<true> followed by the GraphPool backward of the block below in one window pass, dX in LDS only
+bool win_two_stage_usable(const gcmi_graph* g, int n_feat);
+int win_gather_sumacc_max_bwd(const gcmi_graph* g, const float* d_ds, int64_t ldds, int n_feat, float* d_dxs,
+                              int64_t lddxs, const uint8_t* d_arg, float* d_dy, int64_t lddy, hipStream_t st);
 // the same, also adding the column sums of the BatchNorm backward (sum dx, sum dx*xhat; bn.hip scratch layout)
 bool win_stats_usable(const gcmi_graph* g, int n_feat);
 int win_gather_max_bwd_stats(const gcmi_graph* g, const float* d_dout, int64_t lddo, int n_feat, const uint8_t* d_arg,

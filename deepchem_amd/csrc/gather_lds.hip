@@ -146,6 +146,7 @@ struct SumOp {
   float* __restrict__ s;
   int64_t lds;
   using State = NoState;
+  static constexpr bool kExtraTile = false;
   __device__ __forceinline__ bool skip(int) const { return false; }
   template <int WT>
   __device__ __forceinline__ void init(float*, int, State&) const {}
@@ -197,6 +198,7 @@ struct MaxOp {
   float* __restrict__ out;
   int64_t ldo;
   uint8_t* __restrict__ arg;
+  static constexpr bool kExtraTile = false;
   // the folded BatchNorm vectors live in LDS: a global load in the compute phase would make the
   // compiler wait for the LDS-DMA in flight as well
   using State = NoState;
@@ -271,6 +273,7 @@ struct MaxBwdOp {
   // optional (bn_bwd_pool_impl): dx is needed only where the pooled BatchNorm sums are ill-conditioned
   const float* __restrict__ only_if_gamma;
   const float* __restrict__ only_if_beta;
+  static constexpr bool kExtraTile = false;
   __device__ __forceinline__ bool skip(int n_feat) const {
     return only_if_gamma != nullptr && !bn_pool_ill_conditioned(only_if_gamma, only_if_beta, n_feat);
   }
@@ -371,6 +374,92 @@ struct MaxBwdOp {
   }
 };
 
+// The backward between two GraphConv blocks in one window pass:
+//   dX[k]  = dXs[k] + sum_j dS[i_j]                 (SumOp<true>: the neighbour part onto the self part)
+//   dy[k]  = dX[k]*[arg[k]==0] + sum_j dX[i_j]*[arg[i_j] == rev_pos(k,j)+1]       (MaxBwdOp of the block below)
+// dX is the gradient of the pooled rows and nothing else reads it, so it lives in a third LDS tile only: it is neither
+// written (N*F floats) nor read back (N*F) through HBM.  tile = dS rows, aux = arg rows of the block below.  The price
+// is LDS: one workgroup per CU instead of two.  Oversized windows are not handled (the launcher refuses).
+struct SumAccMaxBwdOp {
+  const float* __restrict__ dxs;  // self part of dX (global rows)
+  int64_t lddxs;
+  float* __restrict__ dy;
+  int64_t lddy;
+  struct State {
+    char* extra;  // the third tile: [slot][LPR] float4
+  };
+  static constexpr bool kExtraTile = true;
+  __device__ __forceinline__ bool skip(int) const { return false; }
+  template <int WT>
+  __device__ __forceinline__ void init(float*, int, State&) const {}
+  template <int WT>
+  __device__ __forceinline__ void finish(char*, int, State&) const {}
+  template <int WT, int LPR>
+  __device__ __forceinline__ void run(const char* buf, const Layout& L, const WinMeta& m, const float*, State& st) const {
+    const float4* tile = reinterpret_cast<const float4*>(buf);
+    const uchar4* atile = reinterpret_cast<const uchar4*>(buf + L.tile_bytes);
+    const uint16_t* ent = reinterpret_cast<const uint16_t*>(buf + L.tile_bytes + L.aux_bytes);
+    float4* t2 = reinterpret_cast<float4*>(st.extra);
+    const int n16 = m.sb[kND] * LPR;
+    // ---- stage 1: dX of the window -> the third tile
+    for (int e0 = threadIdx.x; e0 < n16; e0 += kPre * WT) {
+      float4 old[kPre];
+#pragma unroll
+      for (int k = 0; k < kPre; ++k) {
+        const int e = e0 + k * WT < n16 ? e0 + k * WT : n16 - 1;
+        const int slot = e / LPR;
+        const int c = e - slot * LPR;
+        old[k] = *reinterpret_cast<const float4*>(dxs + (int64_t)row_of_slot(m, L.maxd, slot) * lddxs + c * 4);
+      }
+#pragma unroll
+      for (int k = 0; k < kPre; ++k) {
+        const int e = e0 + k * WT;
+        if (e >= n16) break;
+        const int slot = e / LPR;
+        const int c = e - slot * LPR;
+        int d, row, eloc;
+        locate(m, L.maxd, slot, d, row, eloc);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < d; ++j) {
+          const int sl = ent[eloc + j] & GCMI_WIN_MAX_SLOTS;
+          const float4 v = tile[sl * LPR + c];
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        acc.x += old[k].x; acc.y += old[k].y; acc.z += old[k].z; acc.w += old[k].w;  // same order as SumOp<true>
+        t2[e] = acc;
+      }
+    }
+    __syncthreads();
+    // ---- stage 2: the GraphPool backward over it
+    for (int e = threadIdx.x; e < n16; e += WT) {
+      const int slot = e / LPR;
+      const int c = e - slot * LPR;
+      int d, row, eloc;
+      locate(m, L.maxd, slot, d, row, eloc);
+      float4 g = t2[e];
+      uchar4 a = atile[e];
+      float4 acc;
+      acc.x = a.x == 0 ? g.x : 0.f;
+      acc.y = a.y == 0 ? g.y : 0.f;
+      acc.z = a.z == 0 ? g.z : 0.f;
+      acc.w = a.w == 0 ? g.w : 0.f;
+      for (int j = 0; j < d; ++j) {
+        const int en = ent[eloc + j];
+        const int sl = en & GCMI_WIN_MAX_SLOTS;
+        const unsigned char want = (unsigned char)((en >> GCMI_WIN_SLOT_BITS) + 1);
+        g = t2[sl * LPR + c];
+        a = atile[sl * LPR + c];
+        acc.x += a.x == want ? g.x : 0.f;
+        acc.y += a.y == want ? g.y : 0.f;
+        acc.z += a.z == want ? g.z : 0.f;
+        acc.w += a.w == want ? g.w : 0.f;
+      }
+      *reinterpret_cast<float4*>(dy + (int64_t)row * lddy + c * 4) = acc;
+    }
+    // (the walker's barrier at the top of the next window comes before the third tile is written again)
+  }
+};
+
 // ---------------------------------------------------------------- the persistent window walker
 // Workgroups [0, g_norm) walk the ordinary windows double-buffered; workgroups [g_norm, gridDim)
 // walk the oversized windows (one big molecule each) using both buffers as one.
@@ -387,6 +476,7 @@ win_kernel(const int32_t* __restrict__ meta, const uint16_t* __restrict__ edges,
   char* smem = smem_all + kHeadBytes;
   if (op.skip(LPR * 4)) return;  // uniform over the grid
   typename Op::State ost;
+  if constexpr (Op::kExtraTile) ost.extra = smem + 2 * L.buf_bytes();  // behind the two window buffers
   op.template init<WT>(op_lds, LPR * 4, ost);
   const int t = threadIdx.x;
   if ((int)blockIdx.x >= g_norm) {  // oversized windows: stage, wait, compute
@@ -493,7 +583,8 @@ bool win_usable(const gcmi_graph* g, int n_feat, bool aux) {
 
 template <int WT, int LPR, bool AUX, class Op>
 static int launch_wt(const gcmi_graph* g, const WinPlan& p, const float* x, int64_t ldx, const uint8_t* aux,
-                     const Op& op, hipStream_t st, const char* what) {
+                     const Op& op, hipStream_t st, const char* what, int which = 0) {  // which: 0 all windows,
+                                                                                        // 1 ordinary, 2 oversized only
   auto kern = win_kernel<WT, LPR, AUX, Op>;
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
@@ -506,13 +597,22 @@ static int launch_wt(const gcmi_graph* g, const WinPlan& p, const float* x, int6
     attr_done = true;
   }
   const int n_norm = g->n_win - g->n_win_big;
-  const int by_lds = (int)((size_t)kLdsPerCU / p.shmem);
+  size_t shmem = p.shmem;
+  if constexpr (Op::kExtraTile) {
+    if (which != 1) {
+      set_error("%s: oversized windows are not handled by the two-stage form", what);
+      return GCMI_ERR_UNSUPPORTED;
+    }
+    shmem += (size_t)p.L.tile_bytes;
+    if (shmem > (size_t)kLdsPerCU) return GCMI_ERR_UNSUPPORTED;
+  }
+  const int by_lds = (int)((size_t)kLdsPerCU / shmem);
   const int by_threads = 2048 / WT;
   const int per_cu = std::max(1, std::min(env_int("GCMI_WIN_PER_CU", 8), std::min(by_lds, by_threads)));
-  const int g_norm = std::min(n_norm, 256 * per_cu);
-  const int g_big = std::min(g->n_win_big, 64);
+  const int g_norm = which == 2 ? 0 : std::min(n_norm, 256 * per_cu);
+  const int g_big = which == 1 ? 0 : std::min(g->n_win_big, 64);
   if (g_norm + g_big == 0) return GCMI_OK;
-  hipLaunchKernelGGL(kern, dim3(g_norm + g_big), dim3(WT), p.shmem, st, g->d_win_meta, g->d_win_edges, n_norm,
+  hipLaunchKernelGGL(kern, dim3(g_norm + g_big), dim3(WT), shmem, st, g->d_win_meta, g->d_win_edges, n_norm,
                      g->n_win, g_norm, p.L, p.Lbig, x, ldx, aux, op, next_sweep_direction_windows());
   GCMI_CHECK_LAUNCH(what);
   return GCMI_OK;
@@ -520,20 +620,25 @@ static int launch_wt(const gcmi_graph* g, const WinPlan& p, const float* x, int6
 
 template <int LPR, bool AUX, class Op>
 static int launch_lpr(const gcmi_graph* g, const WinPlan& p, const float* x, int64_t ldx, const uint8_t* aux,
-                      const Op& op, hipStream_t st, const char* what) {
+                      const Op& op, hipStream_t st, const char* what, int which) {
   static const int wt = env_int("GCMI_WIN_THREADS", 512);
-  if (wt == 256) return launch_wt<256, LPR, AUX, Op>(g, p, x, ldx, aux, op, st, what);
-  return launch_wt<512, LPR, AUX, Op>(g, p, x, ldx, aux, op, st, what);
+  if constexpr (Op::kExtraTile) {  // one workgroup per CU by LDS: make it a full one
+    static const int wt2 = env_int("GCMI_WIN_THREADS_TWO_STAGE", 1024);
+    if (wt2 == 1024) return launch_wt<1024, LPR, AUX, Op>(g, p, x, ldx, aux, op, st, what, which);
+  }
+  if (wt == 1024) return launch_wt<1024, LPR, AUX, Op>(g, p, x, ldx, aux, op, st, what, which);
+  if (wt == 256) return launch_wt<256, LPR, AUX, Op>(g, p, x, ldx, aux, op, st, what, which);
+  return launch_wt<512, LPR, AUX, Op>(g, p, x, ldx, aux, op, st, what, which);
 }
 
 template <bool AUX, class Op>
 static int launch(const gcmi_graph* g, int n_feat, const float* x, int64_t ldx, const uint8_t* aux,
-                  const Op& op, hipStream_t st, const char* what) {
+                  const Op& op, hipStream_t st, const char* what, int which = 0) {
   const WinPlan p = make_plan(g, n_feat, AUX);
   switch (n_feat / 4) {
-    case 16: return launch_lpr<16, AUX, Op>(g, p, x, ldx, aux, op, st, what);
-    case 19: return launch_lpr<19, AUX, Op>(g, p, x, ldx, aux, op, st, what);
-    case 32: return launch_lpr<32, AUX, Op>(g, p, x, ldx, aux, op, st, what);
+    case 16: return launch_lpr<16, AUX, Op>(g, p, x, ldx, aux, op, st, what, which);
+    case 19: return launch_lpr<19, AUX, Op>(g, p, x, ldx, aux, op, st, what, which);
+    case 32: return launch_lpr<32, AUX, Op>(g, p, x, ldx, aux, op, st, what, which);
     default: break;
   }
   set_error("%s: no window kernel for %d features", what, n_feat);
@@ -572,6 +677,29 @@ int win_gather_max_bwd_if_ill(const gcmi_graph* g, const float* d_dout, int64_t 
                               float* d_dx, int64_t lddx, const float* d_gamma, const float* d_beta, hipStream_t st) {
   MaxBwdOp<false> op{d_dx, lddx, nullptr, 0, nullptr, nullptr, nullptr, d_gamma, d_beta};
   return launch<true>(g, n_feat, d_dout, lddo, d_arg, op, st, "win_gather_max_bwd (conditional)");
+}
+
+// dy = GraphPool backward of (dXs + gather of dS), dX kept in LDS only.  GCMI_ERR_UNSUPPORTED: oversized windows in
+// the batch, or no LDS for the third tile.
+bool win_two_stage_usable(const gcmi_graph* g, int n_feat) {
+  if (!win_has_width(n_feat) || !win_usable(g, n_feat, true)) return false;
+  const WinPlan p = make_plan(g, n_feat, true);
+  return p.shmem + (size_t)p.L.tile_bytes <= (size_t)kLdsPerCU;
+}
+
+// d_dxs holds the self part of dX on entry; on return d_dy holds the GraphPool backward of the complete dX.  The
+// ordinary windows take the two-stage pass (dX in LDS only); the few oversized ones (a molecule above the window cap
+// each) take the two separate passes over their own rows, which completes d_dxs there.
+int win_gather_sumacc_max_bwd(const gcmi_graph* g, const float* d_ds, int64_t ldds, int n_feat, float* d_dxs,
+                              int64_t lddxs, const uint8_t* d_arg, float* d_dy, int64_t lddy, hipStream_t st) {
+  SumAccMaxBwdOp op{d_dxs, lddxs, d_dy, lddy};
+  int rc = launch<true>(g, n_feat, d_ds, ldds, d_arg, op, st, "win_gather_sumacc_max_bwd", 1);
+  if (rc || g->n_win_big == 0) return rc;
+  SumOp<true> acc{d_dxs, lddxs};
+  rc = launch<false>(g, n_feat, d_ds, ldds, nullptr, acc, st, "win_gather_sum (accumulate, oversized windows)", 2);
+  if (rc) return rc;
+  MaxBwdOp<false> mb{d_dy, lddy, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
+  return launch<true>(g, n_feat, d_dxs, lddxs, d_arg, mb, st, "win_gather_max_bwd (oversized windows)", 2);
 }
 
 // threads per workgroup of the window kernels must be a multiple of the row's 16-byte pieces for the statistics form

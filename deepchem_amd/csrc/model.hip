@@ -360,6 +360,8 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
   bool dense_done = false;
   bool have_psums = false;  // acc2 holds sum dP, sum dP * P for the BatchNorm below the block just processed
   static const bool psums_env = !(getenv("GCMI_FUSED_PSUMS") && atoi(getenv("GCMI_FUSED_PSUMS")) == 0);
+  static const bool two_stage_env = !(getenv("GCMI_TWO_STAGE_GATHER") && atoi(getenv("GCMI_TWO_STAGE_GATHER")) == 0);
+  bool dy_ready = false;  // the gather of the block above already left this block's dy (two-stage window pass)
   if (m->batch_norm) {
     // GraphGather backward is recomputed inside the BatchNorm backward from the per-molecule
     // gradient (tanh derivative applied in place): the N x D gradient is never written or re-read
@@ -439,7 +441,9 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
       // bn_bwd_pool_impl).  dy itself is needed when the GraphConv below trains; otherwise only by the
       // ill-conditioned fallback, and the kernel returns at once unless that applies.
       const float* bnv = ws + w.bnv[l];
-      if (full) {
+      if (dy_ready) {
+        // (left by win_gather_sumacc_max_bwd below, one iteration ago)
+      } else if (full) {
         RUN(gcmi_gather_max_bwd(g, dpool, W, W, reinterpret_cast<const uint8_t*>(ws + w.arg[l]), dy, W, stream));
       } else {
         TimedScope ts(GCMI_K_GATHER_MAX_BWD, st);
@@ -449,7 +453,7 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
       RUN(bn_bwd_pool_impl(dy, W, ws + w.gc[l], W, N, W, d_params + m->off_bn_gamma[l], d_params + m->off_bn_beta[l], bnv,
                            bnv + W, d_grads + m->off_bn_gamma[l], d_grads + m->off_bn_beta[l],
                            reinterpret_cast<double*>(ws + w.acc2), reinterpret_cast<double*>(ws + w.acc), stream));
-    } else if (stats_in_gather) {
+    } else if (stats_in_gather && !dy_ready) {
       const float* bnv = ws + w.bnv[l];
       {
         TimedScope ts(GCMI_K_GATHER_MAX_BWD, st);
@@ -459,7 +463,8 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
       RUN(bn_bwd_params_impl(N, W, d_params + m->off_bn_gamma[l], bnv, bnv + W, d_grads + m->off_bn_gamma[l],
                              d_grads + m->off_bn_beta[l], reinterpret_cast<double*>(ws + w.acc), stream));
     } else {
-      RUN(gcmi_gather_max_bwd(g, dpool, W, W, reinterpret_cast<const uint8_t*>(ws + w.arg[l]), dy, W, stream));
+      if (!dy_ready)
+        RUN(gcmi_gather_max_bwd(g, dpool, W, W, reinterpret_cast<const uint8_t*>(ws + w.arg[l]), dy, W, stream));
       if (m->batch_norm) {
         const float* bnv = ws + w.bnv[l];
         RUN(bn_bwd_impl(dy, W, ws + w.gc[l], W, N, W, d_params + m->off_bn_gamma[l], bnv, bnv + W,
@@ -470,6 +475,7 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
         dgc = dy;
       }
     }
+    dy_ready = false;
     if (!full) break;  // reference semantics: nothing in front of a GraphConv output trains
     bool fused_done = false;
     if (try_fused) {
@@ -511,7 +517,16 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
     if (fused_done) {
       // dX holds the self part: the neighbour part is added onto it (bonds listed from both ends: the scatter
       // of dS is a gather)
-      if (sym) RUN(gcmi_gather_sum_fwd(g, dS, K, K, dX, K, 1, stream));
+      // ... and when the window kernels can hold a third tile, the GraphPool backward of the block below in the
+      // same pass: dX = dXs + gather(dS) is consumed in LDS and never exists in HBM
+      const bool two_stage = sym && two_stage_env && fused_bwd_enabled() && win_two_stage_usable(g, K) &&
+                             aligned16(dS) && aligned16(dX) && aligned16(ws + w.tD);
+      if (two_stage) {
+        TimedScope ts(GCMI_K_GATHER_MAX_BWD, st);
+        RUN(win_gather_sumacc_max_bwd(g, dS, K, K, dX, K, reinterpret_cast<const uint8_t*>(ws + w.arg[l - 1]),
+                                      ws + w.tD, K, st));
+        dy_ready = true;
+      } else if (sym) RUN(gcmi_gather_sum_fwd(g, dS, K, K, dX, K, 1, stream));
       else RUN(gcmi_scatter_add(g, dS, K, K, dX, K, stream));
     } else {
       RUN(gcmi_seg_gemm(sg.n, sg.begin, sg.end, dgc, W, W, d_params + m->off_conv_w[l], sg.w_rel, nullptr, 0,

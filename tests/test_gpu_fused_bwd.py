@@ -85,10 +85,14 @@ def test_fused_backward_equals_separate_kernels(grad_mode, n_mols):
     """Both paths split every operand into the same three bf16 pieces and accumulate in fp32; they differ in the
     order rows are added up (64-row tiles walked by persistent workgroups vs row slabs), so gradients agree to
     ~1e-5 of each tensor's scale.  37 molecules: every segment is a ragged tile; 1 500: workgroups cross segment
-    boundaries, degrees 0 (single atoms) to 6 and 10 are present."""
+    boundaries, degrees 0 (single atoms) to 6 and 10 are present, and six molecules of 100-132 atoms get windows of
+    their own (the two-stage gather hands those to the separate passes)."""
     from deepchem_amd.utils.synthetic import (concat_packed, single_atom_and_edge_cases, synthetic_labels,
                                               synthetic_molecules)
-    packed = concat_packed([synthetic_molecules(n_mols, seed=5, max_atoms=40), single_atom_and_edge_cases(75, seed=2)])
+    parts = [synthetic_molecules(n_mols, seed=5, max_atoms=40), single_atom_and_edge_cases(75, seed=2)]
+    if n_mols > 100:  # molecules above the window cap of 96 atoms: oversized windows beside the ordinary ones
+        parts.append(synthetic_molecules(6, seed=3, mean_atoms=118, max_atoms=132, min_atoms=100))
+    packed = concat_packed(parts)
     tasks = 3
     y, w = synthetic_labels(packed.n_mols, tasks, "classification", 5, pos_rate=0.4)
     l1, g1, sl, r1, m1 = _step(packed, y, w, tasks, grad_mode, True)
