@@ -90,7 +90,7 @@ def measured_traffic():
             continue
         tot, n = 0, 0
         for name, rec in kernels.items():
-            if "SumOp" in name and "hbm_bytes_per_launch" in rec:
+            if "SumOp<false>" in name and "hbm_bytes_per_launch" in rec:  # the forward gather-sum launches
                 k = rec.get("fetch_launches", 1)
                 tot += rec["hbm_bytes_per_launch"] * k
                 n += k
@@ -382,13 +382,13 @@ def main():
 
     g = dbatch.graph
     n0 = g.deg_counts[0]
-    # gather-sum launches of one step: forward layer 0 (F=75), forward layer 1 (F=64) and, in
-    # "full" mode, the backward of layer 1 as a gather of dS accumulated onto the self term the one-pass
-    # block kernel left in dX (F=64, read-modify-write of the destination)
+    # gather-sum launches of one step: forward layer 0 (F=75) and forward layer 1 (F=64).  (The backward's gather of dS
+    # is part of the two-stage window pass with the GraphPool backward below it, timed with that family; when that
+    # pass is switched off it is a third, accumulating launch here.)
     per_step = gather_sum_bytes(g.n_atoms, g.n_edges, n0, 75, False) + \
         gather_sum_bytes(g.n_atoms, g.n_edges, n0, 64, False)
     launches_per_step = 2
-    if args.grad_mode == "full":
+    if args.grad_mode == "full" and gather_time[0] >= 3 * args.steps:
         per_step += gather_sum_bytes(g.n_atoms, g.n_edges, n0, 64, True)
         launches_per_step = 3
     n_launch, ms = gather_time
@@ -420,8 +420,8 @@ def main():
             "parallelism": "dp%d (molecules sharded by rank, one flat all-reduce per step)" % world,
         },
         "roofline": {
-            "kernel": "win_kernel<512, {16|19}, false, SumOp<false|true>> (gather_lds.hip: GraphConv.sum_neigh over LDS "
-                      "molecule windows, forward of both layers and, accumulating, the backward of layer 1)",
+            "kernel": "win_kernel<512, {16|19}, false, SumOp<false>> (gather_lds.hip: GraphConv.sum_neigh over LDS "
+                      "molecule windows, forward of both layers)",
             "bound": "hbm",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
@@ -451,8 +451,11 @@ def main():
     fam_bytes = {
         "gather_sum": per_step,
         "gather_max": 2 * (E * (4 * 64 + 4) + 2 * N * 4 * 64 + N * 64),
-        "gather_max_bwd": 2 * (E * (5 * 64 + 5) + 2 * N * 4 * 64 + N * 64) if args.grad_mode == "full" else
-        (E * (5 * 64 + 5) + 2 * N * 4 * 64 + N * 64),
+        # GraphPool backward of the last block; in "full" mode also the two-stage pass (gather of dS onto the self
+        # part + the GraphPool backward of block 0; its dX never leaves LDS: minus one write and one read of N x 64)
+        "gather_max_bwd": (E * (5 * 64 + 5) + 2 * N * 4 * 64 + N * 64) +
+        ((E * (5 * 64 + 5) + 2 * N * 4 * 64 + N * 64) + gather_sum_bytes(N, E, n0, 64, True) - 2 * N * 4 * 64
+         if args.grad_mode == "full" else 0),
         "readout": N * (4 * 128 + 4) + B * 8 * 128,
         # forward: GraphConv 0/1, dense, head; backward: head (the blocks' backward products: fused_bwd)
         "seg_gemm": 4 * (N * (75 + 75 + 64) + N * (64 + 64 + 64) + N * (64 + 128) + B * (256 + 24) + B * (24 + 256)),
