@@ -280,6 +280,284 @@ fwd_fused_kernel(FwdTable st, int n_tiles, FwdArgs a, int rev) {
   }
 }
 
+// ---------------------------------------------------------------- weights in registers, two workgroups per CU
+// The first GraphConv (two 76-column operands) does not fit the scheme above: its operand tile and weight images need
+// more LDS than a CU has at 128 rows.  Here the weight images are not in LDS at all: a workgroup is four waves on a
+// 64-row tile, a wave owns a 32 x 32 output tile over the whole contraction and keeps ITS weight fragments -- already
+// split -- in registers (120 VGPRs at K = 160; reloaded from the L2-resident weights when the tile loop crosses into
+// another degree's segment, no barrier for that).  LDS holds operand rows only (42 KB), so two workgroups share a CU
+// and one's loads, stores and barriers overlap the other's products.  The output leaves straight from the
+// accumulators (lane = column: a store instruction writes two whole 128-byte lines), the BatchNorm sums are per-lane
+// scalars.  Same products in the same order as seg_gemm4_kernel / fwd_fused_kernel.
+// Measured (same box): first GraphConv 294 -> 247 us.  For the two shapes fwd_fused_kernel serves, this form (with
+// two operand buffers and one barrier per tile) measured 211 / 226 us against 215 / 216: no better, not instantiated.
+
+// Where the lanes of rows beyond a ragged tile's end store (see products()): a word per thread of the largest grid.
+// (One shared line would do for correctness, and serialises two million same-address stores in one L2 channel.)
+__device__ float g_fwd_dump[512 * 256];
+
+template <int NOPS, int KO, int NOUT, bool TRANS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+fwd_reg_kernel(FwdTable st, int n_tiles, FwdArgs a, int rev) {
+  constexpr int NT = 256, ROWS = 64;
+  constexpr int NC = NOPS * KO;               // contraction length
+  constexpr int AP = NC + 4;                  // pitch of an operand row in LDS (floats)
+  constexpr int NKS = NC / 16;
+  constexpr int TW = NOUT / 32;               // 32-column tiles of the output
+  constexpr int TPW = TW / 2;                 // ... per wave: waves = 2 row blocks x 2 column groups
+  static_assert(TW % 2 == 0 && KO % 8 == 0 && NC % 16 == 0, "tile shapes");
+  constexpr int IQ = KO / 4;                  // 16-byte pieces of an operand row
+  constexpr int IPASS = ROWS * IQ / NT;       // per operand
+  static_assert(ROWS * IQ % NT == 0, "tile loads divide evenly");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  float* As = reinterpret_cast<float*>(lds_raw);  // [ROWS][AP]
+  __shared__ int t_begin_s[kWMaxSeg], t_end_s[kWMaxSeg], t_tile_s[kWMaxSeg + 1];
+  __shared__ long long t_w_s[2][kWMaxSeg], t_b_s[kWMaxSeg];
+  __shared__ double stat_s[2][NOUT];
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int half = lane >> 5;
+  const int l31 = lane & 31;
+  const int rb = wave & 1, twb = wave >> 1;   // rows rb*32.., column tiles twb, twb + 2, ...
+  float* const my_dump = &g_fwd_dump[(blockIdx.x % 512) * 256 + tid];
+
+  if (tid <= kWMaxSeg) {
+    t_tile_s[tid] = pick_n(st.tile_start, tid);
+    if (tid < kWMaxSeg) {
+      t_begin_s[tid] = pick_n(st.seg_begin, tid);
+      t_end_s[tid] = pick_n(st.seg_end, tid);
+      t_w_s[0][tid] = pick_n(st.w_off[0], tid);
+      t_w_s[1][tid] = pick_n(st.w_off[1], tid);
+      t_b_s[tid] = pick_n(st.b_off, tid);
+    }
+  }
+  for (int c = tid; c < 2 * NOUT; c += NT) stat_s[c / NOUT][c % NOUT] = 0.0;
+  const int n_seg = st.n_seg;
+  __syncthreads();
+
+  const int b = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+  // (64-bit division runs on the vector unit: say that the results are uniform)
+  const int t_begin = __builtin_amdgcn_readfirstlane((int)((int64_t)b * n_tiles / gridDim.x));
+  const int t_end = __builtin_amdgcn_readfirstlane((int)((int64_t)(b + 1) * n_tiles / gridDim.x));
+  const int my_tiles = t_end - t_begin;  // >= 1: the grid is never larger than the tile count
+  auto tile_at = [&](int i) { return rev ? t_end - 1 - i : t_begin + i; };
+  auto tile_info = [&](int tile, int& seg, int& row0, int& valid) {
+    int s = 0;
+    for (int k = 1; k < n_seg; ++k) s += tile >= t_tile_s[k] ? 1 : 0;
+    seg = __builtin_amdgcn_readfirstlane(s);  // LDS reads land in vector registers; these are uniform
+    row0 = __builtin_amdgcn_readfirstlane(t_begin_s[seg] + (tile - t_tile_s[seg]) * ROWS);
+    const int left = __builtin_amdgcn_readfirstlane(t_end_s[seg]) - row0;
+    valid = left < ROWS ? left : ROWS;
+  };
+
+  // ---- prefetch registers: the next tile's operand rows, 16 bytes per lane, unconditional from clamped addresses.
+  // Addresses stay (uniform base, 32-bit byte offset) formed at the load: anything the compiler can hoist out of the
+  // tile loop as a 64-bit per-lane value it does, and then spills it.
+  constexpr bool kEven = NT % IQ == 0;        // every pass of a thread has the same 16-byte column
+  constexpr int RSTEP = NT / IQ;
+  float4 pin[NOPS][IPASS];
+  auto slot_rq = [&](int p, int& r, int& q) {
+    if constexpr (kEven) {
+      r = tid / IQ + p * RSTEP;
+      q = tid % IQ;
+    } else {
+      int slot = tid + p * NT;
+      asm volatile("" : "+v"(slot));  // a multiply and a shift at each use, instead of ten hoisted (and spilled) values
+      r = slot / IQ;
+      q = slot - r * IQ;
+    }
+  };
+  auto load_src = [&](int row0, int valid) {
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o) {
+#pragma unroll
+      for (int p = 0; p < IPASS; ++p) {
+        int r, q;
+        slot_rq(p, r, q);
+        const int ld = a.ldin[o];
+        const int qc = 4 * q + 4 <= ld ? 4 * q : 0;
+        const int rc = r < valid ? r : valid - 1;
+        unsigned off = ((unsigned)(row0 + rc) * (unsigned)ld + (unsigned)qc) * 4u;
+        asm volatile("" : "+v"(off));
+        pin[o][p] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.in[o]) + off);
+      }
+    }
+  };
+  // the prefetched rows -> LDS; what lies outside the tile (ragged tail, columns beyond k_in, an operand the segment
+  // does not have) is zeroed
+  auto write_as = [&](int seg_, int valid_) {
+    bool whole = valid_ == ROWS && a.k_in == KO;
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o) whole = whole && t_w_s[o][seg_] >= 0;
+#pragma unroll
+    for (int o = 0; o < NOPS; ++o) {
+      const bool present = t_w_s[o][seg_] >= 0;
+#pragma unroll
+      for (int p = 0; p < IPASS; ++p) {
+        int r, q;
+        slot_rq(p, r, q);
+        float4 v = pin[o][p];
+        if (!whole) {  // uniform
+          const int tail = a.k_in - 4 * q;
+          const bool ok = present && r < valid_;
+          v.x = (ok && tail > 0) ? v.x : 0.f;
+          v.y = (ok && tail > 1) ? v.y : 0.f;
+          v.z = (ok && tail > 2) ? v.z : 0.f;
+          v.w = (ok && tail > 3) ? v.w : 0.f;
+        }
+        *reinterpret_cast<float4*>(As + r * AP + o * KO + 4 * q) = v;
+      }
+    }
+  };
+
+  // ---- this wave's weight fragments of the segment, split, and its bias column(s)
+  u32x4 wf[TPW][NKS][3];
+  float bv[TPW];
+  auto load_w = [&](int seg_) {
+    int kin = a.k_in;
+    asm volatile("" : "+s"(kin));  // everything below is formed here, on the rare segment change: hoisted out of the
+                                   // tile loop, its 64 addresses and 64 conditions would live in (spilled) registers
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      int n = (twb + 2 * j) * 32 + l31;
+      asm volatile("" : "+v"(n));
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const int c0 = ks * 16 + 8 * half;  // eight consecutive contraction indices, inside one operand (KO % 8 == 0)
+        const int o = c0 >= KO ? 1 : 0;
+        const int ck0 = c0 - o * KO;
+        const int64_t woff = t_w_s[o][seg_];
+        const char* wb = reinterpret_cast<const char*>((o == 1 ? a.w[1] : a.w[0]) + (woff >= 0 ? woff : 0));
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int ck = ck0 + e;
+          const bool ok = woff >= 0 && ck < kin;
+          const unsigned off = ok ? (unsigned)(TRANS ? n * kin + ck : ck * NOUT + n) * 4u : 0u;
+          const float got = *reinterpret_cast<const float*>(wb + off);  // unconditional load, then select
+          v[e] = ok ? got : 0.f;
+        }
+        const Frag3 f = split_frag(v);
+        wf[j][ks][0] = f.p[0];
+        wf[j][ks][1] = f.p[1];
+        wf[j][ks][2] = f.p[2];
+      }
+      const int64_t boff = t_b_s[seg_];
+      bv[j] = (a.bias != nullptr && boff >= 0) ? a.bias[boff + n] : 0.f;
+    }
+  };
+
+  // BatchNorm sums of this lane's output column(s): fp32 over up to eight tiles, then fp64 in LDS
+  float ps1[TPW], ps2[TPW];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) ps1[j] = ps2[j] = 0.f;
+  auto flush_stats = [&]() {
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      atomicAdd(&stat_s[0][(twb + 2 * j) * 32 + l31], (double)ps1[j]);
+      atomicAdd(&stat_s[1][(twb + 2 * j) * 32 + l31], (double)ps2[j]);
+      ps1[j] = ps2[j] = 0.f;
+    }
+  };
+
+  // this wave's output tile(s): products, bias, ReLU, store, sums
+  auto products = [&](int row0_, int valid_) {
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[j][k] = 0.f;
+    float4 glo, ghi;
+    auto read_a = [&](int ks) {
+      const float* arow = As + (rb * 32 + l31) * AP + ks * 16 + 8 * half;
+      glo = *reinterpret_cast<const float4*>(arow);
+      ghi = *reinterpret_cast<const float4*>(arow + 4);
+    };
+    read_a(0);
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      const float v[8] = {glo.x, glo.y, glo.z, glo.w, ghi.x, ghi.y, ghi.z, ghi.w};
+      const Frag3 fa = split_frag(v);
+      if (ks + 1 < NKS) read_a(ks + 1);  // the next k-step's LDS read, issued before this k-step's MFMAs
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) {
+        const u32x4 w1 = wf[j][ks][0], w2 = wf[j][ks][1], w3 = wf[j][ks][2];
+        // rows x output columns: lane = output column, registers = rows; small terms first
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fa.p[2]), as_bf16x8(w1), acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fa.p[0]), as_bf16x8(w3), acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fa.p[1]), as_bf16x8(w2), acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fa.p[1]), as_bf16x8(w1), acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fa.p[0]), as_bf16x8(w2), acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fa.p[0]), as_bf16x8(w1), acc[j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const int rl0 = rb * 32 + 4 * half;
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      char* const obase = reinterpret_cast<char*>(a.out);
+      const unsigned o0 = ((unsigned)(row0_ + rl0) * (unsigned)a.ldo + (unsigned)((twb + 2 * j) * 32 + l31)) * 4u;
+      float s1 = 0.f, s2 = 0.f;
+      // One path for whole and ragged tiles, sixteen stores either way: the rows beyond a ragged tile's end go to a
+      // dump word.  (With the stores under branches, or in two alternative blocks, the compiler cannot count the stores
+      // that follow the next tile's loads in the memory queue -- one in-order counter -- and makes write_as() wait for
+      // all of them instead of s_waitcnt vmcnt(16 + ...): the stores' latency would be serialised with the next tile.)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int r8 = (reg & 3) + 8 * (reg >> 2);
+        const bool live = rl0 + r8 < valid_;
+        float v = acc[j][reg] + bv[j];
+        if (a.relu) v = v > 0.f ? v : 0.f;
+        unsigned off = o0 + (unsigned)r8 * (unsigned)a.ldo * 4u;
+        asm volatile("" : "+v"(off));  // formed at the store: sixteen hoisted offsets would not fit the registers
+        float* dst = live ? reinterpret_cast<float*>(obase + off) : my_dump;
+        *dst = v;
+        v = live ? v : 0.f;
+        s1 += v;
+        s2 = fmaf(v, v, s2);
+      }
+      ps1[j] += s1;
+      ps2[j] += s2;
+    }
+  };
+
+  int seg, row0, valid;
+  tile_info(tile_at(0), seg, row0, valid);
+  int nseg = seg, nrow0 = row0, nvalid = valid;
+  if (my_tiles > 1) tile_info(tile_at(1), nseg, nrow0, nvalid);
+  load_src(row0, valid);
+  int cur_seg = seg;
+  load_w(seg);
+
+  for (int i = 0; i < my_tiles; ++i) {
+    write_as(seg, valid);
+    __syncthreads();
+    int n2seg = nseg, n2row0 = nrow0, n2valid = nvalid;
+    if (i + 2 < my_tiles) tile_info(tile_at(i + 2), n2seg, n2row0, n2valid);
+    load_src(nrow0, nvalid);  // ahead of this tile's stores in the memory queue
+    if (seg != cur_seg) {  // uniform
+      cur_seg = seg;
+      load_w(seg);
+    }
+    products(row0, valid);
+    if (a.stats != nullptr && (i & 7) == 7) flush_stats();
+    __syncthreads();
+    seg = nseg; row0 = nrow0; valid = nvalid;
+    nseg = n2seg; nrow0 = n2row0; nvalid = n2valid;
+  }
+  if (a.stats != nullptr) {
+    flush_stats();
+    __syncthreads();
+    for (int c = tid; c < 2 * NOUT; c += NT) {
+      const int which = c / NOUT, col = c - which * NOUT;
+      atomicAdd(a.stats + (size_t)2 * NOUT * (1 + (blockIdx.x % kBnReplicas)) + (size_t)which * NOUT + col,
+                stat_s[which][col]);
+    }
+  }
+}
+
 static bool fwd_fused_on() {
   static const int env = getenv("GCMI_FUSED_FWD") ? atoi(getenv("GCMI_FUSED_FWD")) : 1;
   return env != 0;
@@ -306,8 +584,34 @@ static int launch_fwd(const FwdTable& st, int n_tiles, const FwdArgs& a, hipStre
   return GCMI_OK;
 }
 
-// The shapes of the default model in split-bf16 mode: two 64-column operands -> 64 columns (GraphConv over pooled
-// rows), one 64-column operand -> 128 columns in nn.Linear layout (the atom-level dense layer).  Anything else:
+static bool fwd_reg_on() {
+  static const int env = getenv("GCMI_FWD_REG") ? atoi(getenv("GCMI_FWD_REG")) : 1;
+  return env != 0;
+}
+
+template <int NOPS, int KO, int NOUT, bool TRANS>
+static int launch_fwd_reg(const FwdTable& st, int n_tiles, const FwdArgs& a, hipStream_t sm) {
+  constexpr int NC = NOPS * KO;
+  const size_t shmem = sizeof(float) * 64 * (NC + 4);
+  auto kern = fwd_reg_kernel<NOPS, KO, NOUT, TRANS>;
+  static bool attr_done = false;  // per instantiation
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)shmem) != hipSuccess) {
+      (void)hipGetLastError();
+      return GCMI_ERR_UNSUPPORTED;
+    }
+    attr_done = true;
+  }
+  const int grid = std::min(n_tiles, 512);  // two workgroups per CU (g_fwd_dump is sized for this)
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, sm, st, n_tiles, a, next_sweep_direction());
+  GCMI_CHECK_LAUNCH("fwd_reg");
+  return GCMI_OK;
+}
+
+// The shapes of the default model in split-bf16 mode: two operands of 65..80 columns -> 64 columns (the first
+// GraphConv: fwd_reg_kernel), two 64-column operands -> 64 columns (GraphConv over pooled rows), one 64-column
+// operand -> 128 columns in nn.Linear layout (the atom-level dense layer).  Anything else:
 // GCMI_ERR_UNSUPPORTED, and the caller runs seg_gemm4_kernel.  *fused: the BatchNorm sums were added to d_stats.
 int fwd_fused_gemm(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_end, const float* d_a1, int64_t lda1,
                    int32_t k1, const float* d_w1, const int64_t* w1_off, const float* d_a2, int64_t lda2, int32_t k2,
@@ -317,8 +621,9 @@ int fwd_fused_gemm(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
   if (!fwd_fused_on() || !fused_bwd_enabled() || n_seg > kWMaxSeg || (act != 0 && act != 1)) return GCMI_ERR_UNSUPPORTED;
   const bool two = d_a1 != nullptr && d_a2 != nullptr;
   const bool conv = two && !trans_w && n_out == 64 && k1 == k2 && k1 > 32 && k1 <= 64;
+  const bool conv80 = fwd_reg_on() && two && !trans_w && n_out == 64 && k1 == k2 && k1 > 64 && k1 <= 80;
   const bool dense = !two && d_a1 != nullptr && trans_w && n_out == 128 && k1 > 32 && k1 <= 64;
-  if (!conv && !dense) return GCMI_ERR_UNSUPPORTED;
+  if (!conv && !dense && !conv80) return GCMI_ERR_UNSUPPORTED;
   if (!aligned16(d_a1) || lda1 % 4 || (two && (!aligned16(d_a2) || lda2 % 4)) || !aligned16(d_out) || ldo % 4 ||
       (d_bias && !aligned16(d_bias)))
     return GCMI_ERR_UNSUPPORTED;
@@ -348,6 +653,7 @@ int fwd_fused_gemm(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
   memset(&a, 0, sizeof(a));
   a.in[0] = d_a1; a.ldin[0] = (int32_t)lda1; a.in[1] = d_a2; a.ldin[1] = (int32_t)lda2; a.k_in = k1;
   a.w[0] = d_w1; a.w[1] = d_w2; a.bias = d_bias; a.out = d_out; a.ldo = (int32_t)ldo; a.relu = act; a.stats = d_stats;
+  if (conv80) return launch_fwd_reg<2, 80, 64, false>(st, (int)tiles, a, sm);
   if (conv) return launch_fwd<128, 2, 64, 64, false>(st, (int)tiles, a, sm);
   return launch_fwd<64, 1, 64, 128, true>(st, (int)tiles, a, sm);
 }
