@@ -125,28 +125,20 @@ class NumpyDataset(Dataset):
     """X (any array, e.g. an object array of ConvMol), y (n, tasks), w, ids (datasets.py:746-1099)."""
 
     def __init__(self, X, y=None, w=None, ids=None, n_tasks: int = 1):
-        n_samples = np.shape(X)[0]
-        if n_samples > 0:
-            if y is None:
-                y = np.zeros((n_samples, n_tasks), np.float32)
-                if w is None:
-                    w = np.zeros((n_samples, 1), np.float32)
-            if ids is None:
-                ids = np.arange(n_samples)
-            if not isinstance(X, np.ndarray):
-                X = np.array(X)
-            if not isinstance(y, np.ndarray):
-                y = np.array(y)
-            if w is None:
-                if len(y.shape) == 1:
-                    w = np.ones(y.shape[0], np.float32)
-                else:
-                    w = np.ones((y.shape[0], 1), np.float32)
-            if not isinstance(w, np.ndarray):
-                w = np.array(w)
-        self._X = X
-        self._y = y
-        self._w = w
+        rows = np.shape(X)[0]
+        if rows > 0:  # an empty set keeps whatever it was given
+            X = X if isinstance(X, np.ndarray) else np.array(X)
+            unlabelled = y is None
+            if unlabelled:
+                # no labels: zero labels, and (unless weights came along) zero weights, so nothing trains on them
+                y = np.zeros((rows, n_tasks), np.float32)
+                w = np.zeros((rows, 1), np.float32) if w is None else w
+            y = y if isinstance(y, np.ndarray) else np.array(y)
+            if w is None:  # labels without weights: every sample counts once
+                w = np.ones(y.shape[:1] if y.ndim == 1 else (y.shape[0], 1), np.float32)
+            w = w if isinstance(w, np.ndarray) else np.array(w)
+            ids = np.arange(rows) if ids is None else ids
+        self._X, self._y, self._w = X, y, w
         self._ids = np.array(ids, dtype=object)
 
     def __len__(self) -> int:
@@ -213,13 +205,9 @@ class NumpyDataset(Dataset):
 
     @staticmethod
     def merge(datasets: Sequence[Dataset]) -> "NumpyDataset":
-        X, y, w, ids = datasets[0].X, datasets[0].y, datasets[0].w, datasets[0].ids
-        for d in datasets[1:]:
-            X = np.concatenate([X, d.X], axis=0)
-            y = np.concatenate([y, d.y], axis=0)
-            w = np.concatenate([w, d.w], axis=0)
-            ids = np.concatenate([ids, d.ids], axis=0)
-        return NumpyDataset(X, y, w, ids, n_tasks=y.shape[1] if len(y.shape) > 1 else 1)
+        X, y, w, ids = (np.concatenate([getattr(d, part) for d in datasets], axis=0) if len(datasets) > 1
+                        else getattr(datasets[0], part) for part in ("X", "y", "w", "ids"))
+        return NumpyDataset(X, y, w, ids, n_tasks=y.shape[1] if y.ndim > 1 else 1)
 
 
 # ------------------------------------------------------------------------------------------ disk
@@ -716,36 +704,26 @@ class DiskDataset(Dataset):
     def reshard(self, shard_size: int) -> None:
         """Rewrite the data in shards of ``shard_size`` rows, in place (datasets.py:1491-1568)."""
         reshard_dir = tempfile.mkdtemp()
-        tasks = self.get_task_names()
+        n_tasks = len(self.get_task_names())
         _, y_shape, w_shape, _ = self.get_shape()
-        if len(y_shape) == 1:
-            y_shape = (len(y_shape), len(tasks))
-        if len(w_shape) == 1:
-            w_shape = (len(w_shape), len(tasks))
-        data_shape = tuple(self.get_data_shape())
+        # per-row shapes of X, y, w (a 1-d label or weight array is given the reference's (1, n_tasks) reading)
+        row_shapes = [tuple(self.get_data_shape())] + [
+            tuple(((len(shape), n_tasks) if len(shape) == 1 else shape)[1:]) for shape in (y_shape, w_shape)]
 
         def generator():
-            X_next = np.zeros((0,) + data_shape)
-            y_next = np.zeros((0,) + tuple(y_shape[1:]))
-            w_next = np.zeros((0,) + tuple(w_shape[1:]))
-            ids_next = np.zeros((0,), dtype=object)
-            for X, y, w, ids in self.itershards():
-                X = np.reshape(X, (len(X),) + data_shape)
-                if y is None:
-                    y, w = y_next, w_next
-                else:
-                    y = np.reshape(y, (len(y),) + tuple(y_shape[1:]))
-                    w = np.reshape(w, (len(w),) + tuple(w_shape[1:]))
-                X_next = np.concatenate([X_next, X], axis=0)
-                y_next = np.concatenate([y_next, y], axis=0)
-                w_next = np.concatenate([w_next, w], axis=0)
-                ids_next = np.concatenate([ids_next, ids])
-                while len(X_next) > shard_size:
-                    out = (X_next[:shard_size], y_next[:shard_size], w_next[:shard_size], ids_next[:shard_size])
-                    X_next, y_next = X_next[shard_size:], y_next[shard_size:]
-                    w_next, ids_next = w_next[shard_size:], ids_next[shard_size:]
-                    yield out
-            yield (X_next, y_next, w_next, ids_next)
+            # rows waiting to fill a shard, [X, y, w, ids]; they start as empty float64 arrays, so the
+            # rewritten shards are float64 whatever the old ones were (as in the reference)
+            pending = [np.zeros((0,) + tail) for tail in row_shapes] + [np.zeros((0,), dtype=object)]
+            for shard in self.itershards():
+                arrived = [None if a is None else np.reshape(a, (len(a),) + tail)
+                           for a, tail in zip(shard[:3], row_shapes)] + [shard[3]]
+                if arrived[1] is None:  # an unlabelled shard re-appends the waiting labels (reference quirk)
+                    arrived[1], arrived[2] = pending[1], pending[2]
+                pending = [np.concatenate([have, new], axis=0) for have, new in zip(pending, arrived)]
+                while len(pending[0]) > shard_size:
+                    yield tuple(a[:shard_size] for a in pending)
+                    pending = [a[shard_size:] for a in pending]
+            yield tuple(pending)
 
         resharded = DiskDataset.create_dataset(generator(), data_dir=reshard_dir, tasks=self.tasks)
         shutil.rmtree(self.data_dir)

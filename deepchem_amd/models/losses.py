@@ -1,62 +1,62 @@
-"""The two losses of the GraphConv path (deepchem/models/losses.py), as Loss
-objects with the reference's interface (``_create_pytorch_loss()`` returns the
-per-sample/per-task criterion).  ``_gcmi_kind`` lets ``_StandardLoss`` replace
-criterion + weighting + mean by the fused HIP kernel (gcmi_loss_fwd_bwd)."""
+"""The two losses of the GraphConv path behind the reference's ``Loss`` interface
+(deepchem/models/losses.py: ``L2Loss`` :76-94, ``SoftmaxCrossEntropy`` :236-259, shape rule :1522-1543).
+
+A loss object hands out a per-element criterion through ``_create_pytorch_loss()``; weighting and the mean
+belong to the caller.  ``_gcmi_kind`` is the criterion's number in ``gcmi_loss_fwd_bwd`` (include/gcmi.h), which
+``_StandardLoss`` uses in place of criterion + weighting + mean when the tensors live on the GPU."""
 import torch
-
-
-class Loss(object):
-    """A per-sample (per-task) loss; weighting and averaging are done by the caller."""
-
-    _gcmi_kind = None
-
-    def _create_pytorch_loss(self):
-        raise NotImplementedError("Subclasses must implement this")
+import torch.nn.functional as F
 
 
 def _make_pytorch_shapes_consistent(output, labels):
-    """Pad the shorter shape with trailing 1s (deepchem/models/losses.py:1522-1543)."""
-    shape1, shape2 = tuple(output.shape), tuple(labels.shape)
-    len1, len2 = len(shape1), len(shape2)
-    if len1 == len2:
-        return (output, labels)
-    if len1 > len2 and all(i == 1 for i in shape1[len2:]):
-        for _ in range(len1 - len2):
-            labels = torch.unsqueeze(labels, -1)
-        return (output, labels)
-    if len2 > len1 and all(i == 1 for i in shape2[len1:]):
-        for _ in range(len2 - len1):
-            output = torch.unsqueeze(output, -1)
-        return (output, labels)
-    raise ValueError("Incompatible shapes for outputs and labels: %s versus %s" %
-                     (str(shape1), str(shape2)))
+    """Give ``output`` and ``labels`` the same rank: the one of lower rank gains trailing unit axes, allowed
+    only where the other's extra axes are all of extent 1.  Anything else is the reference's ValueError."""
+    ro, rl = output.dim(), labels.dim()
+    if ro == rl:
+        return output, labels
+    longer, shorter = (output, labels) if ro > rl else (labels, output)
+    extra = tuple(longer.shape[shorter.dim():])
+    if any(e != 1 for e in extra):
+        raise ValueError("Incompatible shapes for outputs and labels: %s versus %s" %
+                         (str(tuple(output.shape)), str(tuple(labels.shape))))
+    shorter = shorter.reshape(tuple(shorter.shape) + extra)
+    return (output, shorter) if ro > rl else (shorter, labels)
+
+
+def _squared_difference(output, labels):
+    return F.mse_loss(output, labels, reduction='none')
+
+
+def _label_weighted_log_softmax(output, labels):
+    return -(labels * F.log_softmax(output, dim=-1)).sum(dim=-1)
+
+
+class Loss(object):
+    """Base of the loss objects.  Subclasses name a criterion ``f(output, labels) -> per-element loss``."""
+
+    _gcmi_kind = None
+    _criterion = None
+
+    def _create_pytorch_loss(self):
+        criterion = type(self)._criterion
+        if criterion is None:
+            raise NotImplementedError("Subclasses must implement this")
+
+        def loss(output, labels):
+            return criterion(*_make_pytorch_shapes_consistent(output, labels))
+
+        return loss
 
 
 class L2Loss(Loss):
-    """Squared difference (deepchem/models/losses.py:76-94)."""
+    """(output - labels)^2, element by element."""
 
     _gcmi_kind = 1
-
-    def _create_pytorch_loss(self):
-
-        def loss(output, labels):
-            output, labels = _make_pytorch_shapes_consistent(output, labels)
-            return torch.nn.functional.mse_loss(output, labels, reduction='none')
-
-        return loss
+    _criterion = staticmethod(_squared_difference)
 
 
 class SoftmaxCrossEntropy(Loss):
-    """Cross entropy between label probabilities and softmax(logits) over the
-    last axis (deepchem/models/losses.py:236-259)."""
+    """Cross entropy of label probabilities against softmax(logits) over the last axis; that axis is summed away."""
 
     _gcmi_kind = 0
-
-    def _create_pytorch_loss(self):
-        ls = torch.nn.LogSoftmax(dim=-1)
-
-        def loss(output, labels):
-            output, labels = _make_pytorch_shapes_consistent(output, labels)
-            return -torch.sum(labels * ls(output), dim=-1)
-
-        return loss
+    _criterion = staticmethod(_label_weighted_log_softmax)

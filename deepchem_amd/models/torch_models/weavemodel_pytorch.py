@@ -14,7 +14,7 @@ Reference behaviour kept on purpose (it decides what trains):
 needs rdkit, which this package does not ship.
 """
 from collections.abc import Sequence as SequenceCollection
-from typing import Callable, Iterable, List, Optional, Tuple
+from typing import Iterable, List, Tuple
 
 import numpy as np
 import torch
@@ -30,30 +30,19 @@ from deepchem_amd.models.torch_models.torch_model import TorchModel
 
 
 class WeaveMol(object):
-    """Atom features ``nodes`` (n, Fa), pair features ``pairs`` (n_pairs, Fp) and the ordered atom
-    pairs ``pair_edges`` (2, n_pairs) they belong to, grouped by source atom."""
+    """What the weave featurizer hands to the model for one molecule: atom features ``nodes`` (n, Fa), pair
+    features ``pairs`` (n_pairs, Fp) and the ordered atom pairs ``pair_edges`` (2, n_pairs) the pair rows belong
+    to, grouped by source atom.  Accessor names are the reference's (feat/mol_graphs.py:378-410)."""
 
     def __init__(self, nodes, pairs, pair_edges):
-        self.nodes = nodes
-        self.pairs = pairs
-        self.num_atoms = self.nodes.shape[0]
-        self.n_features = self.nodes.shape[1]
-        self.pair_edges = pair_edges
+        self.nodes, self.pairs, self.pair_edges = nodes, pairs, pair_edges
+        self.num_atoms, self.n_features = nodes.shape[:2]
 
-    def get_pair_edges(self):
-        return self.pair_edges
-
-    def get_pair_features(self):
-        return self.pairs
-
-    def get_atom_features(self):
-        return self.nodes
-
-    def get_num_atoms(self):
-        return self.num_atoms
-
-    def get_num_features(self):
-        return self.n_features
+    get_atom_features = lambda self: self.nodes  # noqa: E731
+    get_pair_features = lambda self: self.pairs  # noqa: E731
+    get_pair_edges = lambda self: self.pair_edges  # noqa: E731
+    get_num_atoms = lambda self: self.num_atoms  # noqa: E731
+    get_num_features = lambda self: self.n_features  # noqa: E731
 
 
 class EvalNormActFn(torch.autograd.Function):
@@ -86,6 +75,13 @@ class EvalNormActFn(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None
 
 
+def _per_layer(value, count: int) -> list:
+    """A per-layer setting: a sequence is taken as given, anything else (a string included) is used for all."""
+    if isinstance(value, SequenceCollection) and not isinstance(value, str):
+        return value
+    return [value] * count
+
+
 def _act_name(fn) -> str:
     if isinstance(fn, str):
         return fn.lower()
@@ -110,21 +106,11 @@ class Weave(nn.Module):
         super(Weave, self).__init__()
         if mode not in ['classification', 'regression']:
             raise ValueError("mode must be either 'classification' or 'regression'")
-        if not isinstance(n_atom_feat, SequenceCollection):
-            n_atom_feat = [n_atom_feat] * n_weave
-        if not isinstance(n_pair_feat, SequenceCollection):
-            n_pair_feat = [n_pair_feat] * n_weave
         n_layers = len(fully_connected_layer_sizes)
-        if not isinstance(conv_weight_init_stddevs, SequenceCollection):
-            conv_weight_init_stddevs = [conv_weight_init_stddevs] * n_weave
-        if not isinstance(weight_init_stddevs, SequenceCollection):
-            weight_init_stddevs = [weight_init_stddevs] * n_layers
-        if not isinstance(bias_init_consts, SequenceCollection):
-            bias_init_consts = [bias_init_consts] * n_layers
-        if not isinstance(dropouts, SequenceCollection):
-            dropouts = [dropouts] * n_layers
-        if isinstance(activation_fns, str) or not isinstance(activation_fns, SequenceCollection):
-            activation_fns = [activation_fns] * n_layers
+        n_atom_feat, n_pair_feat, conv_weight_init_stddevs = (
+            _per_layer(v, n_weave) for v in (n_atom_feat, n_pair_feat, conv_weight_init_stddevs))
+        weight_init_stddevs, bias_init_consts, dropouts, activation_fns = (
+            _per_layer(v, n_layers) for v in (weight_init_stddevs, bias_init_consts, dropouts, activation_fns))
         self.n_tasks, self.n_atom_feat, self.n_pair_feat = n_tasks, n_atom_feat, n_pair_feat
         self.n_hidden, self.n_graph_feat, self.mode, self.n_classes = n_hidden, n_graph_feat, mode, n_classes
         self.n_layers = n_layers
@@ -173,10 +159,8 @@ class Weave(nn.Module):
                 layer.dropout = nn.Dropout(dropout)
                 self.layers2.append(layer)
                 in_size = layer_size
-        if self.mode == 'classification':
-            self.layer_2 = nn.Linear(fully_connected_layer_sizes[1], n_tasks * n_classes)
-        else:
-            self.layer_2 = nn.Linear(fully_connected_layer_sizes[1], n_tasks)
+        head_columns = n_tasks * n_classes if mode == 'classification' else n_tasks
+        self.layer_2 = nn.Linear(fully_connected_layer_sizes[1], head_columns)
 
     def forward(self, inputs) -> List[torch.Tensor]:
         """inputs = [atom_features, pair_features, pair_split, atom_split, atom_to_pair]."""
@@ -243,43 +227,31 @@ class WeaveModel(TorchModel):
                            batch_normalize=batch_normalize, gaussian_expand=gaussian_expand,
                            compress_post_gaussian_expansion=compress_post_gaussian_expansion, mode=mode,
                            n_classes=n_classes, batch_size=batch_size, device=device)
-        regularization_loss: Optional[Callable]
-        if weight_decay_penalty != 0.0:
-            weights = [layer.weight for layer in self.model.layers2]
-            if weight_decay_penalty_type == 'l1':
-                regularization_loss = lambda: weight_decay_penalty * torch.sum(  # noqa: E731
-                    torch.stack([torch.abs(w).sum() for w in weights]))
-            else:
-                regularization_loss = lambda: weight_decay_penalty * torch.sum(  # noqa: E731
-                    torch.stack([torch.square(w).sum() for w in weights]))
-        else:
-            regularization_loss = None
-        if self.mode == 'classification':
-            output_types = ['prediction', 'loss']
-            loss = SoftmaxCrossEntropy()
-        else:
-            output_types = ['prediction']
-            loss = L2Loss()
-        super(WeaveModel, self).__init__(self.model, loss=loss, output_types=output_types, batch_size=batch_size,
-                                         regularization_loss=regularization_loss, **kwargs)
+        penalised = [layer.weight for layer in getattr(self.model, 'layers2', [])]
+        magnitude = torch.abs if weight_decay_penalty_type == 'l1' else torch.square
+
+        def weight_penalty():
+            return weight_decay_penalty * torch.stack([magnitude(w).sum() for w in penalised]).sum()
+
+        classify = mode == 'classification'
+        super(WeaveModel, self).__init__(self.model, loss=SoftmaxCrossEntropy() if classify else L2Loss(),
+                                         output_types=['prediction', 'loss'] if classify else ['prediction'],
+                                         batch_size=batch_size,
+                                         regularization_loss=weight_penalty if weight_decay_penalty != 0.0 else None,
+                                         **kwargs)
 
     def compute_features_on_batch(self, X_b):
-        """WeaveMol objects -> (atom_feat, pair_feat, pair_split, atom_split, atom_to_pair)
-        (weavemodel_pytorch.py:516-578): atoms and pairs concatenated molecule by molecule, atom
-        indices shifted to batch numbering."""
-        atom_feat, pair_feat, atom_split, atom_to_pair, pair_split = [], [], [], [], []
-        start = 0
-        for im, mol in enumerate(X_b):
-            n_atoms = mol.get_num_atoms()
-            pair_edges = mol.get_pair_edges()
-            atom_split.extend([im] * n_atoms)
-            atom_to_pair.append(pair_edges.T + start)
-            pair_split.extend(pair_edges.T[:, 0] + start)
-            start = start + n_atoms
-            atom_feat.append(mol.get_atom_features())
-            pair_feat.append(mol.get_pair_features())
-        return (np.concatenate(atom_feat, axis=0), np.concatenate(pair_feat, axis=0), np.array(pair_split),
-                np.array(atom_split), np.concatenate(atom_to_pair, axis=0))
+        """WeaveMol objects -> ``(atom_feat, pair_feat, pair_split, atom_split, atom_to_pair)``
+        (weavemodel_pytorch.py:516-578): atom and pair rows concatenated molecule by molecule; ``atom_to_pair``
+        (n_pairs, 2) holds the pairs in batch atom numbering, ``pair_split`` its first column (the atom a pair row
+        is summed into), ``atom_split`` the molecule of each atom."""
+        sizes = [mol.get_num_atoms() for mol in X_b]
+        first_atom = np.concatenate(([0], np.cumsum(sizes)[:-1])).tolist()
+        atom_to_pair = np.concatenate([mol.get_pair_edges().T + shift for mol, shift in zip(X_b, first_atom)], axis=0)
+        atom_split = np.repeat(np.arange(len(sizes)), sizes)
+        atom_feat = np.concatenate([mol.get_atom_features() for mol in X_b], axis=0)
+        pair_feat = np.concatenate([mol.get_pair_features() for mol in X_b], axis=0)
+        return atom_feat, pair_feat, np.ascontiguousarray(atom_to_pair[:, 0]), atom_split, atom_to_pair
 
     def _prepare_batch(self, batch):
         # the index arrays stay on the host: the layers build their CSR plans from them
@@ -293,11 +265,10 @@ class WeaveModel(TorchModel):
 
     def default_generator(self, dataset, epochs: int = 1, mode: str = 'fit', deterministic: bool = True,
                           pad_batches: bool = True) -> Iterable[Tuple[List, List, List]]:
-        for epoch in range(epochs):
-            for (X_b, y_b, w_b, ids_b) in dataset.iterbatches(batch_size=self.batch_size, deterministic=deterministic,
-                                                              pad_batches=pad_batches):
-                if y_b is not None and self.model.mode == 'classification':
-                    y_b = to_one_hot(y_b.flatten(), self.model.n_classes).reshape(-1, self.model.n_tasks,
-                                                                                  self.model.n_classes)
-                inputs = self.compute_features_on_batch(X_b)
-                yield (inputs, [y_b], [w_b])
+        net = self.model
+        for _ in range(epochs):
+            for X_b, y_b, w_b, _ids in dataset.iterbatches(batch_size=self.batch_size, deterministic=deterministic,
+                                                           pad_batches=pad_batches):
+                if net.mode == 'classification' and y_b is not None:
+                    y_b = to_one_hot(y_b.flatten(), net.n_classes).reshape(-1, net.n_tasks, net.n_classes)
+                yield (self.compute_features_on_batch(X_b), [y_b], [w_b])
