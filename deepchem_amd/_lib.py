@@ -23,6 +23,7 @@ GCMI_OPT_GEMM_EXACT = 1
 GCMI_OPT_FUSED_BN_STATS = 2
 GCMI_OPT_FUSED_BWD = 3
 GCMI_OPT_FUSED_BWD_LAUNCHES = 4
+GCMI_OPT_READOUT_PIPELINED = 5
 GCMI_WIN_META_INTS = 24
 GCMI_COLLATE_WIN_DESC_INTS = 36
 GCMI_WIN_MAX_SLOTS = 4095

@@ -129,6 +129,8 @@ int launch_seg_gemm4(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg
 
 // bwd_fused.hip: BatchNorm-backward + weight gradients + input gradients of one block in one pass over the rows;
 // GCMI_ERR_UNSUPPORTED = switched off / exact mode / shape not covered (the caller runs the separate kernels)
+void set_readout_pipelined(int on);
+int get_readout_pipelined();
 void set_fused_bwd(int on);
 int get_fused_bwd();
 bool fused_bwd_enabled();

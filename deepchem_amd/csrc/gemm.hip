@@ -567,21 +567,24 @@ using namespace gcmi;
 extern "C" {
 
 int gcmi_set_option(int32_t option, int32_t value) {
-  GCMI_CHECK_ARG(option == GCMI_OPT_GEMM_EXACT || option == GCMI_OPT_FUSED_BN_STATS || option == GCMI_OPT_FUSED_BWD,
+  GCMI_CHECK_ARG(option == GCMI_OPT_GEMM_EXACT || option == GCMI_OPT_FUSED_BN_STATS || option == GCMI_OPT_FUSED_BWD ||
+                     option == GCMI_OPT_READOUT_PIPELINED,
                  "set_option: unknown option %d", option);
   if (option == GCMI_OPT_GEMM_EXACT) g_gemm_exact.store(value != 0 ? 1 : 0, std::memory_order_relaxed);
   else if (option == GCMI_OPT_FUSED_BN_STATS) g_fused_bn_stats.store(value != 0 ? 1 : 0, std::memory_order_relaxed);
+  else if (option == GCMI_OPT_READOUT_PIPELINED) set_readout_pipelined(value);
   else set_fused_bwd(value);
   return GCMI_OK;
 }
 
 int gcmi_get_option(int32_t option, int32_t* value) {
   GCMI_CHECK_ARG((option == GCMI_OPT_GEMM_EXACT || option == GCMI_OPT_FUSED_BN_STATS || option == GCMI_OPT_FUSED_BWD ||
-                  option == GCMI_OPT_FUSED_BWD_LAUNCHES) && value,
+                  option == GCMI_OPT_FUSED_BWD_LAUNCHES || option == GCMI_OPT_READOUT_PIPELINED) && value,
                  "get_option: unknown option %d", option);
   if (option == GCMI_OPT_GEMM_EXACT) *value = g_gemm_exact.load(std::memory_order_relaxed);
   else if (option == GCMI_OPT_FUSED_BN_STATS) *value = g_fused_bn_stats.load(std::memory_order_relaxed);
   else if (option == GCMI_OPT_FUSED_BWD) *value = get_fused_bwd();
+  else if (option == GCMI_OPT_READOUT_PIPELINED) *value = get_readout_pipelined();
   else *value = fused_bwd_launches();
   return GCMI_OK;
 }

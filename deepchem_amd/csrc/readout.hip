@@ -14,6 +14,8 @@
 #include <limits.h>
 #include <math.h>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace gcmi {
@@ -48,14 +50,20 @@ mol_runs_kernel(DegTable t, int n_atoms, int n_mols, const int32_t* __restrict__
   }
 }
 
-template <int V, bool BN>
+// PRE (host: a lane group of 11..64 lanes inside one wave, one column chunk per lane): the molecule's run bounds
+// are fetched once, one run per lane, and handed round the group with cross-lane reads; the rows are then walked
+// as ONE sequence of four-row rounds across the runs, the loads of round k + 1 issued before round k is consumed.
+// Same rows in the same order as the plain form (bit-identical sums, same first-maximum rule); what changes is the
+// number of dependent memory round trips per molecule: 1 + ceil(atoms / 4) with two rounds in flight, against one
+// per degree + one per four rows of every run, one at a time.
+template <int V, bool BN, bool PRE>
 __global__ void __launch_bounds__(kRBlock)
 readout_fwd_kernel(int n_mols, int n_deg, const int32_t* __restrict__ runs,
                    const float* __restrict__ x, int64_t ldx, int n_feat, int lpr, int gl,
                    const float* __restrict__ scale, const float* __restrict__ shift, int act,
                    float* __restrict__ out, int64_t ldo, int32_t* __restrict__ arg, float* __restrict__ rawsum,
                    int vec_out) {
-  const int mpb = kRBlock / gl;  // molecules per workgroup
+  const int mpb = (int)blockDim.x / gl;  // molecules per workgroup
   const int grp = threadIdx.x / gl;
   const int lane = threadIdx.x - grp * gl;
   if (grp >= mpb) return;
@@ -76,6 +84,76 @@ readout_fwd_kernel(int n_mols, int n_deg, const int32_t* __restrict__ runs,
       mx[q] = -INFINITY;
       am[q] = -1;
     }
+    auto take = [&](float (&v)[4][V], const int (&idx)[4], int n) {
+      // every row of the round is touched on every path (an empty asm): the waits for the round's loads are then
+      // unconditional, and the compiler knows at the next round that none of these registers is still a load target
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < V; ++q) asm volatile("" : "+v"(v[u][q]));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (u < n) {
+          const int r = idx[u];
+#pragma unroll
+          for (int q = 0; q < V; ++q) {
+            const float a = BN ? fmaf(v[u][q], sc[q], sh[q]) : v[u][q];
+            raw[q] += v[u][q];
+            sum[q] += a;
+            if (a > mx[q]) { mx[q] = a; am[q] = r; rawmx[q] = v[u][q]; }
+          }
+        }
+      }
+    };
+    if constexpr (PRE) {
+      // lane d holds run d.  Loaded unconditionally and passed through an empty asm: the wait for this one load
+      // then sits here, before any row is requested, and the cross-lane reads below carry no memory wait
+      int2 mine = reinterpret_cast<const int2*>(rb)[lane < n_deg ? lane : 0];
+      asm volatile("" : "+v"(mine.x), "+v"(mine.y));
+      // cursor over the molecule's rows in ascending order: [rr, r1) is what is left of the current run, and it is
+      // moved on to the next non-empty run as soon as it empties (rr < r1 <=> rows are left); uniform over the group
+      int d = 0, rr = 0, r1 = 0, last = 0;
+      auto seek = [&]() {
+        while (rr >= r1 && d < n_deg) {
+          rr = __shfl(mine.x, d, gl);
+          r1 = __shfl(mine.y, d, gl);
+          ++d;
+        }
+      };
+      seek();
+      // a round: the next (up to) four rows, whatever runs they lie in; slots past the end re-read a row already read
+      auto issue = [&](float (&v)[4][V], int (&idx)[4], int& n) {
+        n = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool ok = rr < r1;
+          idx[u] = ok ? rr : last;
+          if (ok) {
+            last = rr;
+            ++rr;
+            ++n;
+            seek();
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float4 tv = *reinterpret_cast<const float4*>(x + (int64_t)idx[u] * ldx + c);
+          v[u][0] = tv.x; v[u][1] = tv.y; v[u][2] = tv.z; v[u][3] = tv.w;
+        }
+      };
+      float va[4][V], vb[4][V];
+      int ia[4], ib[4], an = 0, bn = 0;
+      issue(va, ia, an);
+      // one exit, at the top: with a way out between the halves the compiler cannot count the loads in flight and
+      // waits for all of them.  Inside, round B is never empty; the second A may be (at most one such per molecule)
+      while (rr < r1) {
+        issue(vb, ib, bn);
+        take(va, ia, an);
+        issue(va, ia, an);
+        take(vb, ib, bn);
+      }
+      take(va, ia, an);
+    } else
     for (int d = 0; d < n_deg; ++d) {
       const int r0 = rb[2 * d], r1 = rb[2 * d + 1];
       // four rows of the run per round, loads issued together, consumed in row order
@@ -256,6 +334,10 @@ int gcmi_readout_fwd(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t
 }  // extern "C"
 
 namespace gcmi {
+static std::atomic<int> g_readout_pre{getenv("GCMI_READOUT_PRE") && atoi(getenv("GCMI_READOUT_PRE")) == 0 ? 0 : 1};
+void set_readout_pipelined(int on) { g_readout_pre.store(on ? 1 : 0, std::memory_order_relaxed); }
+int get_readout_pipelined() { return g_readout_pre.load(std::memory_order_relaxed); }
+
 // d_rawsum (may be NULL): [n_mols x 2 n_feat] per-molecule [sums of the input rows | value of the arg-max row], both
 // before the folded BatchNorm -- what
 // the BatchNorm backward behind this readout needs to get its column sums without another pass over the atoms
@@ -274,7 +356,8 @@ int readout_fwd_impl(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t
   const int V = vec_width(d_x, ldx, n_feat);
   const int lpr = n_feat / V;
   const int gl = lpr < kRBlock ? lpr : kRBlock;
-  const int mpb = kRBlock / gl;
+  const int tb = kRBlock;  // (64- and 128-thread workgroups measured 3 % slower with the pipelined walk)
+  const int mpb = tb / gl;
   const int blocks = (g->n_mols + mpb - 1) / mpb;
   const bool bn = d_scale != nullptr;
   const int n_deg = g->max_deg + 1;
@@ -283,14 +366,20 @@ int readout_fwd_impl(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t
                           ? 1
                           : 0;
   TimedScope ts(GCMI_K_READOUT, st);
-#define LAUNCH_RO(VV, BB)                                                                        \
-  hipLaunchKernelGGL((readout_fwd_kernel<VV, BB>), dim3(blocks), dim3(kRBlock), 0, st, g->n_mols, \
-                     n_deg, g->d_mol_runs, d_x, ldx, n_feat, lpr, gl, d_scale, d_shift, act,     \
+  // run bounds in registers + two rounds in flight: lane groups of whole power-of-two size inside one wave that
+  // can hold one run per lane (GCMI_OPT_READOUT_PIPELINED / GCMI_READOUT_PRE=0: the plain walk)
+  const bool pre = get_readout_pipelined() != 0 && V == 4 && g->n_atoms > 0 && gl == lpr && gl >= n_deg && gl <= 64 && (gl & (gl - 1)) == 0 &&
+                   (reinterpret_cast<uintptr_t>(g->d_mol_runs) & 7u) == 0;
+#define LAUNCH_RO(VV, BB, PP)                                                                        \
+  hipLaunchKernelGGL((readout_fwd_kernel<VV, BB, PP>), dim3(blocks), dim3(tb), 0, st, g->n_mols, \
+                     n_deg, g->d_mol_runs, d_x, ldx, n_feat, lpr, gl, d_scale, d_shift, act,         \
                      d_out, ldo, d_arg, d_rawsum, vec_out)
-  if (V == 4) {
-    if (bn) LAUNCH_RO(4, true); else LAUNCH_RO(4, false);
+  if (V == 4 && pre) {
+    if (bn) LAUNCH_RO(4, true, true); else LAUNCH_RO(4, false, true);
+  } else if (V == 4) {
+    if (bn) LAUNCH_RO(4, true, false); else LAUNCH_RO(4, false, false);
   } else {
-    if (bn) LAUNCH_RO(1, true); else LAUNCH_RO(1, false);
+    if (bn) LAUNCH_RO(1, true, false); else LAUNCH_RO(1, false, false);
   }
 #undef LAUNCH_RO
   GCMI_CHECK_LAUNCH("readout_fwd");

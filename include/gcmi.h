@@ -118,7 +118,12 @@ enum {
    * up to summation order).  Environment: GCMI_FUSED_BWD=0 before the library is loaded.                        */
   GCMI_OPT_FUSED_BWD = 3,
   /* read-only (gcmi_get_option): launches of the one-pass backward kernel in this process so far */
-  GCMI_OPT_FUSED_BWD_LAUNCHES = 4
+  GCMI_OPT_FUSED_BWD_LAUNCHES = 4,
+  /* 1 (default): gcmi_readout_fwd and the whole-model forward walk a molecule's rows as one sequence of four-row
+   * rounds with two rounds in flight and the run bounds held in registers (readout.hip); 0: run by run, one round
+   * at a time.  Same rows in the same order: the results are bit-identical.  Environment: GCMI_READOUT_PRE=0
+   * before the library is loaded.                                                                              */
+  GCMI_OPT_READOUT_PIPELINED = 5
 };
 int gcmi_set_option(int32_t option, int32_t value);
 int gcmi_get_option(int32_t option, int32_t* value);

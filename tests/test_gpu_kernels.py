@@ -184,6 +184,33 @@ def test_readout_fwd_bwd(n_feat, tanh, ints):
     assert rel(dx, xc.grad) < TOL
 
 
+@pytest.mark.parametrize("n_feat,n_mols,ints", [(128, 60, False), (128, 3000, True), (64, 500, True)])
+def test_readout_pipelined_walk_is_bit_identical_to_the_plain_walk(n_feat, n_mols, ints):
+    """readout.hip: run bounds in registers, rows walked as one sequence of four-row rounds with two rounds in
+    flight (GCMI_OPT_READOUT_PIPELINED, the default) -- the same rows in the same order as the run-by-run walk, so
+    sums, maxima and the first-maximum arg-max agree bit for bit; single atoms, degree-10 atoms, empty molecules at
+    the end, integer features (ties everywhere)."""
+    import ctypes
+    from deepchem_amd import _lib, ops
+    cpu, g, x, n = make_batch(n_mols=n_mols, n_feat=n_feat, seed=29, int_features=ints)
+    v = ctypes.c_int32(-1)
+    _lib.call("gcmi_get_option", _lib.GCMI_OPT_READOUT_PIPELINED, ctypes.byref(v))
+    assert v.value == 1
+    got = {}
+    try:
+        for mode in (1, 0):
+            _lib.call("gcmi_set_option", _lib.GCMI_OPT_READOUT_PIPELINED, mode)
+            out, arg = ops.readout(g, x, n + 5, tanh=False)
+            got[mode] = (out.clone(), arg.clone())
+    finally:
+        _lib.call("gcmi_set_option", _lib.GCMI_OPT_READOUT_PIPELINED, 1)
+    assert torch.equal(got[1][0], got[0][0])
+    assert torch.equal(got[1][1], got[0][1])
+    ref = O.graph_gather(cpu[:3], n + 5, activation=None)
+    fin = torch.isfinite(ref)
+    assert rel(got[1][0].cpu()[fin], ref[fin]) < TOL
+
+
 def test_mol_runs_flag_for_unsorted_membership():
     from deepchem_amd.graph import BatchGraph
     dev = torch.device("cuda:0")
