@@ -52,11 +52,12 @@ mol_runs_kernel(DegTable t, int n_atoms, int n_mols, const int32_t* __restrict__
 
 // PRE (host: a lane group of 11..64 lanes inside one wave, one column chunk per lane): the molecule's run bounds
 // are fetched once, one run per lane, and handed round the group with cross-lane reads; the rows are then walked
-// as ONE sequence of four-row rounds across the runs, the loads of round k + 1 issued before round k is consumed.
+// as ONE sequence of four-row rounds across the runs, the loads of rounds k + 1 (and, DEPTH 3, k + 2) issued before
+// round k is consumed.
 // Same rows in the same order as the plain form (bit-identical sums, same first-maximum rule); what changes is the
 // number of dependent memory round trips per molecule: 1 + ceil(atoms / 4) with two rounds in flight, against one
 // per degree + one per four rows of every run, one at a time.
-template <int V, bool BN, bool PRE>
+template <int V, bool BN, bool PRE, int DEPTH = 2>
 __global__ void __launch_bounds__(kRBlock)
 readout_fwd_kernel(int n_mols, int n_deg, const int32_t* __restrict__ runs,
                    const float* __restrict__ x, int64_t ldx, int n_feat, int lpr, int gl,
@@ -146,13 +147,29 @@ readout_fwd_kernel(int n_mols, int n_deg, const int32_t* __restrict__ runs,
       issue(va, ia, an);
       // one exit, at the top: with a way out between the halves the compiler cannot count the loads in flight and
       // waits for all of them.  Inside, round B is never empty; the second A may be (at most one such per molecule)
-      while (rr < r1) {
-        issue(vb, ib, bn);
+      if constexpr (DEPTH == 2) {
+        while (rr < r1) {
+          issue(vb, ib, bn);
+          take(va, ia, an);
+          issue(va, ia, an);
+          take(vb, ib, bn);
+        }
         take(va, ia, an);
-        issue(va, ia, an);
+      } else {  // three rounds in flight
+        float vc[4][V];
+        int ic[4], cn = 0;
+        issue(vb, ib, bn);
+        while (rr < r1) {
+          issue(vc, ic, cn);
+          take(va, ia, an);
+          issue(va, ia, an);
+          take(vb, ib, bn);
+          issue(vb, ib, bn);
+          take(vc, ic, cn);
+        }
+        take(va, ia, an);
         take(vb, ib, bn);
       }
-      take(va, ia, an);
     } else
     for (int d = 0; d < n_deg; ++d) {
       const int r0 = rb[2 * d], r1 = rb[2 * d + 1];
@@ -374,7 +391,18 @@ int readout_fwd_impl(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t
   hipLaunchKernelGGL((readout_fwd_kernel<VV, BB, PP>), dim3(blocks), dim3(tb), 0, st, g->n_mols, \
                      n_deg, g->d_mol_runs, d_x, ldx, n_feat, lpr, gl, d_scale, d_shift, act,         \
                      d_out, ldo, d_arg, d_rawsum, vec_out)
-  if (V == 4 && pre) {
+  // rounds in flight: three (default; 179-181 us in the step) or two (GCMI_READOUT_DEPTH=2; 184-187 us)
+  static const int depth_env = getenv("GCMI_READOUT_DEPTH") ? atoi(getenv("GCMI_READOUT_DEPTH")) : 3;
+  if (V == 4 && pre && depth_env != 2) {
+    if (bn)
+      hipLaunchKernelGGL((readout_fwd_kernel<4, true, true, 3>), dim3(blocks), dim3(tb), 0, st, g->n_mols, n_deg,
+                         g->d_mol_runs, d_x, ldx, n_feat, lpr, gl, d_scale, d_shift, act, d_out, ldo, d_arg, d_rawsum,
+                         vec_out);
+    else
+      hipLaunchKernelGGL((readout_fwd_kernel<4, false, true, 3>), dim3(blocks), dim3(tb), 0, st, g->n_mols, n_deg,
+                         g->d_mol_runs, d_x, ldx, n_feat, lpr, gl, d_scale, d_shift, act, d_out, ldo, d_arg, d_rawsum,
+                         vec_out);
+  } else if (V == 4 && pre) {
     if (bn) LAUNCH_RO(4, true, true); else LAUNCH_RO(4, false, true);
   } else if (V == 4) {
     if (bn) LAUNCH_RO(4, true, false); else LAUNCH_RO(4, false, false);
