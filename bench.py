@@ -162,6 +162,49 @@ def usable_cores() -> int:
     return max(1, min(n, 64))
 
 
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak (MI355X_MICROARCH.md); fp32 matrix peak: 157.3
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def head_gemm_utilisation(device, args, iters: int = 50):
+    """BASELINE metric (iii): the post-readout task head (B, 256) x (256, tasks * classes) + bias -- the one product
+    of the path that is a plain dense GEMM -- timed alone with events on the stream the library
+    launches on, for the Tox21 head at this run's batch and the PCBA-shaped head (128 two-class tasks, 8 192
+    molecules per GPU).  ``tflops`` counts 2 B K n useful flops; ``mfma_frac`` prices them against what the matrix
+    pipe can deliver IN THIS ARITHMETIC: fast mode spends six bf16 MFMAs per fp32-equivalent product (peak / 6),
+    exact mode runs the fp32 MFMA.  The head reads B x 256 floats for 2 * 256 * n flops per row, so it is bound by
+    HBM (or, at small B, by the launch): ``hbm_frac`` is the fraction that matters."""
+    from deepchem_amd import ops
+    peak = MFMA_BF16_PEAK_TFLOPS / 6.0 if args.gemm_mode == "fast" else MFMA_F32_PEAK_TFLOPS
+    res = {"gemm_mode": args.gemm_mode, "mfma_peak_tflops_this_arithmetic": round(peak, 1)}
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    for name, rows, n_out in (("tox21", args.batch, args.tasks * 2), ("pcba", 8192, 256)):
+        a = torch.randn((rows, 256), generator=gen).to(device)
+        w = (torch.randn(256 * n_out, generator=gen) * 0.05).to(device)
+        b = torch.zeros(n_out, device=device)
+        o = torch.empty((rows, n_out), device=device)
+        run = lambda: ops.seg_gemm([0], [rows], a, w, [0], None, None, None, b, [0], n_out, False, False, rows,  # noqa: E731
+                                   k1=256, out=o)
+        for _ in range(5):
+            run()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        flops = 2.0 * rows * 256 * n_out
+        nbytes = 4.0 * (rows * (256 + n_out) + 256 * n_out + n_out)
+        res[name] = {"rows": rows, "k": 256, "n_out": n_out, "us": round(us, 2),
+                     "tflops": round(flops / (us * 1e-6) / 1e12, 2),
+                     "mfma_frac": round(flops / (us * 1e-6) / 1e12 / peak, 4),
+                     "GBps": round(nbytes / (us * 1e-6) / 1e9, 1),
+                     "hbm_frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                     "bound": "hbm" if flops / nbytes < peak * 1e12 / (HBM_PEAK_GBS * 1e9) else "mfma"}
+    return res
+
+
 def cpu_baseline(args, seconds, batch=100, faithful=True, grad_mode="reference"):
     """The oracle's training step (reference-faithful ops, reference gradient cut, Adam) at the
     reference's default batch size on pre-collated batches; threads = all host cores."""
@@ -474,6 +517,9 @@ def main():
             "frac_of_hbm_peak": round(fam_bytes[k] / (ktimes[k][1] / breakdown_steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)
             if ktimes[k][1] > 0 else 0.0}
         for k in ktimes}
+
+    if rank == 0 and world == 1:
+        out["head_gemm"] = head_gemm_utilisation(device, args)
 
     if rank == 0 and args.small_batch and world == 1:
         m2, b2, l2, w2 = make_workload(args, 0, device, args.small_batch)

@@ -193,9 +193,9 @@ def test_readout_pipelined_walk_is_bit_identical_to_the_plain_walk(n_feat, n_mol
     import ctypes
     from deepchem_amd import _lib, ops
     cpu, g, x, n = make_batch(n_mols=n_mols, n_feat=n_feat, seed=29, int_features=ints)
-    v = ctypes.c_int32(-1)
-    _lib.call("gcmi_get_option", _lib.GCMI_OPT_READOUT_PIPELINED, ctypes.byref(v))
-    assert v.value == 1
+    was = ctypes.c_int32(-1)
+    _lib.call("gcmi_get_option", _lib.GCMI_OPT_READOUT_PIPELINED, ctypes.byref(was))
+    assert was.value in (0, 1)  # 1 unless the process was started with GCMI_READOUT_PRE=0
     got = {}
     try:
         for mode in (1, 0):
@@ -203,7 +203,7 @@ def test_readout_pipelined_walk_is_bit_identical_to_the_plain_walk(n_feat, n_mol
             out, arg = ops.readout(g, x, n + 5, tanh=False)
             got[mode] = (out.clone(), arg.clone())
     finally:
-        _lib.call("gcmi_set_option", _lib.GCMI_OPT_READOUT_PIPELINED, 1)
+        _lib.call("gcmi_set_option", _lib.GCMI_OPT_READOUT_PIPELINED, was.value)
     assert torch.equal(got[1][0], got[0][0])
     assert torch.equal(got[1][1], got[0][1])
     ref = O.graph_gather(cpu[:3], n + 5, activation=None)
