@@ -633,7 +633,7 @@ int launch_seg_gemm4(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg
   if (d_stats && act == 2) return GCMI_ERR_UNSUPPORTED;
   const bool avec = !((d_a1 && (!aligned16(d_a1) || lda1 % 4)) || (d_a2 && (!aligned16(d_a2) || lda2 % 4)));
   if (n_out % 4 || ldo % 4 || !aligned16(d_out)) return GCMI_ERR_UNSUPPORTED;
-  const int nt = n_out <= 32 ? 1 : (n_out <= 64 ? 2 : 4);
+  int nt = n_out <= 32 ? 1 : (n_out <= 64 ? 2 : 4);
   SegTable3 st;
   memset(&st, 0, sizeof(st));
   st.n_seg = n_seg;
@@ -653,6 +653,11 @@ int launch_seg_gemm4(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg
   }
   st.tile_start[kS3MaxSeg] = (int32_t)tiles;
   if (tiles == 0) return GCMI_OK;
+  // Few row tiles (a per-molecule product: the task heads at a per-GPU batch of a few thousand molecules) leave most
+  // of the 256 CUs idle at 128 rows x 128 columns per workgroup: narrower column groups then, until the launch has a
+  // workgroup per CU.  The operand tile is read (from L2) and split once more per extra group; every output element
+  // is the same sum in the same order whatever the group width.
+  while (nt > 1 && tiles * ((n_out + nt * 32 - 1) / (nt * 32)) < 256) nt >>= 1;
   dim3 grid((unsigned)tiles, (unsigned)((n_out + nt * 32 - 1) / (nt * 32)));
   const int rev = next_sweep_direction();
 #define LAUNCH_S4(TT, NN)                                                                                      \
