@@ -518,7 +518,7 @@ def main():
             if ktimes[k][1] > 0 else 0.0}
         for k in ktimes}
 
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.profile_only:
         out["head_gemm"] = head_gemm_utilisation(device, args)
 
     if rank == 0 and args.small_batch and world == 1:
