@@ -722,6 +722,16 @@ int gcmi_seg_gemm_wgrad(int32_t n_seg, const int32_t* seg_begin, const int32_t* 
   slab = ((slab + 63) / 64) * 64;
   if (slab < 256) slab = 256;
   if (slab > 4096) slab = 4096;
+  {
+    // Few rows (the task head's weight gradient at a per-GPU batch of a few thousand molecules): 256-row slabs leave
+    // most CUs idle.  Smaller slabs, down to a floor, until the launch has a workgroup per CU; below the floor the
+    // k x n atomic adds every workgroup ends with outweigh its row loop.
+    static const int floor_env = getenv("GCMI_WGRAD_MIN_SLAB") ? atoi(getenv("GCMI_WGRAD_MIN_SLAB")) : 128;
+    const int64_t floor_rows = floor_env >= 64 && floor_env % 64 == 0 ? floor_env : 256;
+    const int nt_all = (n + 31) / 32;
+    const int64_t col_groups = nt_all >= 3 ? (nt_all + 3) / 4 : 1;
+    while (slab > floor_rows && ((total_rows + slab - 1) / slab + n_seg - 1) * col_groups < 256) slab -= 64;
+  }
   st.slab_rows = (int32_t)slab;
   int64_t slabs = 0;
   for (int s = 0; s < kMaxSeg; ++s) {
