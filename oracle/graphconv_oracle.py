@@ -147,20 +147,29 @@ def unsorted_segment_max(data: torch.Tensor, segment_ids: torch.Tensor, num_segm
             mask = expanded == i
             out[i] = torch.max(data.masked_fill(~mask, float("-inf")), dim=0)[0]
         return out
-    # stable sort keeps row order inside a segment => first-max tie rule holds
+    # O(N F) with the same values and the same gradient routing: rows grouped by segment with a STABLE sort (row order
+    # inside a segment kept), the segment maxima by one scatter-reduce, then -- per (segment, column) -- the first
+    # sorted position that attains the maximum, and ONE differentiable gather of those rows: the gradient reaches
+    # exactly the first maximal row, as torch.max(dim=0) over the masked rows does.  (A per-segment slice + max is
+    # O(N F) forward but its backward builds an N x F zero gradient per segment: 27 s per step at 4 096 molecules.)
+    n_rows = data.shape[0]
+    if n_rows == 0:
+        return torch.full(shape, float("-inf"), dtype=data.dtype)
+    flat = data.reshape(n_rows, -1)
     order = torch.argsort(segment_ids, stable=True)
-    sorted_ids = segment_ids[order]
-    counts = torch.bincount(sorted_ids, minlength=num_segments)
-    rows = []
-    start = 0
-    sdata = data[order]
-    for c in counts.tolist():
-        if c == 0:
-            rows.append(torch.full(shape[1:], float("-inf"), dtype=data.dtype))
-        else:
-            rows.append(torch.max(sdata[start:start + c], dim=0)[0])
-        start += c
-    return torch.stack(rows) if rows else torch.full(shape, float("-inf"), dtype=data.dtype)
+    sdata = flat[order]
+    sid = segment_ids[order].unsqueeze(-1).expand_as(sdata)
+    with torch.no_grad():
+        seg_max = torch.full((num_segments, flat.shape[1]), float("-inf"), dtype=data.dtype)
+        seg_max = seg_max.scatter_reduce(0, sid, sdata, "amax", include_self=True)
+        pos = torch.arange(n_rows).unsqueeze(-1).expand_as(sdata)
+        hit = torch.where(sdata == seg_max.gather(0, sid), pos, torch.full_like(pos, n_rows))
+        first = torch.full((num_segments, flat.shape[1]), n_rows, dtype=torch.int64)
+        first = first.scatter_reduce(0, sid, hit, "amin", include_self=True)
+        empty = first == n_rows
+    picked = sdata.gather(0, first.clamp(max=n_rows - 1))
+    out = torch.where(empty, torch.full_like(picked, float("-inf")), picked)
+    return out.reshape(shape)
 
 
 def graph_gather(inputs: Sequence[torch.Tensor], batch_size: int, activation=None,
