@@ -59,6 +59,9 @@ def parse():
                     help="only the large-batch steps (for rocprofv3 passes): no small-batch, fit or CPU legs")
     ap.add_argument("--small-batch", type=int, default=100,
                     help="also report mol/s at the reference's default batch size (0 = skip)")
+    ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"],
+                    help="activation storage of the timed step (the headline line is fp32; the default run adds a "
+                         "bf16-storage line item beside it; --storage bf16 --profile-only is for the rocprofv3 passes)")
     args = ap.parse_args()
     if args.profile_only:
         args.small_batch, args.fit_pipeline, args.no_cpu_baseline = 0, 0, True
@@ -74,14 +77,15 @@ def gather_sum_bytes(n_atoms, n_edges, n_deg0, feats, accumulate):
     return b
 
 
-def measured_traffic():
+def measured_traffic(storage="fp32"):
     """HBM bytes per gather-sum launch from the newest committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json:
     FETCH_SIZE x2 + WRITE_SIZE per the gfx950 corrections of MI355X_MICROARCH.md, separate passes, tools/pmc_passes.sh
     over THIS command with --profile-only) -- counters cannot be read from inside the process.  Returns
     (bytes per launch, file name) or (None, None)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")))
-    files = [f for f in files if "R1" not in os.path.basename(f)]
+    files = [f for f in files if "R1" not in os.path.basename(f) and (("bf16" in os.path.basename(f)) == (storage == "bf16"))]
+    measured_traffic.step_bytes = None
     for path in reversed(files):
         try:
             with open(path) as f:
@@ -90,7 +94,7 @@ def measured_traffic():
             continue
         tot, n = 0, 0
         for name, rec in kernels.items():
-            if "SumOp<false>" in name and "hbm_bytes_per_launch" in rec:  # the forward gather-sum launches
+            if ("SumOp<false>" in name or "SumOpH" in name or "SumOpFH" in name) and "hbm_bytes_per_launch" in rec:  # the forward gather-sum launches
                 k = rec.get("fetch_launches", 1)
                 tot += rec["hbm_bytes_per_launch"] * k
                 n += k
@@ -112,7 +116,7 @@ def measured_traffic():
 measured_traffic.step_bytes = None
 
 
-def make_workload(args, rank, device, batch):
+def make_workload(args, rank, device, batch, storage="fp32"):
     import deepchem_amd as dc
     from deepchem_amd.data.collate import collate_to_device
     from deepchem_amd.metrics import to_one_hot
@@ -126,7 +130,7 @@ def make_workload(args, rank, device, batch):
     model = dc.models.torch_models.GraphConvModel(args.tasks, number_input_features=[75, 64],
                                                   batch_size=batch, mode="classification",
                                                   grad_mode=args.grad_mode, device=device,
-                                                  learning_rate=1e-3, log_frequency=10**9)
+                                                  learning_rate=1e-3, log_frequency=10**9, activation_storage=storage)
     return model, dbatch, labels, weights
 
 
@@ -382,7 +386,7 @@ def main():
     from deepchem_amd._lib import (K_BATCHNORM, K_FUSED_BWD, K_GATHER_MAX, K_GATHER_MAX_BWD, K_GATHER_SUM, K_READOUT,
                                    K_SEG_GEMM, K_WGRAD)
 
-    model, dbatch, labels, weights = make_workload(args, rank, device, args.batch)
+    model, dbatch, labels, weights = make_workload(args, rank, device, args.batch, args.storage)
     if world > 1:
         from deepchem_amd.dist import shard_model
         shard_model(model)
@@ -436,7 +440,13 @@ def main():
         launches_per_step = 3
     n_launch, ms = gather_time
     achieved = (per_step * args.steps) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    traffic, traffic_file = measured_traffic()
+    traffic, traffic_file = measured_traffic(args.storage)
+    h = args.storage == "bf16"
+    if h:  # bf16 rows: 2 bytes per gathered / written element ("replace 4 F by 2 F for feature reads")
+        e_b = lambda f: 2 * f
+        per_step = (g.n_edges * (4 * 76 + 4) + g.n_atoms * (2 * e_b(80))) + \
+                   (g.n_edges * (e_b(64) + 4) + g.n_atoms * e_b(64))
+        achieved = (per_step * args.steps) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
 
     out = {
         "metric": "molecules/sec fwd+bwd GraphConvModel",
@@ -449,7 +459,7 @@ def main():
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "f32" if not h else "f32 (bf16 activation storage)",
         "data": "synthetic",
         "config": {
             "workload": "Tox21-like synthetic molecules (18.2 atoms/mol, E/N 2.08), 12 binary tasks, "
@@ -463,8 +473,9 @@ def main():
             "parallelism": "dp%d (molecules sharded by rank, one flat all-reduce per step)" % world,
         },
         "roofline": {
-            "kernel": "win_kernel<512, {16|19}, false, SumOp<false>> (gather_lds.hip: GraphConv.sum_neigh over LDS "
-                      "molecule windows, forward of both layers)",
+            "kernel": ("win_kernel<512, {16|19}, false, SumOp<false>> (gather_lds.hip: GraphConv.sum_neigh over LDS "
+                       "molecule windows, forward of both layers)") if not h else
+                      "win_kernel<512, 19, false, SumOpFH> + win_kernel<512, 8, false, SumOpH> (bf16 rows)",
             "bound": "hbm",
             "achieved": round(achieved, 1),
             "peak": HBM_PEAK_GBS,
@@ -520,6 +531,43 @@ def main():
 
     if rank == 0 and world == 1 and not args.profile_only:
         out["head_gemm"] = head_gemm_utilisation(device, args)
+
+    if rank == 0 and world == 1 and not args.profile_only and args.storage == "fp32" and args.gemm_mode == "fast":
+        # BASELINE config 2 "bf16/fp32": the SAME step with every activation the step writes and reads back stored as
+        # bf16 (gcmi_model_* storage = 1; fp32 arithmetic, parameters, gradients, Adam) -- beside the f32 headline,
+        # never instead of it
+        mb, db, lb, wb = make_workload(args, rank, device, args.batch, "bf16")
+        run_steps(mb, db, lb, wb, max(args.warmup, 1))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(mb, db, lb, wb, args.steps)
+        torch.cuda.synchronize()
+        wall_b = time.perf_counter() - t1
+        for kid in kernel_ids.values():
+            ops.timing_enable(kid, True)
+            ops.timing_read(kid, reset=True)
+        run_steps(mb, db, lb, wb, breakdown_steps)
+        torch.cuda.synchronize()
+        kt_b = {name: ops.timing_read(kid, reset=True) for name, kid in kernel_ids.items()}
+        for kid in kernel_ids.values():
+            ops.timing_enable(kid, False)
+        tb, tb_file = measured_traffic("bf16")
+        item = {"dtype": "bf16-storage", "value": round(args.batch * args.steps / wall_b, 1), "unit": "molecules/s",
+                "ms_per_step": round(wall_b / args.steps * 1e3, 4), "steps": args.steps,
+                "what": "atom-feature copy, neighbour sums, GraphConv outputs, pooled rows and the dense output stored as "
+                        "bfloat16 (one rounding per stored element); fp32 accumulation, fp64 BatchNorm sums of the "
+                        "rounded values, fp32 parameters / gradients / gradient streams / Adam",
+                "kernel_ms_per_step": {k: round(v[1] / breakdown_steps, 4) for k, v in kt_b.items()}}
+        if measured_traffic.step_bytes:
+            sb = measured_traffic.step_bytes
+            item["step_traffic"] = {"hbm_bytes_per_step": sb, "source": tb_file,
+                                    "achieved": round(sb / (wall_b / args.steps) / 1e9, 1), "unit": "GB/s",
+                                    "frac_of_hbm_peak": round(sb / (wall_b / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
+        else:
+            item["step_traffic"] = None
+        out["bf16_storage"] = item
+        del mb, db, lb, wb
+        measured_traffic(args.storage)
 
     if rank == 0 and args.small_batch and world == 1:
         m2, b2, l2, w2 = make_workload(args, 0, device, args.small_batch)

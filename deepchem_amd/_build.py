@@ -11,7 +11,7 @@ import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libgcmi.so")
-SOURCES = ["core.cpp", "collate.cpp", "featurize.cpp", "gather.hip", "gather_lds.hip", "readout.hip", "bn.hip", "gemm.hip", "gemm_split.hip", "bwd_fused.hip", "fwd_fused.hip", "head_bwd.hip", "loss.hip", "weave.hip", "mpnn.hip", "model.hip", "smallstep.hip"]
+SOURCES = ["core.cpp", "collate.cpp", "featurize.cpp", "gather.hip", "gather_lds.hip", "readout.hip", "bn.hip", "gemm.hip", "gemm_split.hip", "bwd_fused.hip", "fwd_fused.hip", "fwd_bf16.hip", "head_bwd.hip", "loss.hip", "weave.hip", "mpnn.hip", "model.hip", "smallstep.hip"]
 ARCH = "gfx950"
 
 
@@ -35,8 +35,8 @@ def build_lib(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
     for src in SOURCES:
         obj = os.path.join(CSRC, "build", src.rsplit(".", 1)[0] + ".o")
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-x", "hip",
-               "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-x", "hip"] + \
+            os.environ.get("GCMI_EXTRA_HIPCC_FLAGS", "").split() + ["-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
         objs.append(obj)
     for src, p in procs:

@@ -182,6 +182,8 @@ _SIGNATURES = {
                         c_int64, _P, c_int64],
     "gcmi_small_fit": [_MD, _P, _P, _P, _P, _MIO, _P, c_int64, c_int64, c_int64, c_float, c_float, c_float, c_float,
                        c_int64, _P, _I64P, _I64P, _P],
+    "gcmi_small_fit_dp": [_MD, _P, _P, _P, _P, _MIO, _P, c_int64, c_int64, c_int64, c_float, c_float, c_float, c_float,
+                          c_int64, _P, _I64P, _I64P, _P, _P, _P],
     "gcmi_small_predict": [_MD, _P, _MIO, _P, c_int64, c_int64, c_int64, _P],
     "gcmi_diag_mfma_peak": [c_int32, c_int32, _P, _P],
     "gcmi_set_option": [c_int32, c_int32],

@@ -12,6 +12,7 @@
 // scale/shift on the fly, so the normalised tensor is never written to HBM.
 // Bound: HBM, N*4F bytes read per pass.
 #include "common.h"
+#include "split_bf16.h"
 
 namespace gcmi {
 
@@ -59,7 +60,8 @@ __device__ __forceinline__ void readout_dy(const ReadoutGrad& rg, int64_t r, int
 // sums[0:F] += sum_r a[r,:],  sums[F:2F] += sum_r a[r,:]*b[r,:]
 // MODE 0: b = a (sum of squares).  MODE 1: b = (x - mean)*invstd (x given), a = dy.
 // MODE 2: as MODE 1 with dy recomputed from the readout gradient (rg) instead of read from a.
-template <int V, int MODE>
+// XH (V == 4, MODE 1): x is stored as bf16 (gcmi_model_desc.storage == 1; ldx counts elements).
+template <int V, int MODE, bool XH = false>
 __global__ void __launch_bounds__(kBBlock)
 col_sums_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ x, int64_t ldx,
                 const float* __restrict__ mean, const float* __restrict__ invstd, int64_t n_rows,
@@ -92,7 +94,9 @@ col_sums_kernel(const float* __restrict__ a, int64_t lda, const float* __restric
           t.av[u][0] = t4.x; t.av[u][1] = t4.y; t.av[u][2] = t4.z; t.av[u][3] = t4.w;
         }
         if (MODE >= 1) {
-          const float4 u4 = *reinterpret_cast<const float4*>(x + rc * ldx + c);
+          float4 u4;
+          if constexpr (XH) u4 = widen4(*reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(x) + rc * ldx + c));
+          else u4 = *reinterpret_cast<const float4*>(x + rc * ldx + c);
           t.xv[u][0] = u4.x; t.xv[u][1] = u4.y; t.xv[u][2] = u4.z; t.xv[u][3] = u4.w;
         }
       } else {
@@ -331,7 +335,7 @@ bn_bwd_dx_kernel(const float* __restrict__ dy, int64_t lddy, const float* __rest
 static int launch_col_sums(int mode, const float* a, int64_t lda, const float* x, int64_t ldx,
                            const float* mean, const float* invstd, int64_t n_rows, int n_feat,
                            double* sums, bool acc_clean, hipStream_t st, const ReadoutGrad* rgp = nullptr,
-                           const float* only_if_gamma = nullptr, const float* only_if_beta = nullptr) {
+                           const float* only_if_gamma = nullptr, const float* only_if_beta = nullptr, bool x_bf16 = false) {
   if (!acc_clean &&
       hipMemsetAsync(sums, 0, sizeof(double) * 2 * n_feat * (1 + kReplicas), st) != hipSuccess) {
     set_error("bn: memset failed");
@@ -344,6 +348,12 @@ static int launch_col_sums(int mode, const float* a, int64_t lda, const float* x
     rg = *rgp;
     mode = 2;
     V = (vec_width(x, ldx, n_feat) == 4 && aligned16(rg.g2) && rg.ldg2 % 4 == 0 && aligned16(rg.arg)) ? 4 : 1;
+  } else if (x_bf16) {
+    if (mode != 1 || vec_width(a, lda, n_feat) != 4 || (reinterpret_cast<uintptr_t>(x) & 7u) || ldx % 4) {
+      set_error("bn col_sums: bf16 rows need mode 1 and 8-byte addressable rows");
+      return GCMI_ERR_UNSUPPORTED;
+    }
+    V = 4;
   } else {
     V = vec_width(a, lda, n_feat);
     if (mode == 1 && vec_width(x, ldx, n_feat) != 4) V = 1;
@@ -361,7 +371,10 @@ static int launch_col_sums(int mode, const float* a, int64_t lda, const float* x
 #define LAUNCH_CS(VV, MM)                                                                     \
   hipLaunchKernelGGL((col_sums_kernel<VV, MM>), dim3(blocks), dim3(kBBlock), 0, st, a, lda, x, \
                      ldx, mean, invstd, n_rows, rpb, n_feat, lpr, lx, sums, rg, rev, only_if_gamma, only_if_beta)
-  if (V == 4) {
+  if (x_bf16) {
+    hipLaunchKernelGGL((col_sums_kernel<4, 1, true>), dim3(blocks), dim3(kBBlock), 0, st, a, lda, x, ldx, mean, invstd,
+                       n_rows, rpb, n_feat, lpr, lx, sums, rg, rev, only_if_gamma, only_if_beta);
+  } else if (V == 4) {
     if (mode == 0) LAUNCH_CS(4, 0); else if (mode == 1) LAUNCH_CS(4, 1); else LAUNCH_CS(4, 2);
   } else {
     if (mode == 0) LAUNCH_CS(1, 0); else if (mode == 1) LAUNCH_CS(1, 1); else LAUNCH_CS(1, 2);
@@ -594,14 +607,14 @@ __global__ void bn_bwd_params_pool_kernel(double* __restrict__ psums, double* __
 
 int bn_bwd_pool_impl(const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat,
                      const float* d_gamma, const float* d_beta, const float* d_mean, const float* d_invstd,
-                     float* d_dgamma, float* d_dbeta, double* d_psums, double* d_acc, void* stream) {
+                     float* d_dgamma, float* d_dbeta, double* d_psums, double* d_acc, void* stream, int32_t x_bf16) {
   GCMI_CHECK_ARG(n_feat > 0 && n_rows > 0 && d_mean && d_invstd && d_acc && d_psums && d_x && d_gamma && d_beta,
                  "bn_bwd_pool: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   TimedScope ts(GCMI_K_BATCHNORM, st);
   if (d_dy != nullptr) {
     const int rc = launch_col_sums(1, d_dy, lddy, d_x, ldx, d_mean, d_invstd, n_rows, n_feat, d_acc, true, st, nullptr,
-                                   d_gamma, d_beta);
+                                   d_gamma, d_beta, x_bf16 != 0);
     if (rc) return rc;
   }
   static_assert(kReplicas == 32, "bn_bwd_params_pool_kernel: one lane per replica");

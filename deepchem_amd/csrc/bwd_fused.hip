@@ -19,6 +19,7 @@
 // v_mfma_f32_32x32x16_bf16, fp32 accumulation).  A block that needs no input gradient (the first GraphConv) runs
 // the four weight-gradient waves only.
 #include <atomic>
+#include <type_traits>
 
 #include "common.h"
 #include "split_bf16.h"
@@ -70,7 +71,12 @@ struct FusedArgs {
   unsigned long long* diag;
 };
 
-template <int NG, int KT, int NOPS, bool TRANS, bool RD, bool DGRAD>
+// HB: the block's forward activations (x = its ReLU output, In = its inputs) are stored as bf16
+// (gcmi_model_desc.storage == 1): they arrive as 8-byte pieces of four elements -- half the prefetch registers -- and
+// are widened on their way to LDS; a weight-gradient fragment of In then IS its own first bf16 piece (one v_perm_b32
+// per pair instead of the three-way split) and meets the three pieces of G in 3 MFMAs instead of 6.  Gradients (dy,
+// the outputs) stay fp32.
+template <int NG, int KT, int NOPS, bool TRANS, bool RD, bool DGRAD, bool HB = false>
 __global__ void __launch_bounds__(DGRAD ? 512 : 256) __attribute__((amdgpu_waves_per_eu(2)))
 fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
   constexpr int NT = DGRAD ? 512 : 256;
@@ -157,7 +163,17 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
 
   // ---- prefetch registers (one tile ahead; the molecule index two tiles ahead): all loads are 16 bytes per lane,
   // unconditional, from clamped addresses; what lies outside the tile is zeroed when it goes to LDS
-  float4 pdy[GPASS], px[GPASS], pgm[RD ? GPASS : 1], pin[NOPS][IPASS];
+  using ActV = typename std::conditional<HB, uint2, float4>::type;  // four stored activations
+  auto load_act = [](const float* base, unsigned elem) -> ActV {
+    if constexpr (HB) return *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(base) + elem);
+    else return *reinterpret_cast<const float4*>(base + elem);
+  };
+  auto act4 = [](const ActV& v) -> float4 {
+    if constexpr (HB) return widen4(v);
+    else return v;
+  };
+  float4 pdy[GPASS], pgm[RD ? GPASS : 1];
+  ActV px[GPASS], pin[NOPS][IPASS];
   int4 parg[RD ? GPASS : 1];
   int mem1[RD ? GPASS : 1];
   auto clampr = [](int r, int valid) { return r < valid ? r : valid - 1; };
@@ -171,7 +187,7 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
 #pragma unroll
     for (int p = 0; p < GPASS; ++p) {
       const unsigned r = (unsigned)(row0 + clampr(gr + p * RPP, valid));
-      px[p] = *reinterpret_cast<const float4*>(a.x + (r * (unsigned)a.ldx + 4u * gq));
+      px[p] = load_act(a.x, r * (unsigned)a.ldx + 4u * gq);
       if constexpr (RD) {
         const unsigned m = (unsigned)mem1[p];
         pdy[p] = *reinterpret_cast<const float4*>(a.g2 + (m * (unsigned)a.ldg2 + 4u * gq));
@@ -189,7 +205,7 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
         const int r = slot / IQ, q = slot - r * IQ;
         const int ld = a.ldin[o];
         const int qc = 4 * q + 4 <= ld ? 4 * q : 0;
-        pin[o][p] = *reinterpret_cast<const float4*>(a.in[o] + ((unsigned)(row0 + clampr(r, valid)) * (unsigned)ld + qc));
+        pin[o][p] = load_act(a.in[o], (unsigned)(row0 + clampr(r, valid)) * (unsigned)ld + qc);
       }
     }
   };
@@ -349,7 +365,8 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
     for (int p = 0; p < GPASS; ++p) {
       const int r = gr + p * RPP;
       float dyv[4] = {pdy[p].x, pdy[p].y, pdy[p].z, pdy[p].w};
-      const float xv[4] = {px[p].x, px[p].y, px[p].z, px[p].w};
+      const float4 x4 = act4(px[p]);
+      const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
       if constexpr (RD) {
         const int rg = row0 + r;
         const float gm[4] = {pgm[p].x, pgm[p].y, pgm[p].z, pgm[p].w};
@@ -377,7 +394,7 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
         const int slot = tid + p * NT;
         const int r = slot / IQ, q = slot - r * IQ;
         const int tail = a.k_in - 4 * q;
-        float4 v = pin[o][p];
+        float4 v = act4(pin[o][p]);
         const bool ok = r < valid;
         v.x = (ok && tail > 0) ? v.x : 0.f;
         v.y = (ok && tail > 1) ? v.y : 0.f;
@@ -502,10 +519,37 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
           for (int u = 0; u < 8; ++u) bsum += raw[u];
         }
         unsigned q[3][4];
+        const bool next_is_g = (f + 1) % FPS == 0;  // (compile-time under the unrolling)
         auto pair_split = [&](int i) {
-          if (more) split3_pair(raw[2 * i], raw[2 * i + 1], q[0][i], q[1][i], q[2][i]);
+          if (!more) return;
+          if (HB && !next_is_g) {  // a fragment of stored bf16 values: exact in one piece
+            q[0][i] = pack_exact_bf16x2(raw[2 * i], raw[2 * i + 1]);
+            q[1][i] = q[2][i] = 0u;
+          } else {
+            split3_pair(raw[2 * i], raw[2 * i + 1], q[0][i], q[1][i], q[2][i]);
+          }
         };
-        if (w_ != 0 && on) {  // uniform
+        if (HB && w_ != 0 && on) {  // uniform: In in one piece x G in three
+          const int t = w_ - 1;
+          const Frag3& L = TRANS ? fg : cur;
+          const Frag3& R = TRANS ? cur : fg;
+          // (In is `cur`: TRANS -> the right operand R.p[0], else the left operand L.p[0]; small terms first)
+          accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(TRANS ? L.p[2] : L.p[0]),
+                                                            as_bf16x8(TRANS ? R.p[0] : R.p[2]), accs[t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          pair_split(0);
+          pair_split(1);
+          __builtin_amdgcn_sched_barrier(0);
+          accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(TRANS ? L.p[1] : L.p[0]),
+                                                            as_bf16x8(TRANS ? R.p[0] : R.p[1]), accs[t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          pair_split(2);
+          pair_split(3);
+          __builtin_amdgcn_sched_barrier(0);
+          if (more && f + 2 < NF) read_frag(f + 2);  // `raw` is free: the reads of the fragment after next
+          __builtin_amdgcn_sched_barrier(0);
+          accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(L.p[0]), as_bf16x8(R.p[0]), accs[t], 0, 0, 0);
+        } else if (w_ != 0 && on) {  // uniform
           const int t = w_ - 1;
           const Frag3& L = TRANS ? fg : cur;
           const Frag3& R = TRANS ? cur : fg;
@@ -569,6 +613,17 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
           fg = split_frag(raw[f & 1]);
         } else if (on) {  // uniform
           const int t = w_ - 1;
+          if constexpr (HB) {  // In in one exact piece x G in three
+            u32x4 fi;
+            fi.x = pack_exact_bf16x2(raw[f & 1][0], raw[f & 1][1]); fi.y = pack_exact_bf16x2(raw[f & 1][2], raw[f & 1][3]);
+            fi.z = pack_exact_bf16x2(raw[f & 1][4], raw[f & 1][5]); fi.w = pack_exact_bf16x2(raw[f & 1][6], raw[f & 1][7]);
+#pragma unroll
+            for (int pc = 2; pc >= 0; --pc)
+              accs[t] = TRANS ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[pc]), as_bf16x8(fi), accs[t], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fi), as_bf16x8(fg.p[pc]), accs[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            continue;
+          }
           const Frag3 fa = split_frag(raw[f & 1]);
           const Frag3& L = TRANS ? fg : fa;
           const Frag3& R = TRANS ? fa : fg;
@@ -622,13 +677,13 @@ void set_fused_bwd(int on) { g_fused_bwd.store(on ? 1 : 0, std::memory_order_rel
 int get_fused_bwd() { return g_fused_bwd.load(std::memory_order_relaxed); }
 bool fused_bwd_enabled() { return fused_bwd_on() && get_fused_bwd() != 0 && !gemm_exact_mode(); }
 
-template <int NG, int KT, int NOPS, bool TRANS, bool RD, bool DGRAD>
+template <int NG, int KT, int NOPS, bool TRANS, bool RD, bool DGRAD, bool HB = false>
 static int launch_fused(const FusedTable& st, int n_tiles, const FusedArgs& a, hipStream_t sm) {
   constexpr int KP = KT * 32;
   size_t shmem = sizeof(float) * kFRows * (NG + 4) + sizeof(float) * (size_t)NOPS * kFRows * (KP + 4);
   if (DGRAD)
     shmem += sizeof(unsigned short) * (size_t)NOPS * 3 * KP * (NG + 8) + sizeof(float) * kFRows * (NOPS * KT * 32 + 8);
-  auto kern = fused_bwd_kernel<NG, KT, NOPS, TRANS, RD, DGRAD>;
+  auto kern = fused_bwd_kernel<NG, KT, NOPS, TRANS, RD, DGRAD, HB>;
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
     // exactly what is asked for: the kernel also has a few hundred bytes of static LDS (the segment table)
@@ -690,7 +745,7 @@ int fused_conv_bwd(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
                    const int64_t* w_self, const int64_t* b_off, const float* d_dy, int64_t lddy, const float* d_gc,
                    int64_t ldgc, const float* d_coef, int32_t width, const float* d_s, int64_t lds, const float* d_x,
                    int64_t ldx, int32_t k_in, const float* d_w, float* d_dw, float* d_dbsum, float* d_ds_out,
-                   int64_t ldds, float* d_dxs_out, int64_t lddxs, double* d_psums, hipStream_t sm) {
+                   int64_t ldds, float* d_dxs_out, int64_t lddxs, double* d_psums, hipStream_t sm, int32_t act_bf16) {
   if (!fused_bwd_enabled() || n_seg > kFMaxSeg || width != 64) return GCMI_ERR_UNSUPPORTED;
   {  // 32-bit element offsets inside the kernel: every array below 2^30 elements
     int64_t rows = 0;
@@ -700,6 +755,8 @@ int fused_conv_bwd(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
   }
   if (!aligned16(d_dy) || lddy % 4 || !aligned16(d_gc) || ldgc % 4) return GCMI_ERR_UNSUPPORTED;
   if (d_coef && !aligned16(d_coef)) return GCMI_ERR_UNSUPPORTED;
+  // (act_bf16: d_gc, d_s and d_x point to bf16 rows, their leading dimensions count elements; 8-byte pieces)
+  if (act_bf16 && (!aligned16(d_s) || lds % 4 || !aligned16(d_x) || ldx % 4)) return GCMI_ERR_UNSUPPORTED;
   const bool dgrad = d_ds_out != nullptr;
   FusedTable st;
   const int tiles = make_table(n_seg, seg_begin, seg_end, w_rel, w_self, b_off, &st);
@@ -713,11 +770,17 @@ int fused_conv_bwd(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
   a.psums = dgrad ? d_psums : nullptr;
   if (dgrad) {
     if (k_in % 4 || ldds % 4 || lddxs % 4 || !aligned16(d_ds_out) || !aligned16(d_dxs_out)) return GCMI_ERR_UNSUPPORTED;
-    if (k_in > 32 && k_in <= 64) return launch_fused<64, 2, 2, false, false, true>(st, tiles, a, sm);
+    if (k_in > 32 && k_in <= 64)
+      return act_bf16 ? launch_fused<64, 2, 2, false, false, true, true>(st, tiles, a, sm)
+                      : launch_fused<64, 2, 2, false, false, true>(st, tiles, a, sm);
     return GCMI_ERR_UNSUPPORTED;
   }
-  if (k_in > 32 && k_in <= 64) return launch_fused<64, 2, 2, false, false, false>(st, tiles, a, sm);
-  if (k_in > 64 && k_in <= 96) return launch_fused<64, 3, 2, false, false, false>(st, tiles, a, sm);
+  if (k_in > 32 && k_in <= 64)
+    return act_bf16 ? launch_fused<64, 2, 2, false, false, false, true>(st, tiles, a, sm)
+                    : launch_fused<64, 2, 2, false, false, false>(st, tiles, a, sm);
+  if (k_in > 64 && k_in <= 96)
+    return act_bf16 ? launch_fused<64, 3, 2, false, false, false, true>(st, tiles, a, sm)
+                    : launch_fused<64, 3, 2, false, false, false>(st, tiles, a, sm);
   return GCMI_ERR_UNSUPPORTED;
 }
 
@@ -726,7 +789,7 @@ int fused_conv_bwd(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
 int fused_dense_bwd(int64_t n_rows, const int32_t* d_membership, const float* d_g2, int64_t ldg2,
                     const int32_t* d_arg, const float* d_dense, int64_t ldd, const float* d_coef, int32_t width,
                     const float* d_p, int64_t ldp, int32_t k_in, const float* d_w, float* d_dw, float* d_db,
-                    float* d_dp, int64_t lddp, double* d_psums, hipStream_t sm) {
+                    float* d_dp, int64_t lddp, double* d_psums, hipStream_t sm, int32_t act_bf16) {
   if (!fused_bwd_enabled() || width != 128 || k_in <= 32 || k_in > 64 || d_coef == nullptr) return GCMI_ERR_UNSUPPORTED;
   if (!aligned16(d_g2) || ldg2 % 4 || !aligned16(d_arg) || !aligned16(d_dense) || ldd % 4 || !aligned16(d_coef))
     return GCMI_ERR_UNSUPPORTED;
@@ -744,6 +807,10 @@ int fused_dense_bwd(int64_t n_rows, const int32_t* d_membership, const float* d_
   a.w = d_w; a.dw = d_dw; a.db = d_db;
   a.dout[0] = d_dp; a.lddout[0] = (int32_t)lddp;
   a.psums = d_psums;
+  if (act_bf16) {  // d_dense and d_p point to bf16 rows
+    if (!aligned16(d_p) || ldp % 4) return GCMI_ERR_UNSUPPORTED;
+    return launch_fused<128, 2, 1, true, true, true, true>(st, tiles, a, sm);
+  }
   return launch_fused<128, 2, 1, true, true, true>(st, tiles, a, sm);
 }
 

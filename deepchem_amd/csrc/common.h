@@ -90,12 +90,26 @@ int win_gather_max_bwd_stats(const gcmi_graph* g, const float* d_dout, int64_t l
 // unless the test below says so.  d_dy may be NULL when the caller never produces it (then the direct sums are too).
 int bn_bwd_pool_impl(const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat,
                      const float* d_gamma, const float* d_beta, const float* d_mean, const float* d_invstd,
-                     float* d_dgamma, float* d_dbeta, double* d_psums, double* d_acc, void* stream);
+                     float* d_dgamma, float* d_dbeta, double* d_psums, double* d_acc, void* stream, int32_t x_bf16 = 0);
 int win_gather_max_bwd_if_ill(const gcmi_graph* g, const float* d_dout, int64_t lddo, int n_feat, const uint8_t* d_arg,
                               float* d_dx, int64_t lddx, const float* d_gamma, const float* d_beta, hipStream_t st);
 // the part of the BatchNorm backward after its column sums (dgamma, dbeta, coefficient vectors at the head of d_acc)
 int bn_bwd_params_impl(int64_t n_rows, int32_t n_feat, const float* d_gamma, const float* d_mean,
                        const float* d_invstd, float* d_dgamma, float* d_dbeta, double* d_acc, void* stream);
+
+// ---- bf16 activation storage (gcmi_model_desc.storage == 1): raw 16-bit patterns, leading dimensions in elements
+bool win_usable_h(const gcmi_graph* g, int n_feat);
+int win_gather_sum_fh(const gcmi_graph* g, const float* d_x, int64_t ldx, int n_feat, unsigned short* d_s,
+                      unsigned short* d_xcopy, int64_t ldo, hipStream_t st);
+int win_gather_sum_h(const gcmi_graph* g, const unsigned short* d_x, int64_t ldx, int n_feat, unsigned short* d_s,
+                     int64_t lds, hipStream_t st);
+int win_gather_max_h(const gcmi_graph* g, const unsigned short* d_x, int64_t ldx, int n_feat, const float* d_scale,
+                     const float* d_shift, unsigned short* d_out, int64_t ldo, uint8_t* d_arg, hipStream_t st);
+// fwd_bf16.hip: forward product over bf16 operands, bf16 output, BatchNorm sums of the rounded output
+int fwd_h_gemm(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_end, const unsigned short* d_a1, int64_t lda1,
+               int32_t k1, const float* d_w1, const int64_t* w1_off, const unsigned short* d_a2, int64_t lda2, int32_t k2,
+               const float* d_w2, const int64_t* w2_off, const float* d_bias, const int64_t* bias_off, int32_t n_out,
+               int32_t trans_w, int32_t act, unsigned short* d_out, int64_t ldo, double* d_stats, hipStream_t sm);
 
 bool gemm_exact_mode();  // gcmi_set_option(GCMI_OPT_GEMM_EXACT)
 
@@ -139,11 +153,11 @@ int fused_conv_bwd(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
                    const int64_t* w_self, const int64_t* b_off, const float* d_dy, int64_t lddy, const float* d_gc,
                    int64_t ldgc, const float* d_coef, int32_t width, const float* d_s, int64_t lds, const float* d_x,
                    int64_t ldx, int32_t k_in, const float* d_w, float* d_dw, float* d_dbsum, float* d_ds_out,
-                   int64_t ldds, float* d_dxs_out, int64_t lddxs, double* d_psums, hipStream_t sm);
+                   int64_t ldds, float* d_dxs_out, int64_t lddxs, double* d_psums, hipStream_t sm, int32_t act_bf16 = 0);
 int fused_dense_bwd(int64_t n_rows, const int32_t* d_membership, const float* d_g2, int64_t ldg2,
                     const int32_t* d_arg, const float* d_dense, int64_t ldd, const float* d_coef, int32_t width,
                     const float* d_p, int64_t ldp, int32_t k_in, const float* d_w, float* d_dw, float* d_db,
-                    float* d_dp, int64_t lddp, double* d_psums, hipStream_t sm);
+                    float* d_dp, int64_t lddp, double* d_psums, hipStream_t sm, int32_t act_bf16 = 0);
 
 // fwd_fused.hip: the forward product of a block as persistent workgroups with resident weight images (default widths,
 // split-bf16 mode); GCMI_ERR_UNSUPPORTED = shape not covered
@@ -175,7 +189,7 @@ int seg_gemm_stats(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
 // gcmi_readout_fwd that also leaves the per-molecule sums of the rows before the folded BatchNorm in d_rawsum
 int readout_fwd_impl(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t n_feat, const float* d_scale,
                      const float* d_shift, int32_t act, float* d_out, int64_t ldo, int32_t* d_arg, float* d_rawsum,
-                     void* stream);
+                     void* stream, int32_t x_bf16 = 0);
 // the part of bn_stats_impl after the column sums
 int bn_finalize_impl(int64_t n_rows, int32_t n_feat, const float* d_gamma, const float* d_beta, float eps,
                      float momentum, float* d_running_mean, float* d_running_var, float* d_mean, float* d_invstd,

@@ -17,6 +17,7 @@
 // N*4F + 2E + N*4F: each row is read ONCE; the (1+E/N)-fold re-reads are served by LDS.  The
 // algorithmic figure of SURVEY.md 8d is therefore delivered above the HBM roofline.
 #include "common.h"
+#include "split_bf16.h"
 
 namespace gcmi {
 
@@ -104,9 +105,10 @@ struct Layout {
 
 // Issue the LDS-DMA of one window: rows of `x` (and of the byte matrix `aux`, F bytes per row)
 // and the window's neighbour entries.  Nothing waits here.
+// (x: rows of LPR 16-byte pieces -- 4 floats or 8 bf16 each --, ldx in BYTES: the DMA moves bytes, not elements)
 template <int WT, int LPR, bool AUX>
 __device__ __forceinline__ void stage(char* buf, const Layout& L, const WinMeta& m,
-                                      const float* __restrict__ x, int64_t ldx,
+                                      const char* __restrict__ x, int64_t ldx,
                                       const uint8_t* __restrict__ aux,
                                       const uint16_t* __restrict__ edges) {
   const int tid = threadIdx.x;
@@ -119,7 +121,7 @@ __device__ __forceinline__ void stage(char* buf, const Layout& L, const WinMeta&
       const int slot = e / LPR;
       const int c = e - slot * LPR;
       const int row = row_of_slot(m, L.maxd, slot);
-      glds16(x + (int64_t)row * ldx + c * 4, base + e0 * 16);
+      glds16(x + (int64_t)row * ldx + c * 16, base + e0 * 16);
       if (AUX) glds4(aux + (int64_t)row * (LPR * 4) + c * 4, base + L.tile_bytes + e0 * 4);
     }
   }
@@ -147,6 +149,7 @@ struct SumOp {
   int64_t lds;
   using State = NoState;
   static constexpr bool kExtraTile = false;
+  static constexpr int kEPP = 4;  // elements per 16-byte piece of a tile row
   __device__ __forceinline__ bool skip(int) const { return false; }
   template <int WT>
   __device__ __forceinline__ void init(float*, int, State&) const {}
@@ -199,6 +202,7 @@ struct MaxOp {
   int64_t ldo;
   uint8_t* __restrict__ arg;
   static constexpr bool kExtraTile = false;
+  static constexpr int kEPP = 4;
   // the folded BatchNorm vectors live in LDS: a global load in the compute phase would make the
   // compiler wait for the LDS-DMA in flight as well
   using State = NoState;
@@ -274,6 +278,7 @@ struct MaxBwdOp {
   const float* __restrict__ only_if_gamma;
   const float* __restrict__ only_if_beta;
   static constexpr bool kExtraTile = false;
+  static constexpr int kEPP = 4;
   __device__ __forceinline__ bool skip(int n_feat) const {
     return only_if_gamma != nullptr && !bn_pool_ill_conditioned(only_if_gamma, only_if_beta, n_feat);
   }
@@ -389,6 +394,7 @@ struct SumAccMaxBwdOp {
     char* extra;  // the third tile: [slot][LPR] float4
   };
   static constexpr bool kExtraTile = true;
+  static constexpr int kEPP = 4;
   __device__ __forceinline__ bool skip(int) const { return false; }
   template <int WT>
   __device__ __forceinline__ void init(float*, int, State&) const {}
@@ -460,13 +466,181 @@ struct SumAccMaxBwdOp {
   }
 };
 
+// ---------------------------------------------------------------- bf16 activation storage (gcmi_model_desc.storage == 1)
+// The LDS-DMA moves bytes: a bf16 row of 64 is 8 pieces of 16 bytes, a piece holds 8 elements.  Sums and maxima are
+// formed in fp32 from the widened elements and rounded once (v_cvt_pk_bf16_f32) when the row is stored.
+
+// First GraphConv: the atom features arrive as fp32 rows (the caller's matrix); the sum of the neighbours' rows goes
+// out as bf16, and so does a bf16 copy of the atom's OWN row (it is in LDS anyway), so that the product that follows
+// and the backward read two bf16 operands and the fp32 matrix is read exactly once per step.  Output rows are `ldo`
+// elements; the `pad4` groups of four columns behind the LPR pieces are zeroed (76 -> 80 columns: 16-byte rows).
+struct SumOpFH {
+  bf16_t* __restrict__ s;
+  bf16_t* __restrict__ xcopy;
+  int64_t ldo;
+  int pad4;
+  using State = NoState;
+  static constexpr bool kExtraTile = false;
+  static constexpr int kEPP = 4;
+  __device__ __forceinline__ bool skip(int) const { return false; }
+  template <int WT>
+  __device__ __forceinline__ void init(float*, int, State&) const {}
+  template <int WT>
+  __device__ __forceinline__ void finish(char*, int, State&) const {}
+  template <int WT, int LPR>
+  __device__ __forceinline__ void run(const char* buf, const Layout& L, const WinMeta& m, const float*, State&) const {
+    const float4* tile = reinterpret_cast<const float4*>(buf);
+    const uint16_t* ent = reinterpret_cast<const uint16_t*>(buf + L.tile_bytes + L.aux_bytes);
+    const int n16 = m.sb[kND] * LPR;
+    for (int e = threadIdx.x; e < n16; e += WT) {
+      const int slot = e / LPR;
+      const int c = e - slot * LPR;
+      int d, row, eloc;
+      locate(m, L.maxd, slot, d, row, eloc);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);  // lone atoms: zero
+      for (int j = 0; j < d; ++j) {
+        const int sl = ent[eloc + j] & GCMI_WIN_MAX_SLOTS;
+        const float4 v = tile[sl * LPR + c];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      const float4 own = tile[e];
+      bf16_t* srow = s + (int64_t)row * ldo + c * 4;
+      bf16_t* xrow = xcopy + (int64_t)row * ldo + c * 4;
+      *reinterpret_cast<uint2*>(srow) = narrow4(acc.x, acc.y, acc.z, acc.w);
+      *reinterpret_cast<uint2*>(xrow) = narrow4(own.x, own.y, own.z, own.w);
+      if (c == LPR - 1) {
+        for (int z = 1; z <= pad4; ++z) {
+          *reinterpret_cast<uint2*>(srow + 4 * z) = make_uint2(0u, 0u);
+          *reinterpret_cast<uint2*>(xrow + 4 * z) = make_uint2(0u, 0u);
+        }
+      }
+    }
+  }
+};
+
+// GraphConv.sum_neigh over rows stored as bf16 (the pooled rows of the block below): bf16 in, bf16 out
+struct SumOpH {
+  bf16_t* __restrict__ s;
+  int64_t lds;
+  using State = NoState;
+  static constexpr bool kExtraTile = false;
+  static constexpr int kEPP = 8;
+  __device__ __forceinline__ bool skip(int) const { return false; }
+  template <int WT>
+  __device__ __forceinline__ void init(float*, int, State&) const {}
+  template <int WT>
+  __device__ __forceinline__ void finish(char*, int, State&) const {}
+  template <int WT, int LPR>
+  __device__ __forceinline__ void run(const char* buf, const Layout& L, const WinMeta& m, const float*, State&) const {
+    const uint4* tile = reinterpret_cast<const uint4*>(buf);
+    const uint16_t* ent = reinterpret_cast<const uint16_t*>(buf + L.tile_bytes + L.aux_bytes);
+    const int n16 = m.sb[kND] * LPR;
+    for (int e = threadIdx.x; e < n16; e += WT) {
+      const int slot = e / LPR;
+      const int c = e - slot * LPR;
+      int d, row, eloc;
+      locate(m, L.maxd, slot, d, row, eloc);
+      float acc[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+      for (int j = 0; j < d; ++j) {
+        const int sl = ent[eloc + j] & GCMI_WIN_MAX_SLOTS;
+        float v[8];
+        widen8(tile[sl * LPR + c], v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += v[q];
+      }
+      uint4 o;
+      o.x = pack_bf16x2(acc[0], acc[1]); o.y = pack_bf16x2(acc[2], acc[3]);
+      o.z = pack_bf16x2(acc[4], acc[5]); o.w = pack_bf16x2(acc[6], acc[7]);
+      *reinterpret_cast<uint4*>(s + (int64_t)row * lds + c * 8) = o;
+    }
+  }
+};
+
+// GraphPool over bf16 rows with the folded BatchNorm applied on the fly: candidates y = x * scale + shift in fp32,
+// the first maximum wins (self first, then neighbour order), the winner is rounded once when it is stored
+template <bool BN>
+struct MaxOpH {
+  const float* __restrict__ scale;
+  const float* __restrict__ shift;
+  bf16_t* __restrict__ out;
+  int64_t ldo;
+  uint8_t* __restrict__ arg;
+  static constexpr bool kExtraTile = false;
+  static constexpr int kEPP = 8;
+  using State = NoState;
+  __device__ __forceinline__ bool skip(int) const { return false; }
+  template <int WT>
+  __device__ __forceinline__ void init(float* sh_lds, int n_feat, State&) const {
+    if (BN)
+      for (int i = threadIdx.x; i < n_feat; i += WT) {
+        sh_lds[i] = scale[i];
+        sh_lds[256 + i] = shift[i];
+      }
+  }
+  template <int WT>
+  __device__ __forceinline__ void finish(char*, int, State&) const {}
+  template <int WT, int LPR>
+  __device__ __forceinline__ void run(const char* buf, const Layout& L, const WinMeta& m,
+                                      const float* sh_lds, State&) const {
+    const uint4* tile = reinterpret_cast<const uint4*>(buf);
+    const uint16_t* ent = reinterpret_cast<const uint16_t*>(buf + L.tile_bytes + L.aux_bytes);
+    const int n16 = m.sb[kND] * LPR;
+    for (int e = threadIdx.x; e < n16; e += WT) {
+      const int slot = e / LPR;
+      const int c = e - slot * LPR;
+      int d, row, eloc;
+      locate(m, L.maxd, slot, d, row, eloc);
+      float sc[8], sh[8];
+      if (BN) {
+        const float4 a0 = *reinterpret_cast<const float4*>(sh_lds + c * 8);
+        const float4 a1 = *reinterpret_cast<const float4*>(sh_lds + c * 8 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(sh_lds + 256 + c * 8);
+        const float4 b1 = *reinterpret_cast<const float4*>(sh_lds + 256 + c * 8 + 4);
+        sc[0] = a0.x; sc[1] = a0.y; sc[2] = a0.z; sc[3] = a0.w; sc[4] = a1.x; sc[5] = a1.y; sc[6] = a1.z; sc[7] = a1.w;
+        sh[0] = b0.x; sh[1] = b0.y; sh[2] = b0.z; sh[3] = b0.w; sh[4] = b1.x; sh[5] = b1.y; sh[6] = b1.z; sh[7] = b1.w;
+      }
+      float best[8];
+      widen8(tile[e], best);  // self first
+      unsigned char ba[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (BN) best[q] = fmaf(best[q], sc[q], sh[q]);
+        ba[q] = 0;
+      }
+      for (int j = 0; j < d; ++j) {
+        const int sl = ent[eloc + j] & GCMI_WIN_MAX_SLOTS;
+        float v[8];
+        widen8(tile[sl * LPR + c], v);
+        const unsigned char a = (unsigned char)(j + 1);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (BN) v[q] = fmaf(v[q], sc[q], sh[q]);
+          if (v[q] > best[q]) { best[q] = v[q]; ba[q] = a; }  // strict >: the first maximum wins
+        }
+      }
+      uint4 o;
+      o.x = pack_bf16x2(best[0], best[1]); o.y = pack_bf16x2(best[2], best[3]);
+      o.z = pack_bf16x2(best[4], best[5]); o.w = pack_bf16x2(best[6], best[7]);
+      *reinterpret_cast<uint4*>(out + (int64_t)row * ldo + c * 8) = o;
+      if (arg) {
+        uint2 av;
+        av.x = (unsigned)ba[0] | ((unsigned)ba[1] << 8) | ((unsigned)ba[2] << 16) | ((unsigned)ba[3] << 24);
+        av.y = (unsigned)ba[4] | ((unsigned)ba[5] << 8) | ((unsigned)ba[6] << 16) | ((unsigned)ba[7] << 24);
+        *reinterpret_cast<uint2*>(arg + (int64_t)row * (LPR * 8) + c * 8) = av;
+      }
+    }
+  }
+};
+
 // ---------------------------------------------------------------- the persistent window walker
 // Workgroups [0, g_norm) walk the ordinary windows double-buffered; workgroups [g_norm, gridDim)
 // walk the oversized windows (one big molecule each) using both buffers as one.
 template <int WT, int LPR, bool AUX, class Op>
 __global__ void __launch_bounds__(WT)
 win_kernel(const int32_t* __restrict__ meta, const uint16_t* __restrict__ edges, int n_norm, int n_win,
-           int g_norm, Layout L, Layout Lbig, const float* __restrict__ x, int64_t ldx,
+           int g_norm, Layout L, Layout Lbig, const char* __restrict__ x, int64_t ldx,
            const uint8_t* __restrict__ aux, Op op, int rev) {
   // ALL LDS is one array (a second __shared__ object beside an LDS-DMA target makes hipcc wait
   // vmcnt(0) before every ds_read): [window descriptors: it, it+1, it+2][op constants][2 buffers]
@@ -474,10 +648,10 @@ win_kernel(const int32_t* __restrict__ meta, const uint16_t* __restrict__ edges,
   int(*ring)[GCMI_WIN_META_INTS] = reinterpret_cast<int(*)[GCMI_WIN_META_INTS]>(smem_all);
   float* op_lds = reinterpret_cast<float*>(smem_all + kRingBytes);
   char* smem = smem_all + kHeadBytes;
-  if (op.skip(LPR * 4)) return;  // uniform over the grid
+  if (op.skip(LPR * Op::kEPP)) return;  // uniform over the grid
   typename Op::State ost;
   if constexpr (Op::kExtraTile) ost.extra = smem + 2 * L.buf_bytes();  // behind the two window buffers
-  op.template init<WT>(op_lds, LPR * 4, ost);
+  op.template init<WT>(op_lds, LPR * Op::kEPP, ost);
   const int t = threadIdx.x;
   if ((int)blockIdx.x >= g_norm) {  // oversized windows: stage, wait, compute
     const int G = gridDim.x - g_norm;
@@ -539,6 +713,7 @@ static int env_int(const char* name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 
+// (n_feat counts FLOATS per tile row: a bf16 row of n elements is a tile row of n / 2 "floats")
 static Layout make_layout(int alloc, int ecap, int maxd, int n_feat, bool aux) {
   Layout L;
   L.tile_bytes = alloc * n_feat * 4;
@@ -582,7 +757,7 @@ bool win_usable(const gcmi_graph* g, int n_feat, bool aux) {
 }
 
 template <int WT, int LPR, bool AUX, class Op>
-static int launch_wt(const gcmi_graph* g, const WinPlan& p, const float* x, int64_t ldx, const uint8_t* aux,
+static int launch_wt(const gcmi_graph* g, const WinPlan& p, const char* x, int64_t ldx, const uint8_t* aux,
                      const Op& op, hipStream_t st, const char* what, int which = 0) {  // which: 0 all windows,
                                                                                         // 1 ordinary, 2 oversized only
   auto kern = win_kernel<WT, LPR, AUX, Op>;
@@ -619,7 +794,7 @@ static int launch_wt(const gcmi_graph* g, const WinPlan& p, const float* x, int6
 }
 
 template <int LPR, bool AUX, class Op>
-static int launch_lpr(const gcmi_graph* g, const WinPlan& p, const float* x, int64_t ldx, const uint8_t* aux,
+static int launch_lpr(const gcmi_graph* g, const WinPlan& p, const char* x, int64_t ldx, const uint8_t* aux,
                       const Op& op, hipStream_t st, const char* what, int which) {
   static const int wt = env_int("GCMI_WIN_THREADS", 512);
   if constexpr (Op::kExtraTile) {  // one workgroup per CU by LDS: make it a full one
@@ -635,13 +810,30 @@ template <bool AUX, class Op>
 static int launch(const gcmi_graph* g, int n_feat, const float* x, int64_t ldx, const uint8_t* aux,
                   const Op& op, hipStream_t st, const char* what, int which = 0) {
   const WinPlan p = make_plan(g, n_feat, AUX);
+  const char* xb = reinterpret_cast<const char*>(x);
   switch (n_feat / 4) {
-    case 16: return launch_lpr<16, AUX, Op>(g, p, x, ldx, aux, op, st, what, which);
-    case 19: return launch_lpr<19, AUX, Op>(g, p, x, ldx, aux, op, st, what, which);
-    case 32: return launch_lpr<32, AUX, Op>(g, p, x, ldx, aux, op, st, what, which);
+    case 16: return launch_lpr<16, AUX, Op>(g, p, xb, ldx * 4, aux, op, st, what, which);
+    case 19: return launch_lpr<19, AUX, Op>(g, p, xb, ldx * 4, aux, op, st, what, which);
+    case 32: return launch_lpr<32, AUX, Op>(g, p, xb, ldx * 4, aux, op, st, what, which);
     default: break;
   }
   set_error("%s: no window kernel for %d features", what, n_feat);
+  return GCMI_ERR_UNSUPPORTED;
+}
+
+// rows of bf16: n_feat elements = n_feat / 8 pieces (64 -> 8, 80 -> 10, 128 -> 16)
+template <class Op>
+static int launch_h(const gcmi_graph* g, int n_feat, const bf16_t* x, int64_t ldx, const Op& op, hipStream_t st,
+                    const char* what) {
+  const WinPlan p = make_plan(g, n_feat / 2, false);
+  const char* xb = reinterpret_cast<const char*>(x);
+  switch (n_feat / 8) {
+    case 8: return launch_lpr<8, false, Op>(g, p, xb, ldx * 2, nullptr, op, st, what, 0);
+    case 10: return launch_lpr<10, false, Op>(g, p, xb, ldx * 2, nullptr, op, st, what, 0);
+    case 16: return launch_lpr<16, false, Op>(g, p, xb, ldx * 2, nullptr, op, st, what, 0);
+    default: break;
+  }
+  set_error("%s: no bf16 window kernel for %d features", what, n_feat);
   return GCMI_ERR_UNSUPPORTED;
 }
 
@@ -677,6 +869,41 @@ int win_gather_max_bwd_if_ill(const gcmi_graph* g, const float* d_dout, int64_t 
                               float* d_dx, int64_t lddx, const float* d_gamma, const float* d_beta, hipStream_t st) {
   MaxBwdOp<false> op{d_dx, lddx, nullptr, 0, nullptr, nullptr, nullptr, d_gamma, d_beta};
   return launch<true>(g, n_feat, d_dout, lddo, d_arg, op, st, "win_gather_max_bwd (conditional)");
+}
+
+// ---- bf16 activation storage
+bool win_usable_h(const gcmi_graph* g, int n_feat) {
+  if (windows_disabled() || g->d_win_meta == nullptr || g->n_win <= 0) return false;
+  if (g->d_win_edges == nullptr || g->n_win_big < 0 || g->n_win_big > g->n_win) return false;
+  if (n_feat != 64 && n_feat != 80 && n_feat != 128) return false;
+  return make_plan(g, n_feat / 2, false).ok;
+}
+
+// fp32 rows of n_feat (76) columns -> bf16 neighbour sums and a bf16 copy of the rows, both `ldo` (80) wide
+int win_gather_sum_fh(const gcmi_graph* g, const float* d_x, int64_t ldx, int n_feat, bf16_t* d_s, bf16_t* d_xcopy,
+                      int64_t ldo, hipStream_t st) {
+  if (n_feat % 4 != 0 || ldo < n_feat || (ldo - n_feat) % 4 != 0 || ldo % 8 != 0 || !aligned16(d_s) || !aligned16(d_xcopy)) {
+    set_error("win_gather_sum (fp32 -> bf16): bad shape (n_feat %d, ldo %lld)", n_feat, (long long)ldo);
+    return GCMI_ERR_UNSUPPORTED;
+  }
+  SumOpFH op{d_s, d_xcopy, ldo, (int)((ldo - n_feat) / 4)};
+  return launch<false>(g, n_feat, d_x, ldx, nullptr, op, st, "win_gather_sum (fp32 -> bf16)");
+}
+
+int win_gather_sum_h(const gcmi_graph* g, const bf16_t* d_x, int64_t ldx, int n_feat, bf16_t* d_s, int64_t lds,
+                     hipStream_t st) {
+  SumOpH op{d_s, lds};
+  return launch_h(g, n_feat, d_x, ldx, op, st, "win_gather_sum (bf16)");
+}
+
+int win_gather_max_h(const gcmi_graph* g, const bf16_t* d_x, int64_t ldx, int n_feat, const float* d_scale,
+                     const float* d_shift, bf16_t* d_out, int64_t ldo, uint8_t* d_arg, hipStream_t st) {
+  if (d_scale) {
+    MaxOpH<true> op{d_scale, d_shift, d_out, ldo, d_arg};
+    return launch_h(g, n_feat, d_x, ldx, op, st, "win_gather_max (bf16)");
+  }
+  MaxOpH<false> op{nullptr, nullptr, d_out, ldo, d_arg};
+  return launch_h(g, n_feat, d_x, ldx, op, st, "win_gather_max (bf16)");
 }
 
 // dy = GraphPool backward of (dXs + gather of dS), dX kept in LDS only.  GCMI_ERR_UNSUPPORTED: oversized windows in

@@ -4,6 +4,7 @@
 // Host code only enqueues the kernels of this library on the caller's stream; the few
 // device functions here are parameter-layout helpers (bias packing, counters).
 #include "common.h"
+#include "split_bf16.h"
 
 namespace gcmi {
 
@@ -47,9 +48,12 @@ struct Ws {
   int64_t S[kMaxL], gc[kMaxL], pool[kMaxL], arg[kMaxL], bsum[kMaxL], bnv[kMaxL + 1];
   int64_t ldS[kMaxL], ngather[kMaxL];
   int64_t dense, arg_r, rsum, dfp, tA, tB, tC, tD, tE, total;
+  int64_t xb;  // storage == 1: bf16 copy of the atom features (ld = ldS[0])
   // one region the backward zeroes with a single memset: [dlogits | dbsum per layer | lacc | acc]
   int64_t dlogits, dbsum[kMaxL], lacc, acc, acc2, z_end;
 };
+
+static inline int64_t up8(int64_t n) { return (n + 7) / 8 * 8; }
 
 static Ws carve(const gcmi_model_desc* m, int64_t N, int64_t B, int64_t ld_features) {
   Ws w;
@@ -60,6 +64,10 @@ static Ws carve(const gcmi_model_desc* m, int64_t N, int64_t B, int64_t ld_featu
     off += up4(n);
     return o;
   };
+  // storage == 1: the matrices the step writes and reads back (S, gc, pool, dense, and a copy of the atom features)
+  // are bf16: rows of ld ELEMENTS with ld a multiple of 8, half the floats of the workspace per element
+  const bool h = m->storage == 1;
+  auto take_act = [&](int64_t rows, int64_t ld) { return take(h ? (rows * ld + 1) / 2 : rows * ld); };
   const int L = m->n_layers;
   int64_t wmax = m->dense_width, kmax = up4(m->n_feat_in);
   for (int l = 0; l < L; ++l) {
@@ -67,11 +75,13 @@ static Ws carve(const gcmi_model_desc* m, int64_t N, int64_t B, int64_t ld_featu
     const int64_t ldx = l == 0 ? ld_features : m->conv_width[l - 1];
     // gather over the padded width when the rows are 16-byte addressable (pad columns are 0)
     w.ngather[l] = (l == 0 && ldx % 4 == 0 && ldx < k + 4) ? ldx : k;
-    w.ldS[l] = up4(w.ngather[l]);
+    if (h && l == 0) w.ngather[l] = up4(k);
+    w.ldS[l] = h ? up8(w.ngather[l]) : up4(w.ngather[l]);
     const int64_t wd = m->conv_width[l];
-    w.S[l] = take(N * w.ldS[l]);
-    w.gc[l] = take(N * wd);
-    w.pool[l] = take(N * wd);
+    w.S[l] = take_act(N, w.ldS[l]);
+    if (h && l == 0) w.xb = take_act(N, w.ldS[0]);
+    w.gc[l] = take_act(N, wd);
+    w.pool[l] = take_act(N, wd);
     w.arg[l] = take((N * wd + 3) / 4);
     w.bsum[l] = take((int64_t)(m->max_deg + 1) * wd);
     w.bnv[l] = take(4 * wd);
@@ -81,7 +91,7 @@ static Ws carve(const gcmi_model_desc* m, int64_t N, int64_t B, int64_t ld_featu
   const int64_t D = m->dense_width;
   const int64_t TC = (int64_t)m->n_tasks * m->n_classes;
   w.bnv[L] = take(4 * D);
-  w.dense = take(N * D);
+  w.dense = take_act(N, D);
   w.arg_r = take(B * D);
   w.rsum = take(2 * B * D);  // per-molecule [row sums | arg-max row value] of the dense output (BatchNorm backward)
   w.dfp = take(B * 2 * D);
@@ -109,8 +119,15 @@ static int check_desc(const gcmi_model_desc* m) {
   GCMI_CHECK_ARG(m->mode == 0 || m->n_classes == 1, "regression needs n_classes == 1");
   for (int l = 0; l < m->n_layers; ++l) GCMI_CHECK_ARG(m->conv_width[l] > 0, "bad conv width");
   if (m->storage != 0) {
-    set_error("gcmi_model_*: bf16 activation storage is implemented by the small-batch engine (gcmi_small_*) only");
-    return GCMI_ERR_UNSUPPORTED;
+    // bf16 activation storage in the streaming kernels (fwd_bf16.hip, bwd_fused.hip HB, gather_lds.hip *OpH): the
+    // default shapes -- GraphConv widths 64 over 65..80 input columns, dense width 128, BatchNorm on
+    bool ok = m->storage == 1 && m->batch_norm && m->dense_width == 128 && m->n_feat_in > 64 && m->n_feat_in <= 80;
+    for (int l = 0; l < m->n_layers; ++l) ok = ok && m->conv_width[l] == 64;
+    if (!ok) {
+      set_error("gcmi_model_*: bf16 activation storage covers graph_conv_layers of width 64 over 65..80 atom features, "
+                "dense_layer_size 128 and batch_normalize=True (other shapes: gcmi_small_* or storage 0)");
+      return GCMI_ERR_UNSUPPORTED;
+    }
   }
   return GCMI_OK;
 }
@@ -135,11 +152,293 @@ static Segs make_segs(const gcmi_graph* g, int64_t k, int64_t width) {
   return s;
 }
 
+static int model_forward_h(const gcmi_model_desc* m, const gcmi_graph* g, const float* d_params, const gcmi_model_io* io,
+                           int32_t training, void* stream);
+static int model_loss_backward_h(const gcmi_model_desc* m, const gcmi_graph* g, const float* d_params, float* d_grads,
+                                 const gcmi_model_io* io, const float* d_labels, const float* d_weights, int64_t n_rows,
+                                 int64_t* grad_lo, int64_t* grad_hi, void* stream);
+
 #define RUN(call)            \
   do {                       \
     int rc__ = (call);       \
     if (rc__) return rc__;   \
   } while (0)
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// storage == 1: the same step with every matrix it writes and reads back kept as bf16 (fp32 arithmetic, fp64
+// statistics, fp32 parameters / gradients / gradient streams).  One linear sequence of the kernels that have a bf16
+// form; what they do not cover (other widths, no BatchNorm, graphs without window plans or reverse slots, the
+// exact-fp32 product mode) is refused, never computed some other way.
+static int require_h(const gcmi_model_desc* m, const gcmi_graph* g, const gcmi_model_io* io, bool backward) {
+  if (gemm_exact_mode()) {
+    set_error("bf16 activation storage: not available in the exact-fp32 product mode (set_gemm_mode('fast'))");
+    return GCMI_ERR_UNSUPPORTED;
+  }
+  if (g->n_atoms > 0 && (!win_usable_h(g, 64) || !win_usable_h(g, 80) || !win_usable(g, (int)up4(m->n_feat_in), false))) {
+    set_error("bf16 activation storage: the graph carries no usable molecule-window plan (collate with gcmi_collate_plans)");
+    return GCMI_ERR_UNSUPPORTED;
+  }
+  if (g->n_atoms > 0 && (io->ld_features % 4 != 0 || io->ld_features < up4(m->n_feat_in) || !aligned16(io->d_atom_features))) {
+    set_error("bf16 activation storage: atom feature rows must be 16-byte addressable and padded to %d columns",
+              (int)up4(m->n_feat_in));
+    return GCMI_ERR_UNSUPPORTED;
+  }
+  if (backward && g->n_atoms > 0) {
+    if (!(g->d_rev_pos != nullptr || g->n_edges == 0)) {
+      set_error("bf16 activation storage: the backward needs reverse slots (every bond listed from both ends)");
+      return GCMI_ERR_UNSUPPORTED;
+    }
+    if (!fused_bwd_enabled()) {
+      set_error("bf16 activation storage: the one-pass block kernels are switched off (GCMI_OPT_FUSED_BWD)");
+      return GCMI_ERR_UNSUPPORTED;
+    }
+  }
+  return GCMI_OK;
+}
+
+static int model_forward_h(const gcmi_model_desc* m, const gcmi_graph* g, const float* d_params, const gcmi_model_io* io,
+                           int32_t training, void* stream) {
+  RUN(require_h(m, g, io, false));
+  hipStream_t st = (hipStream_t)stream;
+  const int L = m->n_layers;
+  const int64_t N = g->n_atoms, B = g->n_mols;
+  const Ws w = carve(m, N, B, io->ld_features);
+  float* ws = io->d_workspace;
+  auto H = [&](int64_t off) { return reinterpret_cast<bf16_t*>(ws + off); };
+  if (training && N > 0 && hipMemsetAsync(ws + w.acc, 0, sizeof(float) * (size_t)(w.z_end - w.acc), st) != hipSuccess) {
+    set_error("model_forward: memset failed");
+    return GCMI_ERR_LAUNCH;
+  }
+  const bf16_t* xin = nullptr;
+  int64_t ldin = 0;
+  for (int l = 0; l < L; ++l) {
+    const int K = l == 0 ? m->n_feat_in : m->conv_width[l - 1];
+    const int W = m->conv_width[l];
+    const Segs sg = make_segs(g, K, W);
+    hipLaunchKernelGGL(bias_pack_kernel, dim3(4), dim3(256), 0, st, d_params + m->off_conv_b[l], m->max_deg, W,
+                       ws + w.bsum[l]);
+    GCMI_CHECK_LAUNCH("bias_pack");
+    float* bnv = ws + w.bnv[l];
+    float* scale = bnv + 2 * W;
+    float* shift = bnv + 3 * W;
+    if (N > 0) {
+      {
+        TimedScope ts(GCMI_K_GATHER_SUM, st);
+        if (l == 0) {  // fp32 atom features -> bf16 neighbour sums + a bf16 copy of the rows themselves
+          RUN(win_gather_sum_fh(g, io->d_atom_features, io->ld_features, (int)w.ngather[0], H(w.S[0]), H(w.xb), w.ldS[0], st));
+          xin = H(w.xb);
+          ldin = w.ldS[0];
+        } else {
+          RUN(win_gather_sum_h(g, xin, ldin, K, H(w.S[l]), w.ldS[l], st));
+        }
+      }
+      {
+        TimedScope ts(GCMI_K_SEG_GEMM, st);
+        const int rc = fwd_h_gemm(sg.n, sg.begin, sg.end, H(w.S[l]), w.ldS[l], K, d_params + m->off_conv_w[l], sg.w_rel, xin,
+                                  ldin, K, d_params + m->off_conv_w[l], sg.w_self, ws + w.bsum[l], sg.b_off, W, 0, 1,
+                                  H(w.gc[l]), W, training ? reinterpret_cast<double*>(ws + w.acc) : nullptr, st);
+        if (rc == GCMI_ERR_UNSUPPORTED) set_error("bf16 activation storage: GraphConv %d has no bf16 product kernel", l);
+        RUN(rc);
+      }
+      if (training) {
+        RUN(bn_finalize_impl(N, W, d_params + m->off_bn_gamma[l], d_params + m->off_bn_beta[l], m->bn_eps, m->bn_momentum,
+                             io->d_bn_running_mean[l], io->d_bn_running_var[l], bnv, bnv + W, scale, shift,
+                             reinterpret_cast<double*>(ws + w.acc), stream));
+      } else {
+        RUN(gcmi_bn_fold_eval(d_params + m->off_bn_gamma[l], d_params + m->off_bn_beta[l], io->d_bn_running_mean[l],
+                              io->d_bn_running_var[l], m->bn_eps, W, scale, shift, stream));
+      }
+      {
+        TimedScope ts(GCMI_K_GATHER_MAX, st);
+        RUN(win_gather_max_h(g, H(w.gc[l]), W, W, scale, shift, H(w.pool[l]), W,
+                             training ? reinterpret_cast<uint8_t*>(ws + w.arg[l]) : nullptr, st));
+      }
+    }
+    xin = H(w.pool[l]);
+    ldin = W;
+  }
+  const int Wl = m->conv_width[L - 1];
+  const int D = m->dense_width;
+  const int32_t zero32 = 0;
+  const int64_t zero64 = 0;
+  float* bnvD = ws + w.bnv[L];
+  float* scale = bnvD + 2 * D;
+  float* shift = bnvD + 3 * D;
+  if (N > 0) {
+    const int32_t nN = (int32_t)N;
+    {
+      TimedScope ts(GCMI_K_SEG_GEMM, st);
+      const int rc = fwd_h_gemm(1, &zero32, &nN, xin, ldin, Wl, d_params + m->off_dense_w, &zero64, nullptr, 0, 0, nullptr,
+                                nullptr, d_params + m->off_dense_b, &zero64, D, 1, 1, H(w.dense), D,
+                                training ? reinterpret_cast<double*>(ws + w.acc) : nullptr, st);
+      if (rc == GCMI_ERR_UNSUPPORTED) set_error("bf16 activation storage: the dense layer has no bf16 product kernel");
+      RUN(rc);
+    }
+    if (training) {
+      RUN(bn_finalize_impl(N, D, d_params + m->off_bn_gamma[L], d_params + m->off_bn_beta[L], m->bn_eps, m->bn_momentum,
+                           io->d_bn_running_mean[L], io->d_bn_running_var[L], bnvD, bnvD + D, scale, shift,
+                           reinterpret_cast<double*>(ws + w.acc), stream));
+    } else {
+      RUN(gcmi_bn_fold_eval(d_params + m->off_bn_gamma[L], d_params + m->off_bn_beta[L], io->d_bn_running_mean[L],
+                            io->d_bn_running_var[L], m->bn_eps, D, scale, shift, stream));
+    }
+  }
+  RUN(readout_fwd_impl(g, reinterpret_cast<const float*>(H(w.dense)), D, D, N > 0 ? scale : nullptr,
+                       N > 0 ? shift : nullptr, 1, io->d_fingerprint, 2 * D, reinterpret_cast<int32_t*>(ws + w.arg_r),
+                       training ? ws + w.rsum : nullptr, stream, 1));
+  const int TC = m->n_tasks * m->n_classes;
+  const int32_t nB = (int32_t)B;
+  RUN(gcmi_seg_gemm(1, &zero32, &nB, io->d_fingerprint, 2 * D, 2 * D, d_params + m->off_head_w, &zero64, nullptr, 0, 0,
+                    nullptr, nullptr, d_params + m->off_head_b, &zero64, TC, 1, 0, io->d_logits, TC, stream));
+  if (m->mode == 0 && io->d_probs) RUN(gcmi_softmax(io->d_logits, B * m->n_tasks, m->n_classes, io->d_probs, stream));
+  if (training) {
+    CounterPtrs c;
+    c.n = L + 1;
+    bool any = false;
+    for (int i = 0; i <= kMaxL; ++i) {
+      c.p[i] = i <= L ? io->d_bn_batches_tracked[i] : nullptr;
+      any = any || c.p[i] != nullptr;
+    }
+    if (any) {
+      hipLaunchKernelGGL(bump_counters_kernel, dim3(1), dim3(64), 0, st, c);
+      GCMI_CHECK_LAUNCH("bump_counters");
+    }
+  }
+  return GCMI_OK;
+}
+
+static int model_loss_backward_h(const gcmi_model_desc* m, const gcmi_graph* g, const float* d_params, float* d_grads,
+                                 const gcmi_model_io* io, const float* d_labels, const float* d_weights, int64_t n_rows,
+                                 int64_t* grad_lo, int64_t* grad_hi, void* stream) {
+  RUN(require_h(m, g, io, true));
+  hipStream_t st = (hipStream_t)stream;
+  const int L = m->n_layers;
+  const int64_t N = g->n_atoms, B = g->n_mols;
+  const Ws w = carve(m, N, B, io->ld_features);
+  float* ws = io->d_workspace;
+  auto H = [&](int64_t off) { return reinterpret_cast<bf16_t*>(ws + off); };
+  auto HF = [&](int64_t off) { return reinterpret_cast<const float*>(ws + off); };  // a bf16 matrix behind a float* parameter
+  const int D = m->dense_width;
+  const int TC = m->n_tasks * m->n_classes;
+  const bool full = m->grad_mode == 1;
+  const int64_t lo = full ? 0 : m->off_bn_gamma[L - 1];
+  const int64_t hi = m->n_params;
+  if (grad_lo) *grad_lo = lo;
+  if (grad_hi) *grad_hi = hi;
+  if (hipMemsetAsync(d_grads + lo, 0, sizeof(float) * (size_t)(hi - lo), st) != hipSuccess ||
+      hipMemsetAsync(ws + w.dlogits, 0, sizeof(float) * (size_t)(w.z_end - w.dlogits), st) != hipSuccess) {
+    set_error("model_loss_backward: memset failed");
+    return GCMI_ERR_LAUNCH;
+  }
+  const int32_t zero32 = 0;
+  const int64_t zero64 = 0;
+  const int32_t nB = (int32_t)B;
+  // ---- per-molecule part (fp32 throughout: the fingerprint and everything behind it are per-molecule rows)
+  const float* bnvL = ws + w.bnv[L];
+  bool head_sums = false;
+  {
+    const int rc = head_bwd_fused(m->mode == 0 ? 0 : 1, io->d_logits, d_labels, d_weights, n_rows, m->n_tasks, m->n_classes,
+                                  B, io->d_fingerprint, 2 * D, d_params + m->off_head_w, d_grads + m->off_head_w,
+                                  d_grads + m->off_head_b, ws + w.dfp, 2 * D, reinterpret_cast<double*>(ws + w.lacc),
+                                  g->d_mol_runs, g->max_deg + 1, reinterpret_cast<const int32_t*>(ws + w.arg_r), ws + w.rsum,
+                                  bnvL, bnvL + D, (N > 0 && g->d_mol_runs) ? reinterpret_cast<double*>(ws + w.acc) : nullptr,
+                                  D, st);
+    if (rc == GCMI_OK) {
+      head_sums = N > 0 && g->d_mol_runs != nullptr;
+      RUN(loss_finalize_impl(reinterpret_cast<double*>(ws + w.lacc), 1.f / (float)(n_rows * m->n_tasks), io->d_loss, stream));
+    } else if (rc != GCMI_ERR_UNSUPPORTED) {
+      return rc;
+    } else {
+      RUN(loss_impl(m->mode == 0 ? 0 : 1, io->d_logits, d_labels, d_weights, n_rows, m->n_tasks, m->n_classes, io->d_loss,
+                    ws + w.dlogits, nullptr, reinterpret_cast<double*>(ws + w.lacc), true, stream));
+      RUN(gcmi_seg_gemm_wgrad(1, &zero32, &nB, io->d_fingerprint, 2 * D, 2 * D, ws + w.dlogits, TC, TC,
+                              d_grads + m->off_head_w, &zero64, d_grads + m->off_head_b, &zero64, 1, stream));
+      RUN(gcmi_seg_gemm(1, &zero32, &nB, ws + w.dlogits, TC, TC, d_params + m->off_head_w, &zero64, nullptr, 0, 0, nullptr,
+                        nullptr, nullptr, nullptr, 2 * D, 0, 0, ws + w.dfp, 2 * D, stream));
+      RUN(readout_grad_prep(ws + w.dfp, 2 * D, io->d_fingerprint, 2 * D, B, D, st));
+    }
+  }
+  if (N == 0) return GCMI_OK;
+  const int Wl = m->conv_width[L - 1];
+  float* dpool = ws + w.tC;
+  const float* coef = ws + w.acc;
+  // ---- dense block: BatchNorm sums from per-molecule data, then one pass (dense and pool rows arrive as bf16)
+  if (head_sums) {
+    RUN(bn_bwd_params_impl(N, D, d_params + m->off_bn_gamma[L], bnvL, bnvL + D, d_grads + m->off_bn_gamma[L],
+                           d_grads + m->off_bn_beta[L], reinterpret_cast<double*>(ws + w.acc), stream));
+  } else {
+    // (the per-molecule sums kernel reads rawsum, never the atom rows: the bf16 matrix is only passed through)
+    RUN(bn_bwd_readout_impl(g->d_membership, ws + w.dfp, 2 * D, reinterpret_cast<const int32_t*>(ws + w.arg_r),
+                            HF(w.dense), D, N, D, d_params + m->off_bn_gamma[L], bnvL, bnvL + D,
+                            d_grads + m->off_bn_gamma[L], d_grads + m->off_bn_beta[L], nullptr, D, 1,
+                            reinterpret_cast<double*>(ws + w.acc), true, stream, ws + w.rsum, g->d_mol_runs, g->n_mols,
+                            g->max_deg + 1));
+  }
+  {
+    TimedScope ts(GCMI_K_FUSED_BWD, st);
+    const int rc = fused_dense_bwd(N, g->d_membership, ws + w.dfp, 2 * D, reinterpret_cast<const int32_t*>(ws + w.arg_r),
+                                   HF(w.dense), D, coef, D, HF(w.pool[L - 1]), Wl, Wl, d_params + m->off_dense_w,
+                                   d_grads + m->off_dense_w, d_grads + m->off_dense_b, dpool, Wl,
+                                   reinterpret_cast<double*>(ws + w.acc2), st, 1);
+    if (rc == GCMI_ERR_UNSUPPORTED) set_error("bf16 activation storage: the dense block has no one-pass backward");
+    RUN(rc);
+  }
+  // ---- GraphConv / BatchNorm / GraphPool blocks, last to first (gradient streams fp32: the window kernels as they are)
+  bool dy_ready = false;
+  for (int l = L - 1; l >= 0; --l) {
+    const int W = m->conv_width[l];
+    const int K = l == 0 ? m->n_feat_in : m->conv_width[l - 1];
+    float* dy = ws + w.tD;
+    const Segs sg = make_segs(g, K, W);
+    const bf16_t* xin = l == 0 ? H(w.xb) : H(w.pool[l - 1]);
+    const int64_t ldx = l == 0 ? w.ldS[0] : m->conv_width[l - 1];
+    float* dS = ws + w.tE;
+    float* dX = ws + w.tC;
+    const float* bnv = ws + w.bnv[l];
+    // the block above left sum dP and sum dP * P: this BatchNorm's backward needs no pass over dy (bn_bwd_pool_impl);
+    // dy itself only when the GraphConv below trains, or where the pooled sums are ill-conditioned
+    if (dy_ready) {
+      // (left by win_gather_sumacc_max_bwd below, one iteration ago)
+    } else if (full) {
+      RUN(gcmi_gather_max_bwd(g, dpool, W, W, reinterpret_cast<const uint8_t*>(ws + w.arg[l]), dy, W, stream));
+    } else {
+      TimedScope ts(GCMI_K_GATHER_MAX_BWD, st);
+      RUN(win_gather_max_bwd_if_ill(g, dpool, W, W, reinterpret_cast<const uint8_t*>(ws + w.arg[l]), dy, W,
+                                    d_params + m->off_bn_gamma[l], d_params + m->off_bn_beta[l], st));
+    }
+    RUN(bn_bwd_pool_impl(dy, W, HF(w.gc[l]), W, N, W, d_params + m->off_bn_gamma[l], d_params + m->off_bn_beta[l], bnv, bnv + W,
+                         d_grads + m->off_bn_gamma[l], d_grads + m->off_bn_beta[l], reinterpret_cast<double*>(ws + w.acc2),
+                         reinterpret_cast<double*>(ws + w.acc), stream, 1));
+    dy_ready = false;
+    if (!full) break;  // reference semantics: nothing in front of a GraphConv output trains
+    {
+      TimedScope ts(GCMI_K_FUSED_BWD, st);
+      const int rc = fused_conv_bwd(sg.n, sg.begin, sg.end, sg.w_rel, sg.w_self, sg.b_off, dy, W, HF(w.gc[l]), W, coef, W,
+                                    HF(w.S[l]), w.ldS[l], reinterpret_cast<const float*>(xin), ldx, K,
+                                    d_params + m->off_conv_w[l], d_grads + m->off_conv_w[l], ws + w.dbsum[l],
+                                    l > 0 ? dS : nullptr, K, l > 0 ? dX : nullptr, K,
+                                    l > 0 ? reinterpret_cast<double*>(ws + w.acc2) : nullptr, st, 1);
+      if (rc == GCMI_ERR_UNSUPPORTED) set_error("bf16 activation storage: GraphConv %d has no one-pass backward", l);
+      RUN(rc);
+    }
+    hipLaunchKernelGGL(bias_unpack_kernel, dim3(4), dim3(256), 0, st, ws + w.dbsum[l], m->max_deg, W,
+                       d_grads + m->off_conv_b[l]);
+    GCMI_CHECK_LAUNCH("bias_unpack");
+    if (l == 0) break;  // the atom features need no gradient
+    // dX holds the self part; the neighbour part is added onto it, and where the window kernels can hold a third tile
+    // the GraphPool backward of the block below runs in the same pass
+    if (win_two_stage_usable(g, K) && aligned16(dS) && aligned16(dX) && aligned16(ws + w.tD)) {
+      TimedScope ts(GCMI_K_GATHER_MAX_BWD, st);
+      RUN(win_gather_sumacc_max_bwd(g, dS, K, K, dX, K, reinterpret_cast<const uint8_t*>(ws + w.arg[l - 1]), ws + w.tD, K, st));
+      dy_ready = true;
+    } else {
+      RUN(gcmi_gather_sum_fwd(g, dS, K, K, dX, K, 1, stream));
+    }
+    dpool = dX;
+  }
+  return GCMI_OK;
+}
 
 }  // namespace gcmi
 
@@ -163,6 +462,7 @@ int gcmi_model_forward(const gcmi_model_desc* m, const gcmi_graph* g, const floa
   GCMI_CHECK_ARG(g->n_mols > 1, "graph_gather requires batches larger than 1");
   GCMI_CHECK_ARG(g->n_atoms == 0 || io->d_atom_features, "model_forward: NULL atom features");
   GCMI_CHECK_ARG(io->ld_features >= m->n_feat_in, "ld_features < n_feat_in");
+  if (m->storage == 1) return model_forward_h(m, g, d_params, io, training, stream);
   hipStream_t st = (hipStream_t)stream;
   const int L = m->n_layers;
   const int64_t N = g->n_atoms, B = g->n_mols;
@@ -289,6 +589,8 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
                  "model_loss_backward: NULL buffer");
   GCMI_CHECK_ARG(n_rows > 0 && n_rows <= g->n_mols, "n_rows %lld outside (0, n_mols=%d]", (long long)n_rows,
                  g->n_mols);
+  if (m->storage == 1)
+    return model_loss_backward_h(m, g, d_params, d_grads, io, d_labels, d_weights, n_rows, grad_lo, grad_hi, stream);
   hipStream_t st = (hipStream_t)stream;
   const int L = m->n_layers;
   const int64_t N = g->n_atoms, B = g->n_mols;

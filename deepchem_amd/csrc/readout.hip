@@ -17,6 +17,7 @@
 #include <atomic>
 
 #include "common.h"
+#include "split_bf16.h"
 
 namespace gcmi {
 
@@ -57,7 +58,9 @@ mol_runs_kernel(DegTable t, int n_atoms, int n_mols, const int32_t* __restrict__
 // Same rows in the same order as the plain form (bit-identical sums, same first-maximum rule); what changes is the
 // number of dependent memory round trips per molecule: 1 + ceil(atoms / 4) with two rounds in flight, against one
 // per degree + one per four rows of every run, one at a time.
-template <int V, bool BN, bool PRE, int DEPTH = 2>
+// HB: the rows are stored as bf16 (gcmi_model_desc.storage == 1; ldx counts elements): a lane's four columns are one
+// 8-byte load, widened; sums, maxima and everything written stay fp32.
+template <int V, bool BN, bool PRE, int DEPTH = 2, bool HB = false>
 __global__ void __launch_bounds__(kRBlock)
 readout_fwd_kernel(int n_mols, int n_deg, const int32_t* __restrict__ runs,
                    const float* __restrict__ x, int64_t ldx, int n_feat, int lpr, int gl,
@@ -138,7 +141,11 @@ readout_fwd_kernel(int n_mols, int n_deg, const int32_t* __restrict__ runs,
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const float4 tv = *reinterpret_cast<const float4*>(x + (int64_t)idx[u] * ldx + c);
+          float4 tv;
+          if constexpr (HB)
+            tv = widen4(*reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(x) + (int64_t)idx[u] * ldx + c));
+          else
+            tv = *reinterpret_cast<const float4*>(x + (int64_t)idx[u] * ldx + c);
           v[u][0] = tv.x; v[u][1] = tv.y; v[u][2] = tv.z; v[u][3] = tv.w;
         }
       };
@@ -180,7 +187,11 @@ readout_fwd_kernel(int n_mols, int n_deg, const int32_t* __restrict__ runs,
         for (int u = 0; u < 4; ++u) {
           const int r = rr + u < r1 ? rr + u : rr;
           if constexpr (V == 4) {
-            const float4 tv = *reinterpret_cast<const float4*>(x + (int64_t)r * ldx + c);
+            float4 tv;
+            if constexpr (HB)
+              tv = widen4(*reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(x) + (int64_t)r * ldx + c));
+            else
+              tv = *reinterpret_cast<const float4*>(x + (int64_t)r * ldx + c);
             v[u][0] = tv.x; v[u][1] = tv.y; v[u][2] = tv.z; v[u][3] = tv.w;
           } else {
             v[u][0] = x[(int64_t)r * ldx + c];
@@ -360,7 +371,7 @@ int get_readout_pipelined() { return g_readout_pre.load(std::memory_order_relaxe
 // the BatchNorm backward behind this readout needs to get its column sums without another pass over the atoms
 int readout_fwd_impl(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t n_feat, const float* d_scale,
                      const float* d_shift, int32_t act, float* d_out, int64_t ldo, int32_t* d_arg, float* d_rawsum,
-                     void* stream) {
+                     void* stream, int32_t x_bf16) {
   int rc = check_graph(g, false);
   if (rc) return rc;
   GCMI_CHECK_ARG(n_feat > 0 && ldx >= n_feat && ldo >= 2 * (int64_t)n_feat, "readout: bad n_feat/ld");
@@ -370,7 +381,13 @@ int readout_fwd_impl(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t
   GCMI_CHECK_ARG(act == 0 || act == 1, "readout: act must be 0 or 1");
   if (g->n_mols == 0) return GCMI_OK;
   hipStream_t st = (hipStream_t)stream;
-  const int V = vec_width(d_x, ldx, n_feat);
+  // (bf16 rows: 8-byte pieces, so the alignment test runs on half the element counts)
+  const int V = x_bf16 ? ((reinterpret_cast<uintptr_t>(d_x) & 7u) == 0 && ldx % 4 == 0 && n_feat % 4 == 0 ? 4 : 1)
+                       : vec_width(d_x, ldx, n_feat);
+  if (x_bf16 && V != 4) {
+    set_error("readout (bf16 rows): rows must be 8-byte addressable");
+    return GCMI_ERR_UNSUPPORTED;
+  }
   const int lpr = n_feat / V;
   const int gl = lpr < kRBlock ? lpr : kRBlock;
   const int tb = kRBlock;  // (64- and 128-thread workgroups measured 3 % slower with the pipelined walk)
@@ -393,7 +410,27 @@ int readout_fwd_impl(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t
                      d_out, ldo, d_arg, d_rawsum, vec_out)
   // rounds in flight: three (default; 179-181 us in the step) or two (GCMI_READOUT_DEPTH=2; 184-187 us)
   static const int depth_env = getenv("GCMI_READOUT_DEPTH") ? atoi(getenv("GCMI_READOUT_DEPTH")) : 3;
-  if (V == 4 && pre && depth_env != 2) {
+  if (x_bf16) {
+    if (pre) {
+      if (bn)
+        hipLaunchKernelGGL((readout_fwd_kernel<4, true, true, 3, true>), dim3(blocks), dim3(tb), 0, st, g->n_mols, n_deg,
+                           g->d_mol_runs, d_x, ldx, n_feat, lpr, gl, d_scale, d_shift, act, d_out, ldo, d_arg, d_rawsum,
+                           vec_out);
+      else
+        hipLaunchKernelGGL((readout_fwd_kernel<4, false, true, 3, true>), dim3(blocks), dim3(tb), 0, st, g->n_mols, n_deg,
+                           g->d_mol_runs, d_x, ldx, n_feat, lpr, gl, d_scale, d_shift, act, d_out, ldo, d_arg, d_rawsum,
+                           vec_out);
+    } else {
+      if (bn)
+        hipLaunchKernelGGL((readout_fwd_kernel<4, true, false, 2, true>), dim3(blocks), dim3(tb), 0, st, g->n_mols, n_deg,
+                           g->d_mol_runs, d_x, ldx, n_feat, lpr, gl, d_scale, d_shift, act, d_out, ldo, d_arg, d_rawsum,
+                           vec_out);
+      else
+        hipLaunchKernelGGL((readout_fwd_kernel<4, false, false, 2, true>), dim3(blocks), dim3(tb), 0, st, g->n_mols, n_deg,
+                           g->d_mol_runs, d_x, ldx, n_feat, lpr, gl, d_scale, d_shift, act, d_out, ldo, d_arg, d_rawsum,
+                           vec_out);
+    }
+  } else if (V == 4 && pre && depth_env != 2) {
     if (bn)
       hipLaunchKernelGGL((readout_fwd_kernel<4, true, true, 3>), dim3(blocks), dim3(tb), 0, st, g->n_mols, n_deg,
                          g->d_mol_runs, d_x, ldx, n_feat, lpr, gl, d_scale, d_shift, act, d_out, ldo, d_arg, d_rawsum,

@@ -1581,8 +1581,19 @@ static int make_small_graph(const gcmi_graph* g, bool need_rev, SmallGraph* out)
     if (d <= g->max_deg) t += (g->deg_start[d + 1] - g->deg_start[d] + kTileRows - 1) / kTileRows;
   }
   s.n_tiles = t;
+  // the diagnostic switches exist only in a build made for them (tools/small_diag.sh: -DGCMI_SMALL_DIAG_BUILD): in
+  // the shipped library a stray environment variable cannot switch parts of the training kernels off
+#ifdef GCMI_SMALL_DIAG_BUILD
   static const int diag = getenv("GCMI_SMALL_DIAG") ? atoi(getenv("GCMI_SMALL_DIAG")) : 0;
+  if (diag) {
+    static bool warned = false;
+    if (!warned) fprintf(stderr, "libgcmi: GCMI_SMALL_DIAG=%d -- parts of the small-batch kernels are OFF, results are wrong\n", diag);
+    warned = true;
+  }
   s.diag = diag;
+#else
+  s.diag = 0;
+#endif
   s.col_idx = g->d_col_idx;
   s.membership = g->d_membership;
   s.mol_runs = g->d_mol_runs;
@@ -1883,23 +1894,30 @@ static int small_backward(const SmallCtx& c, const SmallGraph& g, const gcmi_sma
   return GCMI_OK;
 }
 
-// the second stream of gcmi_small_fit and its events: created once per process (one process per GPU)
+// the second stream of gcmi_small_fit and its events: one set per DEVICE (created on the device that is current at
+// the first call for it, and only ever used there); `busy` serialises the calls that use it -- two host threads
+// enqueueing gcmi_small_fit at once would otherwise share ev_start / ev_conv / ev_free and corrupt each other's order
 struct SideStream {
   hipStream_t st;
   hipEvent_t ev_start, ev_conv[2], ev_free[2];
+  std::mutex busy;
 };
 static SideStream* side_stream() {
+  constexpr int kMaxDev = 64;
   static std::mutex mu;
-  static SideStream* s = nullptr;
-  static bool failed = false;
+  static SideStream* per_dev[kMaxDev] = {nullptr};
+  static bool failed[kMaxDev] = {false};
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;  // the one-stream path
   std::lock_guard<std::mutex> lock(mu);
-  if (s || failed) return s;
+  if (per_dev[dev] || failed[dev]) return per_dev[dev];
+  SideStream*& s = per_dev[dev];
   SideStream* n = new SideStream();
   bool ok = hipStreamCreateWithFlags(&n->st, hipStreamNonBlocking) == hipSuccess;
   hipEvent_t* evs[5] = {&n->ev_start, &n->ev_conv[0], &n->ev_conv[1], &n->ev_free[0], &n->ev_free[1]};
   for (int i = 0; ok && i < 5; ++i) ok = hipEventCreateWithFlags(evs[i], hipEventDisableTiming) == hipSuccess;
   if (!ok) {
-    failed = true;  // no overlap then: the one-stream path is always valid
+    failed[dev] = true;  // no overlap then: the one-stream path is always valid
     delete n;
     return nullptr;
   }
@@ -1922,6 +1940,15 @@ int gcmi_small_fit(const gcmi_model_desc* m, float* d_params, float* d_grads, fl
                    const gcmi_model_io* io, const gcmi_small_batch* batches, int64_t n_batches, int64_t ws_atoms,
                    int64_t ws_mols, float lr, float beta1, float beta2, float eps, int64_t first_step,
                    float* d_losses, int64_t* grad_lo, int64_t* grad_hi, void* stream) {
+  return gcmi_small_fit_dp(m, d_params, d_grads, d_adam_m, d_adam_v, io, batches, n_batches, ws_atoms, ws_mols, lr, beta1,
+                           beta2, eps, first_step, d_losses, grad_lo, grad_hi, nullptr, nullptr, stream);
+}
+
+int gcmi_small_fit_dp(const gcmi_model_desc* m, float* d_params, float* d_grads, float* d_adam_m, float* d_adam_v,
+                      const gcmi_model_io* io, const gcmi_small_batch* batches, int64_t n_batches, int64_t ws_atoms,
+                      int64_t ws_mols, float lr, float beta1, float beta2, float eps, int64_t first_step,
+                      float* d_losses, int64_t* grad_lo, int64_t* grad_hi, gcmi_grad_sync_fn sync, void* sync_ctx,
+                      void* stream) {
   SRUN(small_check(m));
   GCMI_CHECK_ARG(d_params && d_grads && d_adam_m && d_adam_v && io && io->d_workspace && (batches || n_batches == 0),
                  "small_fit: NULL buffer");
@@ -1958,6 +1985,8 @@ int gcmi_small_fit(const gcmi_model_desc* m, float* d_params, float* d_grads, fl
   // caller's; the two parities of the conv outputs / statistics keep them apart.  (GCMI_SMALL_OVERLAP=0: one stream.)
   static const bool overlap_env = !(getenv("GCMI_SMALL_OVERLAP") && atoi(getenv("GCMI_SMALL_OVERLAP")) == 0);
   SideStream* side = (!full && overlap_env && n_batches > 1) ? side_stream() : nullptr;
+  std::unique_lock<std::mutex> side_lock;
+  if (side) side_lock = std::unique_lock<std::mutex>(side->busy);  // held while this call enqueues
   std::vector<SmallGraph> graphs((size_t)n_batches);
   for (int64_t i = 0; i < n_batches; ++i) {
     const gcmi_small_batch* b = batches + i;
@@ -2026,6 +2055,12 @@ int gcmi_small_fit(const gcmi_model_desc* m, float* d_params, float* d_grads, fl
     ra.bsum = m->batch_norm ? c.accs + c.w.bsum : nullptr;
     SRUN(launch_readout(c, g, ra));
     SRUN(small_backward(c, g, b, d_grads));
+    // data parallel: the ranks' gradients of the trained range are summed here, in order on the step's stream,
+    // between the backward launches above and the Adam launch below (the caller's callback enqueues the all-reduce)
+    if (sync != nullptr && sync(sync_ctx, d_grads + lo, hi - lo, stream) != 0) {
+      set_error("small_fit: the gradient all-reduce callback failed at step %lld", (long long)(first_step + i));
+      return GCMI_ERR_LAUNCH;
+    }
     // Adam over the trained range, loss, running statistics, counters, zeroing
     StepEnd se;
     memset(&se, 0, sizeof(se));

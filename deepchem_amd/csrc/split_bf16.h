@@ -34,6 +34,34 @@ __device__ __forceinline__ void split3(float x, unsigned& p1, unsigned& p2, unsi
   p3 = q3 << 16;
 }
 
+// ---- bfloat16 activation storage (gcmi_model_desc.storage == 1): raw 16-bit patterns in HBM, fp32 everywhere else
+typedef unsigned short bf16_t;
+
+// two floats -> one dword of two bf16 (round to nearest even, v_cvt_pk_bf16_f32; a NaN stays a NaN): low half = a
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+// the value a float has after one trip through bf16 storage
+__device__ __forceinline__ float round_bf16(float a) { return bf16_lo(pack_bf16x2(a, 0.f)); }
+// 8 (4) bf16 of a 16-byte (8-byte) piece -> floats
+__device__ __forceinline__ void widen8(const uint4 r, float (&v)[8]) {
+  v[0] = bf16_lo(r.x); v[1] = bf16_hi(r.x); v[2] = bf16_lo(r.y); v[3] = bf16_hi(r.y);
+  v[4] = bf16_lo(r.z); v[5] = bf16_hi(r.z); v[6] = bf16_lo(r.w); v[7] = bf16_hi(r.w);
+}
+__device__ __forceinline__ float4 widen4(const uint2 r) {
+  return make_float4(bf16_lo(r.x), bf16_hi(r.x), bf16_lo(r.y), bf16_hi(r.y));
+}
+__device__ __forceinline__ uint2 narrow4(float a, float b, float c, float d) {
+  return make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+}
+// two floats that ARE bf16 values (low 16 bits zero) -> their packed pair, exactly (one v_perm_b32)
+__device__ __forceinline__ unsigned pack_exact_bf16x2(float a, float b) {
+  return __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u);
+}
+
 struct Frag3 {
   u32x4 p[3];
 };

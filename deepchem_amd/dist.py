@@ -74,6 +74,45 @@ class FlatGradAllReduce:
             g.copy_(v)
 
 
+class FlatGradArena:
+    """One flat fp32 buffer behind ``p.grad`` of every trainable parameter of a module whose backward is driven by
+    autograd (``MPNNModel``, ``WeaveModel``): autograd accumulates into an existing ``.grad`` in place, so the
+    gradients of a step land side by side and the data-parallel exchange is ``FlatGradAllReduce.reduce_flat`` on the
+    arena -- one collective, no copy in, no copy out.  (``GraphConvModel`` has its own arena in ``native.NativeNet``.)"""
+
+    def __init__(self, module: torch.nn.Module):
+        ps = [p for p in module.parameters() if p.requires_grad]
+        if not ps:
+            raise ValueError("the module has no trainable parameters")
+        dev, dt = ps[0].device, ps[0].dtype
+        if any(p.device != dev or p.dtype != dt for p in ps):
+            raise ValueError("parameters on several devices / of several dtypes")
+        sizes = [((p.numel() + 3) // 4) * 4 for p in ps]  # every block 16-byte aligned
+        self.flat = torch.zeros(sum(sizes), dtype=dt, device=dev)
+        self.views = []
+        off = 0
+        for p, n in zip(ps, sizes):
+            self.views.append((p, self.flat[off:off + p.numel()].view_as(p)))
+            off += n
+
+    def attach(self) -> None:
+        """Instead of ``optimizer.zero_grad()``: every gradient a zeroed view of the arena."""
+        self.flat.zero_()
+        for p, v in self.views:
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                p.grad = v
+
+    def covers(self, module: torch.nn.Module) -> bool:
+        """Are the module's trainable parameters still exactly the ones this arena was built for?"""
+        ps = [p for p in module.parameters() if p.requires_grad]
+        return len(ps) == len(self.views) and all(a is b for a, (b, _) in zip(ps, self.views))
+
+    def intact(self) -> bool:
+        """Did the backward leave every gradient in the arena (it replaces ``.grad`` only in exotic cases:
+        sparse gradients, ``create_graph``)?"""
+        return all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in self.views)
+
+
 def shard_model(model, group=None) -> None:
     """Make ``model.fit*`` data-parallel across the initialised process group:
     broadcast rank 0's parameters and buffers, then all-reduce gradients each step."""
@@ -83,3 +122,11 @@ def shard_model(model, group=None) -> None:
         for t in list(model.model.parameters()) + list(model.model.buffers()):
             dist.broadcast(t, src=0, group=group)
     model._grad_sync = FlatGradAllReduce(group=group)
+    # models whose backward runs through autograd get one flat gradient arena, so that their exchange is the same single
+    # zero-copy all-reduce (GraphConvModel's native step brings its own)
+    model._grad_arena = None
+    if not hasattr(model.model, "_native_net"):
+        try:
+            model._grad_arena = FlatGradArena(model.model)
+        except ValueError:
+            model._grad_arena = None

@@ -39,8 +39,9 @@ from deepchem_amd.models.torch_models.torch_model import TorchModel
 from deepchem_amd.utils.pytorch_utils import get_activation
 
 
-_BF16_ONLY_SMALL = ("activation_storage='bf16' is implemented by the small-batch engine: GraphConvModel.fit / predict on a "
-                    "ConvMol dataset with batch_size x mean atoms <= 16 384 and the model's own loss and optimizer")
+_BF16_NATIVE_ONLY = ("activation_storage='bf16' runs on the library's own step only (gcmi_small_* for small batches, "
+                     "gcmi_model_* with storage = 1 for large ones): the model's own loss and optimizer, no dropout in "
+                     "training mode, no uncertainty head; the layer-by-layer autograd path has no bf16 form")
 
 
 class TrimGraphOutput(nn.Module):
@@ -182,8 +183,6 @@ class _GraphConvTorchModel(nn.Module):
     def forward(self, inputs, training=False) -> List[torch.Tensor]:
         """inputs = [atom_features, degree_slice, membership, n_samples, deg_adj_1..10]
         (graphconvmodel.py:202-208), or a ``deepchem_amd.data.collate.DeviceBatch``."""
-        if self.activation_storage != "fp32":
-            raise NotImplementedError(_BF16_ONLY_SMALL)
         graph = getattr(inputs, "graph", None)
         if graph is not None:  # pre-collated batch already resident on the GPU
             atom_features, n_samples = inputs.atom_features, inputs.n_samples
@@ -201,6 +200,8 @@ class _GraphConvTorchModel(nn.Module):
             native = self._native_net()
             if native is not None:  # prediction: the whole forward is one C call
                 return self._native_outputs(native, x, graph, n_samples, self.training)
+        if self.activation_storage != "fp32":
+            raise NotImplementedError(_BF16_NATIVE_ONLY)
         for i in range(len(self.graph_convs)):
             bn_t, has_bn, bn_train, eps, mom = self._bn_args(i)
             use_dropout = training and not isinstance(self.dropouts[i], nn.Identity)
@@ -454,14 +455,16 @@ class GraphConvModel(TorchModel):
         n = packed.n_mols
         T = self.n_tasks
         y = np.asarray(y)
+        # a y of another size goes to the per-batch path, which raises the reference's own shape error for it (the
+        # one-hot reshape below would raise an opaque one -- or silently misalign labels when the sizes divide)
+        if y.size != n * T:
+            return None
         if self.mode == 'classification':
             def one_hot(a):
                 return to_one_hot(a.flatten(), self.n_classes).reshape(-1, T, self.n_classes)
             y_dev = resident_labels(packed, self.device, y, one_hot, ("y", ("one_hot", T, self.n_classes)))
             label_stride = T * self.n_classes
         else:
-            if y.size != n * T:
-                return None
             y_dev = resident_labels(packed, self.device, y.reshape(n, T), None, ("y", None))
             label_stride = T
         w = np.asarray(w)
@@ -479,15 +482,14 @@ class GraphConvModel(TorchModel):
         engine: the whole loop of fit_generator runs inside libgcmi.so, ``small_chunk_batches`` optimizer steps
         per call (same batches, same order, same losses, logging windows and checkpoint steps)."""
         done = None
+        # (data parallel: the engine takes a gradient exchange that works on the flat arena, deepchem_amd.dist)
         plain = (variables is None and loss is None and not callbacks and self.regularization_loss is None
-                 and self._grad_sync is None)
+                 and (self._grad_sync is None or hasattr(self._grad_sync, "reduce_flat")))
         if plain:
             done = self._fit_small(dataset, nb_epoch, max_checkpoints_to_keep, checkpoint_interval, deterministic,
                                    restore, all_losses)
         if done is not None:
             return done
-        if self.model.activation_storage != "fp32":
-            raise NotImplementedError(_BF16_ONLY_SMALL)
         return super(GraphConvModel, self).fit(dataset, nb_epoch, max_checkpoints_to_keep, checkpoint_interval,
                                                deterministic, restore, variables, loss, callbacks, all_losses)
 
@@ -566,7 +568,7 @@ class GraphConvModel(TorchModel):
                 if r < B:
                     w_t[b * B + r:(b + 1) * B] = 0  # padding rows of a ragged last batch carry no weight
             collator.bind(ch, [B] * ch.n_batches, labels=y_t, label_stride=label_stride, weights=w_t, weight_stride=T)
-            losses = engine.fit(ch.descs, self._pytorch_optimizer, ch.max_atoms, B)
+            losses = engine.fit(ch.descs, self._pytorch_optimizer, ch.max_atoms, B, grad_sync=self._grad_sync)
             held.hold(ch)
             pending.append((self._global_step + 1, losses))
             self._global_step += ch.n_batches
@@ -665,8 +667,6 @@ class GraphConvModel(TorchModel):
             plan = self._small_predict_plan(dataset, deterministic)
             if plan is not None:
                 return plan
-        if self.model.activation_storage != "fp32":
-            raise NotImplementedError(_BF16_ONLY_SMALL)
         fast = self._fast_generator(dataset, epochs, mode, deterministic, pad_batches)
         if fast is not None:
             return fast

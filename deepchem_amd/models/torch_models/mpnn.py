@@ -302,7 +302,10 @@ class _MPNNTorchModel(nn.Module):
             rp = MatmulFn.apply(m, self.gru_Wr, self.gru_br, h, self.gru_Ur)
             z, r, hr = GruGatesFn.apply(zp, rp, h)
             hpre = MatmulFn.apply(m, self.gru_Wh, self.gru_bh, hr, self.gru_Uh)
-            h = GruOutFn.apply(z, hpre, m)
+            # Keras GatedRecurrentUnit.call (models/layers.py:3796-3799): inputs = [out, message] and the carry is
+            # z * inputs[0] = z * h (the torch port of the layer, torch_models/layers.py:2912, carries z * message;
+            # the stand-alone GatedRecurrentUnit of mpnn_layers.py keeps that, its reference asset pins it)
+            h = GruOutFn.apply(z, hpre, h)
         emb = ops.LinearFn.apply(h, self.atom_embed.weight, self.atom_embed.bias, False, False)
         B = self.batch_size
         c = torch.zeros((B, d), dtype=torch.float32, device=dev)

@@ -306,14 +306,23 @@ class TorchModel(Model):
         """One optimizer step on one prepared batch (torch_model.py:435-443): zero_grad, forward,
         loss over the loss outputs, backward, gradient all-reduce on data-parallel ranks, step.
         Subclasses replace this by a fused native step."""
-        optimizer.zero_grad()
+        arena = getattr(self, "_grad_arena", None) if self._grad_sync is not None else None
+        if arena is not None and not arena.covers(self.model):
+            arena = None  # somebody replaced parameters since shard_model: the per-tensor exchange handles any set
+        if arena is not None:
+            arena.attach()  # zeroed views of one flat buffer behind every p.grad (deepchem_amd.dist.FlatGradArena)
+        else:
+            optimizer.zero_grad()
         outputs = self._forward_lists(inputs)
         if self._roles.declared:
             outputs = [outputs[i] for i in self._roles.loss]
         batch_loss = loss(outputs, labels, weights)
         batch_loss.backward()
         if self._grad_sync is not None:
-            self._grad_sync(self.model)
+            if arena is not None and arena.intact() and hasattr(self._grad_sync, "reduce_flat"):
+                self._grad_sync.reduce_flat(arena.flat)  # ONE zero-copy collective
+            else:
+                self._grad_sync(self.model)
         optimizer.step()
         return batch_loss
 

@@ -166,7 +166,9 @@ class NativeNet:
     def _workspace(self, n_atoms: int, n_mols: int) -> torch.Tensor:
         need = int(_lib.load().gcmi_model_workspace_floats(ctypes.byref(self.desc), n_atoms, n_mols))
         if need < 0:
-            raise _lib.GcmiError("gcmi_model_workspace_floats rejected the model description")
+            why = _lib.load().gcmi_last_error()
+            raise _lib.GcmiError("gcmi_model_workspace_floats rejected the model description: %s" %
+                                 (why.decode() if isinstance(why, bytes) else why))
         if self._ws is None or self._ws.numel() < need or self._ws.device != self.flat.device:
             self._ws = torch.empty(int(need * 1.1) + 1024, dtype=torch.float32, device=self.flat.device)
         return self._ws

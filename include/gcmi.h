@@ -556,6 +556,23 @@ int gcmi_small_fit(const gcmi_model_desc* m, float* d_params, float* d_grads, fl
                    const gcmi_model_io* io, const gcmi_small_batch* batches, int64_t n_batches, int64_t ws_atoms,
                    int64_t ws_mols, float lr, float beta1, float beta2, float eps, int64_t first_step,
                    float* d_losses, int64_t* grad_lo, int64_t* grad_hi, void* stream);
+/* Data-parallel form (molecules sharded by rank, ONE flat-bucket all-reduce per step; the reference
+ * shards disk shards by rank, data/pytorch_datasets.py:104-113, and leaves the gradient exchange to torch DDP):
+ * exactly gcmi_small_fit, with `sync` called once per optimizer step between the backward launches and the Adam
+ * launch of that step, on the calling thread:
+ *     sync(ctx, d_grads + *grad_lo, *grad_hi - *grad_lo, stream)
+ * It must ENQUEUE, in order on `stream`, a sum all-reduce over the ranks of that range (and whatever scaling the
+ * caller's mean needs) and return 0; a non-zero return aborts the call with GCMI_ERR_LAUNCH.  The library makes no
+ * RCCL call itself: the host side owns the communicator (torch.distributed's "nccl" backend = RCCL over xGMI), and
+ * the callback is the only thing it has to provide.  sync == NULL: gcmi_small_fit.  BatchNorm statistics stay per
+ * rank.  In reference gradient mode the GraphConv stacks of the next steps still run ahead on the second stream:
+ * nothing they read is trained, so nothing they read is exchanged.                                         */
+typedef int (*gcmi_grad_sync_fn)(void* ctx, float* d_grad_range, int64_t n_floats, void* stream);
+int gcmi_small_fit_dp(const gcmi_model_desc* m, float* d_params, float* d_grads, float* d_adam_m, float* d_adam_v,
+                      const gcmi_model_io* io, const gcmi_small_batch* batches, int64_t n_batches, int64_t ws_atoms,
+                      int64_t ws_mols, float lr, float beta1, float beta2, float eps, int64_t first_step,
+                      float* d_losses, int64_t* grad_lo, int64_t* grad_hi, gcmi_grad_sync_fn sync, void* sync_ctx,
+                      void* stream);
 int gcmi_small_predict(const gcmi_model_desc* m, const float* d_params, const gcmi_model_io* io,
                        const gcmi_small_batch* batches, int64_t n_batches, int64_t ws_atoms, int64_t ws_mols,
                        void* stream);

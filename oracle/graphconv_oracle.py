@@ -41,6 +41,58 @@ import torch.nn.functional as F
 
 MAX_DEG = 10
 
+# The reference casts to float32 in GraphConv (layers.py:6210-6214 `.type(torch.float32)`) and sums segments in float
+# (`data.float()`, utils/pytorch_utils.py:71): WORK_DTYPE is that float32.  ``precision(torch.float64)`` re-runs the
+# SAME op sequence in double precision -- not the reference's arithmetic, but the yardstick that tells how far the
+# reference's own float32 accumulation (BatchNorm statistics over 10^5..10^6 rows) is from exact arithmetic, which
+# bounds how closely ANY other implementation can be asked to match it at large batch sizes.
+WORK_DTYPE = torch.float32
+
+
+def _identity(t):
+    return t
+
+
+# What the reference does NOT have: bf16 storage of the activations (deepchem_amd's opt-in activation_storage="bf16",
+# BASELINE.json config 2).  STORE is applied wherever that mode keeps a matrix in HBM (atom features, neighbour sums,
+# GraphConv outputs, pooled rows, the dense output); by default it is the identity and this file is the reference's
+# arithmetic.  ``bf16_storage()`` makes it a round-to-nearest-even to bfloat16 with a straight-through gradient, which
+# is what a backward pass over the STORED values computes.  Used by tests of that mode only; it is not pinned by the
+# reference (which has no such mode) -- the float32 oracle stays the anchor those tests also compare with.
+STORE = _identity
+
+
+def _round_bf16_ste(t):
+    if not t.is_floating_point():
+        return t
+    r = t.detach().to(torch.float32).to(torch.bfloat16).to(t.dtype)
+    return t + (r - t.detach())
+
+
+class bf16_storage:
+    def __enter__(self):
+        global STORE
+        self.prev = STORE
+        STORE = _round_bf16_ste
+
+    def __exit__(self, *exc):
+        global STORE
+        STORE = self.prev
+
+
+class precision:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global WORK_DTYPE
+        self.prev = WORK_DTYPE
+        WORK_DTYPE = self.dtype
+
+    def __exit__(self, *exc):
+        global WORK_DTYPE
+        WORK_DTYPE = self.prev
+
 
 # --------------------------------------------------------------------------- layers
 def sum_neigh(atoms: torch.Tensor, deg_adj_lists: Sequence[torch.Tensor],
@@ -67,7 +119,7 @@ def graph_conv(inputs: Sequence[torch.Tensor], W_list: Sequence[torch.Tensor],
     deg_slice = inputs[1]
     deg_adj_lists = inputs[3:]
     cut = grad_mode == "reference"
-    summed = sum_neigh(atom_features, deg_adj_lists, max_degree)
+    summed = [STORE(t) for t in sum_neigh(atom_features, deg_adj_lists, max_degree)]
     if cut:
         summed = [s.detach() for s in summed]  # :6244 / :6204
     split = torch.split(atom_features, deg_slice[:, 1].tolist())  # :6199-6201
@@ -77,12 +129,12 @@ def graph_conv(inputs: Sequence[torch.Tensor], W_list: Sequence[torch.Tensor],
     for deg in range(1, max_degree + 1):
         rel = summed[deg - 1]
         self_atoms = split[deg - min_degree]
-        rel_out = torch.matmul(rel.type(torch.float32), next(w)) + next(b)
-        self_out = torch.matmul(self_atoms.type(torch.float32), next(w)) + next(b)
+        rel_out = torch.matmul(rel.type(WORK_DTYPE), next(w)) + next(b)
+        self_out = torch.matmul(self_atoms.type(WORK_DTYPE), next(w)) + next(b)
         o = rel_out + self_out
         blocks.append(o.detach() if cut else o)  # :6216
     if min_degree == 0:
-        o = torch.matmul(split[0].type(torch.float32), next(w)) + next(b)
+        o = torch.matmul(split[0].type(WORK_DTYPE), next(w)) + next(b)
         blocks.insert(0, o.detach() if cut else o)  # :6226
     out = torch.concat(blocks, 0)
     if activation is not None:
@@ -104,7 +156,7 @@ def graph_pool(inputs: Sequence[torch.Tensor], min_degree: int = 0,
     for deg in range(1, max_degree + 1):
         self_atoms = split[deg - min_degree]
         if deg_adj_lists[deg - 1].shape[0] == 0:
-            blocks.append(torch.zeros((0, self_atoms.shape[-1])))  # :6346-6350
+            blocks.append(torch.zeros((0, self_atoms.shape[-1]), dtype=WORK_DTYPE))  # :6346-6350
         else:
             cand = torch.concat(
                 [torch.unsqueeze(self_atoms, 1), atom_features[deg_adj_lists[deg - 1]]], 1)
@@ -122,7 +174,7 @@ def unsorted_segment_sum(data: torch.Tensor, segment_ids: torch.Tensor,
     if data.shape[0] != segment_ids.shape[0]:
         raise AssertionError("segment_ids should be the same size as dimension 0 of input.")
     idx = segment_ids.view(-1, *([1] * (data.dim() - 1))).expand_as(data)
-    out = torch.zeros(num_segments, *data.shape[1:]).scatter_add(0, idx, data.float())
+    out = torch.zeros(num_segments, *data.shape[1:], dtype=WORK_DTYPE).scatter_add(0, idx, data.type(WORK_DTYPE))
     return out.type(data.dtype)
 
 
@@ -288,16 +340,16 @@ def model_forward(cfg: ModelConfig, st: Dict[str, torch.Tensor], inputs: Sequenc
     membership = inputs[2].to(torch.int64)
     n_samples = int(inputs[3])
     deg_adjs = [a.to(torch.int64) for a in inputs[4:]]
-    x = atom_features
+    x = STORE(atom_features)
     for i in range(len(cfg.graph_conv_layers)):
         W = [st["graph_convs.%d.W_list.%d" % (i, k)] for k in range(2 * MAX_DEG + 1)]
         b = [st["graph_convs.%d.b_list.%d" % (i, k)] for k in range(2 * MAX_DEG + 1)]
-        gc = graph_conv([x, degree_slice, membership] + deg_adjs, W, b, activation=F.relu,
-                        grad_mode=grad_mode)
+        gc = STORE(graph_conv([x, degree_slice, membership] + deg_adjs, W, b, activation=F.relu,
+                              grad_mode=grad_mode))
         if cfg.batch_normalize:
             gc = _batch_norm(gc, st, i, bn_training)
-        x = graph_pool([gc, degree_slice, membership] + deg_adjs)
-    dense = F.relu(F.linear(x, st["dense.weight"], st["dense.bias"]))
+        x = STORE(graph_pool([gc, degree_slice, membership] + deg_adjs))
+    dense = STORE(F.relu(F.linear(x, st["dense.weight"], st["dense.bias"])))
     if cfg.batch_normalize:
         dense = _batch_norm(dense, st, len(cfg.graph_conv_layers), bn_training)
     fp = graph_gather([dense, degree_slice, membership] + deg_adjs, cfg.batch_size,

@@ -110,12 +110,12 @@ class MPNNOracle:
         self.n_atom_feat, self.d, self.T, self.M, self.B = n_atom_feat, n_hidden, T, M, batch_size
         self.mode, self.n_tasks, self.n_classes = mode, n_tasks, n_classes
 
-    def forward(self, atom_features, pair_features, atom_split, atom_to_pair, n_samples):
+    def message_passing(self, atom_features, pair_features, atom_to_pair):
+        """MessagePassing.call (models/layers.py:3692-3709): the atom states after T rounds."""
         p, d = self.p, self.d
         x = torch.as_tensor(np.asarray(atom_features)).float()
         pf = torch.as_tensor(np.asarray(pair_features)).float()
         a2p = torch.as_tensor(np.asarray(atom_to_pair)).long()
-        split = torch.as_tensor(np.asarray(atom_split)).long()
         n = x.shape[0]
         h = torch.cat([x, torch.zeros((n, d - x.shape[1]))], 1)
         for _ in range(self.T):
@@ -124,7 +124,15 @@ class MPNNOracle:
             m = torch.zeros((n, d)).index_add(0, a2p[:, 0], msg)
             z = torch.sigmoid(m @ p["gru_Wz"] + h @ p["gru_Uz"] + p["gru_bz"])
             r = torch.sigmoid(m @ p["gru_Wr"] + h @ p["gru_Ur"] + p["gru_br"])
-            h = (1 - z) * torch.tanh(m @ p["gru_Wh"] + (h * r) @ p["gru_Uh"] + p["gru_bh"]) + z * m
+            # Keras carry (models/layers.py:3796-3799: "+ z * inputs[0]", inputs = [out, message]): z * h, not the
+            # torch layer port's z * x (gru() above restates that port for its reference asset)
+            h = (1 - z) * torch.tanh(m @ p["gru_Wh"] + (h * r) @ p["gru_Uh"] + p["gru_bh"]) + z * h
+        return h
+
+    def forward(self, atom_features, pair_features, atom_split, atom_to_pair, n_samples):
+        p, d = self.p, self.d
+        split = torch.as_tensor(np.asarray(atom_split)).long()
+        h = self.message_passing(atom_features, pair_features, atom_to_pair)
         emb = h @ p["atom_embed.weight"].t() + p["atom_embed.bias"]
         c = torch.zeros((self.B, d))
         hs = torch.zeros((self.B, d))

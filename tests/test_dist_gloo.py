@@ -110,3 +110,59 @@ def test_two_ranks_reproduce_the_global_batch_gradient(tmp_path):
             assert k not in r0["grads"]
             continue
         assert torch.allclose(p.grad, r0["grads"][k], atol=1e-6), k
+
+
+def _arena_worker(rank, world, port, tmp):
+    """The generic (autograd-driven) data-parallel step of TorchModel._train_step with a flat gradient arena:
+    attach -> backward -> ONE reduce_flat on the arena."""
+    from deepchem_amd.dist import FlatGradArena
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(200 + rank)
+        holder = _Holder(_Tiny())
+        shard_model(holder)
+        arena = holder._grad_arena
+        assert isinstance(arena, FlatGradArena) and arena.covers(holder.model)
+        gen = torch.Generator().manual_seed(1)
+        X = torch.randn((8, 6), generator=gen)
+        Y = torch.randn((8, 3), generator=gen)
+        idx = shard_indices(np.arange(8))
+        for _ in range(2):  # the second round starts from re-zeroed views of the same buffer
+            arena.attach()
+            ((holder.model(X[idx]) - Y[idx])**2).mean().backward()
+            assert arena.intact()
+            holder._grad_sync.reduce_flat(arena.flat)
+        # every trainable parameter's .grad is a view of the one buffer; a parameter the loss never reaches keeps zeros
+        base = arena.flat.data_ptr()
+        for p in holder.model.parameters():
+            assert base <= p.grad.data_ptr() < base + 4 * arena.flat.numel()
+        assert float(holder.model.frozen.weight.grad.abs().max()) == 0.0
+        grads = {k: p.grad.clone() for k, p in holder.model.named_parameters()}
+        torch.save({"grads": grads, "state": {k: v.clone() for k, v in holder.model.state_dict().items()}},
+                   os.path.join(tmp, "arena%d.pt" % rank))
+        # a replaced parameter is noticed (TorchModel._train_step then takes the per-tensor exchange)
+        holder.model.b.weight = torch.nn.Parameter(holder.model.b.weight.detach().clone())
+        assert not arena.covers(holder.model)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_flat_gradient_arena_on_two_ranks(tmp_path):
+    world = 2
+    mp.spawn(_arena_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(str(tmp_path / "arena0.pt"))
+    r1 = torch.load(str(tmp_path / "arena1.pt"))
+    for k in r0["grads"]:
+        assert torch.allclose(r0["grads"][k], r1["grads"][k], atol=1e-7), k
+    ref = _Tiny()
+    ref.load_state_dict(r0["state"])
+    gen = torch.Generator().manual_seed(1)
+    X = torch.randn((8, 6), generator=gen)
+    Y = torch.randn((8, 3), generator=gen)
+    ((ref(X) - Y)**2).mean().backward()
+    for k, p in ref.named_parameters():
+        want = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert torch.allclose(want, r0["grads"][k], atol=1e-6), k

@@ -254,17 +254,31 @@ def test_bf16_storage_follows_fp32_within_bf16_resolution(grad_mode):
     assert np.abs(p16 - p32).max() < 0.6 and np.abs(p16 - p32).mean() < 0.1, (np.abs(p16 - p32).max(), np.abs(p16 - p32).mean())
 
 
-def test_bf16_storage_is_refused_outside_the_small_engine():
+def test_bf16_storage_is_refused_only_where_no_kernel_has_it():
+    """bf16 storage runs on the library's own steps: the small-batch engine, and (round 3) the streaming kernels of
+    the per-batch path (gcmi_model_* with storage = 1).  What is left without a bf16 form -- the layer-by-layer
+    autograd path a custom loss needs, shapes the streaming kernels do not cover -- refuses instead of computing in
+    some other way."""
     import deepchem_amd as dc
+    from deepchem_amd._lib import GcmiError
     from deepchem_amd.utils.synthetic import synthetic_labels, synthetic_molecules
     packed = synthetic_molecules(16, seed=1, max_atoms=20)
     y, w = synthetic_labels(16, 2, "classification", 1)
     model = dc.models.torch_models.GraphConvModel(2, number_input_features=[75, 64], batch_size=8,
                                                   device=torch.device(DEV), activation_storage="bf16")
     ds = dc.data.PackedDataset(packed, y, w)
-    model.fit(ds, nb_epoch=1, checkpoint_interval=0)           # small batches: runs
+    model.fit(ds, nb_epoch=1, checkpoint_interval=0)           # small batches: the engine
     assert model.predict(ds).shape == (16, 2, 2)
-    with pytest.raises(NotImplementedError, match="small-batch engine"):
-        model.fit(ds, nb_epoch=1, checkpoint_interval=0, callbacks=[lambda m, s: None])   # per-batch path
+    seen = []
+    model.fit(ds, nb_epoch=1, checkpoint_interval=0, callbacks=[lambda m, s: seen.append(s)])   # per-batch path: streaming kernels
+    assert len(seen) == 2
+    with pytest.raises(NotImplementedError, match="library's own step"):
+        model.fit(ds, nb_epoch=1, checkpoint_interval=0, loss=lambda o, l, w_: (o[0] * 0).sum())   # autograd path
+    wide = dc.models.torch_models.GraphConvModel(2, number_input_features=[75, 128], graph_conv_layers=[128, 128],
+                                                 dense_layer_size=256, batch_size=8, device=torch.device(DEV),
+                                                 activation_storage="bf16")
+    wide.small_batch_engine = False
+    with pytest.raises(GcmiError, match="bf16 activation storage covers"):
+        wide.fit(ds, nb_epoch=1, checkpoint_interval=0)
     with pytest.raises(ValueError):
         dc.models.torch_models.GraphConvModel(2, number_input_features=[75, 64], activation_storage="fp8")

@@ -267,18 +267,15 @@ def test_full_mode_gradient_against_finite_differences():
     st = {k: (v.double() if v.is_floating_point() else v) for k, v in O.init_state(cfg, 1).items()}
 
     def run(st_):
-        # float64 end-to-end: bypass the float32 casts of graph_conv by patching type()
+        # float64 end-to-end (O.precision below)
         s2 = {k: v.clone() for k, v in st_.items()}
         outs = O.model_forward(cfg, s2, inputs, bn_training=True, grad_mode="full")
         return O.batch_loss(cfg, O.loss_outputs(cfg, outs), labels, weights)
 
-    # the oracle keeps the reference's float32 casts (.type(float32), .float());
-    # make them the identity so that the whole chain runs in float64
-    orig_type = torch.Tensor.type
-    orig_float = torch.Tensor.float
-    torch.Tensor.type = lambda self, *a, **k: self if a and a[0] == torch.float32 else orig_type(self, *a, **k)
-    torch.Tensor.float = lambda self: self
-    torch.set_default_dtype(torch.float64)
+    # the oracle keeps the reference's float32 casts (.type(float32), .float()) in its working dtype: O.precision
+    # re-runs the same op sequence in float64
+    ctx = O.precision(torch.float64)
+    ctx.__enter__()
     try:
         keys = ["graph_convs.0.W_list.2", "graph_convs.1.W_list.3", "graph_convs.0.b_list.0",
                 "batch_norms.0.weight", "dense.weight", "reshape_dense.bias"]
@@ -301,6 +298,4 @@ def test_full_mode_gradient_against_finite_differences():
                 fd = (lp - lm) / (2 * eps)
                 assert abs(fd - float(gk.view(-1)[pos])) < 1e-6 + 1e-4 * abs(fd), (k, pos)
     finally:
-        torch.Tensor.type = orig_type
-        torch.Tensor.float = orig_float
-        torch.set_default_dtype(torch.float32)
+        ctx.__exit__(None, None, None)
