@@ -109,7 +109,9 @@ int win_gather_max_h(const gcmi_graph* g, const unsigned short* d_x, int64_t ldx
 int fwd_h_gemm(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_end, const unsigned short* d_a1, int64_t lda1,
                int32_t k1, const float* d_w1, const int64_t* w1_off, const unsigned short* d_a2, int64_t lda2, int32_t k2,
                const float* d_w2, const int64_t* w2_off, const float* d_bias, const int64_t* bias_off, int32_t n_out,
-               int32_t trans_w, int32_t act, unsigned short* d_out, int64_t ldo, double* d_stats, hipStream_t sm);
+               int32_t trans_w, int32_t act, unsigned short* d_out, int64_t ldo, double* d_stats, float* d_wimg_scratch,
+               hipStream_t sm);
+constexpr int64_t kFwdHWimgFloats = 16 * 20 * 3 * 256;  // scratch of fwd_h_gemm: split weight fragments of <= 16 segments
 
 bool gemm_exact_mode();  // gcmi_set_option(GCMI_OPT_GEMM_EXACT)
 

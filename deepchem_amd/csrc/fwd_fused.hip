@@ -91,12 +91,30 @@ fwd_fused_kernel(FwdTable st, int n_tiles, FwdArgs a, int rev) {
   const int t_end = (int)((int64_t)(b + 1) * n_tiles / gridDim.x);
   const int my_tiles = t_end - t_begin;  // >= 1: the grid is never larger than the tile count
   auto tile_at = [&](int i) { return rev ? t_end - 1 - i : t_begin + i; };
+  // Tile -> (segment, first row, rows) by a cursor that moves with the walk: a workgroup's tiles are consecutive, so the
+  // segment changes now and then and a look-up is otherwise two scalar operations.  (The per-tile search it replaces --
+  // a loop of LDS reads over the segment starts, each landing in a vector register -- measured ~1 200 cycles per
+  // look-up in fwd_hd_kernel's phase clocks, csrc/fwd_bf16.hip.)
+  struct Cursor { int seg, t0, t1, r0, r1; } cur;
+  auto cur_load = [&]() {
+    cur.t0 = __builtin_amdgcn_readfirstlane(t_tile_s[cur.seg]);
+    cur.t1 = __builtin_amdgcn_readfirstlane(t_tile_s[cur.seg + 1]);
+    cur.r0 = __builtin_amdgcn_readfirstlane(t_begin_s[cur.seg]);
+    cur.r1 = __builtin_amdgcn_readfirstlane(t_end_s[cur.seg]);
+  };
+  {
+    const int first = tile_at(0);
+    int sg = 0;
+    for (int k = 1; k < n_seg; ++k) sg += first >= t_tile_s[k] ? 1 : 0;
+    cur.seg = __builtin_amdgcn_readfirstlane(sg);
+    cur_load();
+  }
   auto tile_info = [&](int tile, int& seg, int& row0, int& valid) {
-    int s = 0;
-    for (int k = 1; k < n_seg; ++k) s += tile >= t_tile_s[k] ? 1 : 0;
-    seg = s;
-    row0 = t_begin_s[s] + (tile - t_tile_s[s]) * ROWS;
-    const int left = t_end_s[s] - row0;
+    while (tile >= cur.t1) { ++cur.seg; cur_load(); }  // (uniform; empty segments are stepped over)
+    while (tile < cur.t0) { --cur.seg; cur_load(); }
+    seg = cur.seg;
+    row0 = cur.r0 + (tile - cur.t0) * ROWS;
+    const int left = cur.r1 - row0;
     valid = left < ROWS ? left : ROWS;
   };
 
@@ -343,12 +361,30 @@ fwd_reg_kernel(FwdTable st, int n_tiles, FwdArgs a, int rev) {
   const int t_end = __builtin_amdgcn_readfirstlane((int)((int64_t)(b + 1) * n_tiles / gridDim.x));
   const int my_tiles = t_end - t_begin;  // >= 1: the grid is never larger than the tile count
   auto tile_at = [&](int i) { return rev ? t_end - 1 - i : t_begin + i; };
+  // Tile -> (segment, first row, rows) by a cursor that moves with the walk: a workgroup's tiles are consecutive, so the
+  // segment changes now and then and a look-up is otherwise two scalar operations.  (The per-tile search it replaces --
+  // a loop of LDS reads over the segment starts, each landing in a vector register -- measured ~1 200 cycles per
+  // look-up in fwd_hd_kernel's phase clocks, csrc/fwd_bf16.hip.)
+  struct Cursor { int seg, t0, t1, r0, r1; } cur;
+  auto cur_load = [&]() {
+    cur.t0 = __builtin_amdgcn_readfirstlane(t_tile_s[cur.seg]);
+    cur.t1 = __builtin_amdgcn_readfirstlane(t_tile_s[cur.seg + 1]);
+    cur.r0 = __builtin_amdgcn_readfirstlane(t_begin_s[cur.seg]);
+    cur.r1 = __builtin_amdgcn_readfirstlane(t_end_s[cur.seg]);
+  };
+  {
+    const int first = tile_at(0);
+    int sg = 0;
+    for (int k = 1; k < n_seg; ++k) sg += first >= t_tile_s[k] ? 1 : 0;
+    cur.seg = __builtin_amdgcn_readfirstlane(sg);
+    cur_load();
+  }
   auto tile_info = [&](int tile, int& seg, int& row0, int& valid) {
-    int s = 0;
-    for (int k = 1; k < n_seg; ++k) s += tile >= t_tile_s[k] ? 1 : 0;
-    seg = __builtin_amdgcn_readfirstlane(s);  // LDS reads land in vector registers; these are uniform
-    row0 = __builtin_amdgcn_readfirstlane(t_begin_s[seg] + (tile - t_tile_s[seg]) * ROWS);
-    const int left = __builtin_amdgcn_readfirstlane(t_end_s[seg]) - row0;
+    while (tile >= cur.t1) { ++cur.seg; cur_load(); }  // (uniform; empty segments are stepped over)
+    while (tile < cur.t0) { --cur.seg; cur_load(); }
+    seg = cur.seg;
+    row0 = cur.r0 + (tile - cur.t0) * ROWS;
+    const int left = cur.r1 - row0;
     valid = left < ROWS ? left : ROWS;
   };
 

@@ -48,7 +48,8 @@ struct Ws {
   int64_t S[kMaxL], gc[kMaxL], pool[kMaxL], arg[kMaxL], bsum[kMaxL], bnv[kMaxL + 1];
   int64_t ldS[kMaxL], ngather[kMaxL];
   int64_t dense, arg_r, rsum, dfp, tA, tB, tC, tD, tE, total;
-  int64_t xb;  // storage == 1: bf16 copy of the atom features (ld = ldS[0])
+  int64_t xb;    // storage == 1: bf16 copy of the atom features (ld = ldS[0])
+  int64_t wimg;  // storage == 1: scratch of fwd_h_gemm (split weight fragments, rebuilt by every launch)
   // one region the backward zeroes with a single memset: [dlogits | dbsum per layer | lacc | acc]
   int64_t dlogits, dbsum[kMaxL], lacc, acc, acc2, z_end;
 };
@@ -79,7 +80,10 @@ static Ws carve(const gcmi_model_desc* m, int64_t N, int64_t B, int64_t ld_featu
     w.ldS[l] = h ? up8(w.ngather[l]) : up4(w.ngather[l]);
     const int64_t wd = m->conv_width[l];
     w.S[l] = take_act(N, w.ldS[l]);
-    if (h && l == 0) w.xb = take_act(N, w.ldS[0]);
+    if (h && l == 0) {
+      w.xb = take_act(N, w.ldS[0]);
+      w.wimg = take(kFwdHWimgFloats);
+    }
     w.gc[l] = take_act(N, wd);
     w.pool[l] = take_act(N, wd);
     w.arg[l] = take((N * wd + 3) / 4);
@@ -237,7 +241,8 @@ static int model_forward_h(const gcmi_model_desc* m, const gcmi_graph* g, const 
         TimedScope ts(GCMI_K_SEG_GEMM, st);
         const int rc = fwd_h_gemm(sg.n, sg.begin, sg.end, H(w.S[l]), w.ldS[l], K, d_params + m->off_conv_w[l], sg.w_rel, xin,
                                   ldin, K, d_params + m->off_conv_w[l], sg.w_self, ws + w.bsum[l], sg.b_off, W, 0, 1,
-                                  H(w.gc[l]), W, training ? reinterpret_cast<double*>(ws + w.acc) : nullptr, st);
+                                  H(w.gc[l]), W, training ? reinterpret_cast<double*>(ws + w.acc) : nullptr, ws + w.wimg,
+                                  st);
         if (rc == GCMI_ERR_UNSUPPORTED) set_error("bf16 activation storage: GraphConv %d has no bf16 product kernel", l);
         RUN(rc);
       }
@@ -271,7 +276,7 @@ static int model_forward_h(const gcmi_model_desc* m, const gcmi_graph* g, const 
       TimedScope ts(GCMI_K_SEG_GEMM, st);
       const int rc = fwd_h_gemm(1, &zero32, &nN, xin, ldin, Wl, d_params + m->off_dense_w, &zero64, nullptr, 0, 0, nullptr,
                                 nullptr, d_params + m->off_dense_b, &zero64, D, 1, 1, H(w.dense), D,
-                                training ? reinterpret_cast<double*>(ws + w.acc) : nullptr, st);
+                                training ? reinterpret_cast<double*>(ws + w.acc) : nullptr, ws + w.wimg, st);
       if (rc == GCMI_ERR_UNSUPPORTED) set_error("bf16 activation storage: the dense layer has no bf16 product kernel");
       RUN(rc);
     }
