@@ -74,8 +74,12 @@ struct FusedArgs {
 // HB: the block's forward activations (x = its ReLU output, In = its inputs) are stored as bf16
 // (gcmi_model_desc.storage == 1): they arrive as 8-byte pieces of four elements -- half the prefetch registers -- and
 // are widened on their way to LDS; a weight-gradient fragment of In then IS its own first bf16 piece (one v_perm_b32
-// per pair instead of the three-way split) and meets the three pieces of G in 3 MFMAs instead of 6.  Gradients (dy,
-// the outputs) stay fp32.
+// per pair instead of the three-way split).  The products of this form keep the terms above 2^-16: the result of every
+// forward product was itself rounded to 2^-9 when it was stored, so the third pieces of G and W buy nothing here --
+// dW += In^T G is In x the two leading pieces of G (2 MFMAs per fragment instead of 6), dIn = G W^T the three products
+// g1 w1 + g1 w2 + g2 w1 (3 instead of 6): the matrix pipe, which two waves per SIMD share and which bounds these
+// kernels together with the split's vector work, does half the work.  Accumulation stays fp32; gradients (dy, the
+// outputs) stay fp32.
 template <int NG, int KT, int NOPS, bool TRANS, bool RD, bool DGRAD, bool HB = false>
 __global__ void __launch_bounds__(DGRAD ? 512 : 256) __attribute__((amdgpu_waves_per_eu(2)))
 fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
@@ -461,7 +465,7 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
           const unsigned short* wrow = Wimg + ((size_t)(o * 3) * KP + kt * 32 + l31) * WP + ks * 16 + 8 * half;
           wv[u & 1][0] = *reinterpret_cast<const u32x4*>(wrow);
           wv[u & 1][1] = *reinterpret_cast<const u32x4*>(wrow + (size_t)KP * WP);
-          wv[u & 1][2] = *reinterpret_cast<const u32x4*>(wrow + (size_t)2 * KP * WP);
+          if constexpr (!HB) wv[u & 1][2] = *reinterpret_cast<const u32x4*>(wrow + (size_t)2 * KP * WP);
         };
         read_g(0);
         read_w(0);
@@ -478,11 +482,14 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
             if (t == TPW - 1) read_g(ks + 1);
           }
           if (on[t]) {  // uniform
-            const u32x4 w1 = wv[u & 1][0], w2 = wv[u & 1][1], w3 = wv[u & 1][2];
+            const u32x4 w1 = wv[u & 1][0], w2 = wv[u & 1][1];
             // rows of G x input columns: lane = input column, registers = rows; small terms first
-            accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[2]), as_bf16x8(w1), accs[t], 0, 0, 0);
-            accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[0]), as_bf16x8(w3), accs[t], 0, 0, 0);
-            accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[1]), as_bf16x8(w2), accs[t], 0, 0, 0);
+            if constexpr (!HB) {
+              const u32x4 w3 = wv[u & 1][2];
+              accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[2]), as_bf16x8(w1), accs[t], 0, 0, 0);
+              accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[0]), as_bf16x8(w3), accs[t], 0, 0, 0);
+              accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[1]), as_bf16x8(w2), accs[t], 0, 0, 0);
+            }
             accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[1]), as_bf16x8(w1), accs[t], 0, 0, 0);
             accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[0]), as_bf16x8(w2), accs[t], 0, 0, 0);
             accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[0]), as_bf16x8(w1), accs[t], 0, 0, 0);
@@ -552,10 +559,8 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
           const int t = w_ - 1;
           const Frag3& L = TRANS ? fg : cur;
           const Frag3& R = TRANS ? cur : fg;
-          // (In is `cur`: TRANS -> the right operand R.p[0], else the left operand L.p[0]; small terms first)
-          accs[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(TRANS ? L.p[2] : L.p[0]),
-                                                            as_bf16x8(TRANS ? R.p[0] : R.p[2]), accs[t], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
+          // (In is `cur`: TRANS -> the right operand R.p[0], else the left operand L.p[0]; G in its two leading pieces,
+          // the smaller first)
           pair_split(0);
           pair_split(1);
           __builtin_amdgcn_sched_barrier(0);
@@ -637,7 +642,7 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
             fi.x = pack_exact_bf16x2(raw[f & 1][0], raw[f & 1][1]); fi.y = pack_exact_bf16x2(raw[f & 1][2], raw[f & 1][3]);
             fi.z = pack_exact_bf16x2(raw[f & 1][4], raw[f & 1][5]); fi.w = pack_exact_bf16x2(raw[f & 1][6], raw[f & 1][7]);
 #pragma unroll
-            for (int pc = 2; pc >= 0; --pc)
+            for (int pc = 1; pc >= 0; --pc)  // G in its two leading pieces (terms above 2^-16)
               accs[t] = TRANS ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fg.p[pc]), as_bf16x8(fi), accs[t], 0, 0, 0)
                               : __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(fi), as_bf16x8(fg.p[pc]), accs[t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);

@@ -105,6 +105,10 @@ int win_gather_sum_h(const gcmi_graph* g, const unsigned short* d_x, int64_t ldx
                      int64_t lds, hipStream_t st);
 int win_gather_max_h(const gcmi_graph* g, const unsigned short* d_x, int64_t ldx, int n_feat, const float* d_scale,
                      const float* d_shift, unsigned short* d_out, int64_t ldo, uint8_t* d_arg, hipStream_t st);
+bool win_max_sum_usable_h(const gcmi_graph* g, int n_feat);
+int win_gather_max_sum_h(const gcmi_graph* g, const unsigned short* d_x, int64_t ldx, int n_feat, const float* d_scale,
+                         const float* d_shift, unsigned short* d_out, int64_t ldo, uint8_t* d_arg, unsigned short* d_s,
+                         int64_t lds, hipStream_t st);
 // fwd_bf16.hip: forward product over bf16 operands, bf16 output, BatchNorm sums of the rounded output
 int fwd_h_gemm(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_end, const unsigned short* d_a1, int64_t lda1,
                int32_t k1, const float* d_w1, const int64_t* w1_off, const unsigned short* d_a2, int64_t lda2, int32_t k2,

@@ -634,6 +634,116 @@ struct MaxOpH {
   }
 };
 
+// GraphPool of block l and GraphConv.sum_neigh of block l + 1 in ONE window pass (bf16 rows): the pooled rows of the
+// window are formed in a third LDS tile (and stored, with their arg-max bytes, as MaxOpH stores them), then every atom
+// sums its neighbours' pooled rows from that tile.  The pooled matrix is written once and NOT read back by a second
+// launch (-128 bytes per atom and one launch); the third tile is half the size it would be in fp32, so two workgroups
+// still share a CU.  Same values as MaxOpH followed by SumOpH (same candidates in the same order, the same rounded
+// pooled values summed in the same neighbour order).  Oversized windows take the two separate ops over their own rows.
+template <bool BN>
+struct MaxSumOpH {
+  const float* __restrict__ scale;
+  const float* __restrict__ shift;
+  bf16_t* __restrict__ out;   // pooled rows
+  int64_t ldo;
+  uint8_t* __restrict__ arg;
+  bf16_t* __restrict__ s;     // neighbour sums of the pooled rows
+  int64_t lds;
+  struct State {
+    char* extra;  // the third tile: [slot][LPR] 16-byte pieces of pooled rows
+  };
+  static constexpr bool kExtraTile = true;
+  static constexpr int kEPP = 8;
+  __device__ __forceinline__ bool skip(int) const { return false; }
+  template <int WT>
+  __device__ __forceinline__ void init(float* sh_lds, int n_feat, State&) const {
+    if (BN)
+      for (int i = threadIdx.x; i < n_feat; i += WT) {
+        sh_lds[i] = scale[i];
+        sh_lds[256 + i] = shift[i];
+      }
+  }
+  template <int WT>
+  __device__ __forceinline__ void finish(char*, int, State&) const {}
+  template <int WT, int LPR>
+  __device__ __forceinline__ void run(const char* buf, const Layout& L, const WinMeta& m, const float* sh_lds,
+                                      State& st) const {
+    const uint4* tile = reinterpret_cast<const uint4*>(buf);
+    const uint16_t* ent = reinterpret_cast<const uint16_t*>(buf + L.tile_bytes + L.aux_bytes);
+    uint4* t2 = reinterpret_cast<uint4*>(st.extra);
+    const int n16 = m.sb[kND] * LPR;
+    // ---- stage 1: the pooled rows of the window -> HBM and the third tile
+    for (int e = threadIdx.x; e < n16; e += WT) {
+      const int slot = e / LPR;
+      const int c = e - slot * LPR;
+      int d, row, eloc;
+      locate(m, L.maxd, slot, d, row, eloc);
+      float sc[8], sh[8];
+      if (BN) {
+        const float4 a0 = *reinterpret_cast<const float4*>(sh_lds + c * 8);
+        const float4 a1 = *reinterpret_cast<const float4*>(sh_lds + c * 8 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(sh_lds + 256 + c * 8);
+        const float4 b1 = *reinterpret_cast<const float4*>(sh_lds + 256 + c * 8 + 4);
+        sc[0] = a0.x; sc[1] = a0.y; sc[2] = a0.z; sc[3] = a0.w; sc[4] = a1.x; sc[5] = a1.y; sc[6] = a1.z; sc[7] = a1.w;
+        sh[0] = b0.x; sh[1] = b0.y; sh[2] = b0.z; sh[3] = b0.w; sh[4] = b1.x; sh[5] = b1.y; sh[6] = b1.z; sh[7] = b1.w;
+      }
+      float best[8];
+      widen8(tile[e], best);  // self first
+      unsigned char ba[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (BN) best[q] = fmaf(best[q], sc[q], sh[q]);
+        ba[q] = 0;
+      }
+      for (int j = 0; j < d; ++j) {
+        const int sl = ent[eloc + j] & GCMI_WIN_MAX_SLOTS;
+        float v[8];
+        widen8(tile[sl * LPR + c], v);
+        const unsigned char a = (unsigned char)(j + 1);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (BN) v[q] = fmaf(v[q], sc[q], sh[q]);
+          if (v[q] > best[q]) { best[q] = v[q]; ba[q] = a; }  // strict >: the first maximum wins
+        }
+      }
+      uint4 o;
+      o.x = pack_bf16x2(best[0], best[1]); o.y = pack_bf16x2(best[2], best[3]);
+      o.z = pack_bf16x2(best[4], best[5]); o.w = pack_bf16x2(best[6], best[7]);
+      *reinterpret_cast<uint4*>(out + (int64_t)row * ldo + c * 8) = o;
+      t2[e] = o;
+      if (arg) {
+        uint2 av;
+        av.x = (unsigned)ba[0] | ((unsigned)ba[1] << 8) | ((unsigned)ba[2] << 16) | ((unsigned)ba[3] << 24);
+        av.y = (unsigned)ba[4] | ((unsigned)ba[5] << 8) | ((unsigned)ba[6] << 16) | ((unsigned)ba[7] << 24);
+        *reinterpret_cast<uint2*>(arg + (int64_t)row * (LPR * 8) + c * 8) = av;
+      }
+    }
+    __syncthreads();
+    // ---- stage 2: every atom sums its neighbours' pooled rows
+    for (int e = threadIdx.x; e < n16; e += WT) {
+      const int slot = e / LPR;
+      const int c = e - slot * LPR;
+      int d, row, eloc;
+      locate(m, L.maxd, slot, d, row, eloc);
+      float acc[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+      for (int j = 0; j < d; ++j) {
+        const int sl = ent[eloc + j] & GCMI_WIN_MAX_SLOTS;
+        float v[8];
+        widen8(t2[sl * LPR + c], v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += v[q];
+      }
+      uint4 o;
+      o.x = pack_bf16x2(acc[0], acc[1]); o.y = pack_bf16x2(acc[2], acc[3]);
+      o.z = pack_bf16x2(acc[4], acc[5]); o.w = pack_bf16x2(acc[6], acc[7]);
+      *reinterpret_cast<uint4*>(s + (int64_t)row * lds + c * 8) = o;
+    }
+    // (the walker's barrier at the top of the next window comes before the third tile is written again)
+  }
+};
+
 // ---------------------------------------------------------------- the persistent window walker
 // Workgroups [0, g_norm) walk the ordinary windows double-buffered; workgroups [g_norm, gridDim)
 // walk the oversized windows (one big molecule each) using both buffers as one.
@@ -824,13 +934,13 @@ static int launch(const gcmi_graph* g, int n_feat, const float* x, int64_t ldx, 
 // rows of bf16: n_feat elements = n_feat / 8 pieces (64 -> 8, 80 -> 10, 128 -> 16)
 template <class Op>
 static int launch_h(const gcmi_graph* g, int n_feat, const bf16_t* x, int64_t ldx, const Op& op, hipStream_t st,
-                    const char* what) {
+                    const char* what, int which = 0) {
   const WinPlan p = make_plan(g, n_feat / 2, false);
   const char* xb = reinterpret_cast<const char*>(x);
   switch (n_feat / 8) {
-    case 8: return launch_lpr<8, false, Op>(g, p, xb, ldx * 2, nullptr, op, st, what, 0);
-    case 10: return launch_lpr<10, false, Op>(g, p, xb, ldx * 2, nullptr, op, st, what, 0);
-    case 16: return launch_lpr<16, false, Op>(g, p, xb, ldx * 2, nullptr, op, st, what, 0);
+    case 8: return launch_lpr<8, false, Op>(g, p, xb, ldx * 2, nullptr, op, st, what, which);
+    case 10: return launch_lpr<10, false, Op>(g, p, xb, ldx * 2, nullptr, op, st, what, which);
+    case 16: return launch_lpr<16, false, Op>(g, p, xb, ldx * 2, nullptr, op, st, what, which);
     default: break;
   }
   set_error("%s: no bf16 window kernel for %d features", what, n_feat);
@@ -904,6 +1014,42 @@ int win_gather_max_h(const gcmi_graph* g, const bf16_t* d_x, int64_t ldx, int n_
   }
   MaxOpH<false> op{nullptr, nullptr, d_out, ldo, d_arg};
   return launch_h(g, n_feat, d_x, ldx, op, st, "win_gather_max (bf16)");
+}
+
+// GraphPool of this block + sum_neigh of the next in one window pass (MaxSumOpH); the oversized windows (a molecule
+// above the window cap each) take the two separate ops over their own rows
+bool win_max_sum_usable_h(const gcmi_graph* g, int n_feat) {
+  // measured on the 65 536-molecule step: 288 us for the fused pass against 196 + 72 for the two it replaces (the second
+  // stage waits behind a barrier for the whole window's pooled rows) -- 153 MB less traffic, 20 us more time: off by
+  // default, GCMI_FUSED_POOL_SUM=1 switches it on
+  static const bool on = getenv("GCMI_FUSED_POOL_SUM") && atoi(getenv("GCMI_FUSED_POOL_SUM")) != 0;
+  if (!on || !win_usable_h(g, n_feat)) return false;
+  const WinPlan p = make_plan(g, n_feat / 2, false);
+  return p.shmem + (size_t)p.L.tile_bytes <= (size_t)kLdsPerCU;
+}
+
+int win_gather_max_sum_h(const gcmi_graph* g, const bf16_t* d_x, int64_t ldx, int n_feat, const float* d_scale,
+                         const float* d_shift, bf16_t* d_out, int64_t ldo, uint8_t* d_arg, bf16_t* d_s, int64_t lds,
+                         hipStream_t st) {
+  int rc;
+  if (d_scale) {
+    MaxSumOpH<true> op{d_scale, d_shift, d_out, ldo, d_arg, d_s, lds};
+    rc = launch_h(g, n_feat, d_x, ldx, op, st, "win_gather_max_sum (bf16)", 1);
+  } else {
+    MaxSumOpH<false> op{nullptr, nullptr, d_out, ldo, d_arg, d_s, lds};
+    rc = launch_h(g, n_feat, d_x, ldx, op, st, "win_gather_max_sum (bf16)", 1);
+  }
+  if (rc || g->n_win_big == 0) return rc;
+  if (d_scale) {
+    MaxOpH<true> mx{d_scale, d_shift, d_out, ldo, d_arg};
+    rc = launch_h(g, n_feat, d_x, ldx, mx, st, "win_gather_max (bf16, oversized windows)", 2);
+  } else {
+    MaxOpH<false> mx{nullptr, nullptr, d_out, ldo, d_arg};
+    rc = launch_h(g, n_feat, d_x, ldx, mx, st, "win_gather_max (bf16, oversized windows)", 2);
+  }
+  if (rc) return rc;
+  SumOpH sm{d_s, lds};
+  return launch_h(g, n_feat, d_out, ldo, sm, st, "win_gather_sum (bf16, oversized windows)", 2);
 }
 
 // dy = GraphPool backward of (dXs + gather of dS), dX kept in LDS only.  GCMI_ERR_UNSUPPORTED: oversized windows in

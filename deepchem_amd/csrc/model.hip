@@ -216,6 +216,7 @@ static int model_forward_h(const gcmi_model_desc* m, const gcmi_graph* g, const 
   }
   const bf16_t* xin = nullptr;
   int64_t ldin = 0;
+  bool sum_done = false;  // S[l] was written by the fused pass of block l - 1
   for (int l = 0; l < L; ++l) {
     const int K = l == 0 ? m->n_feat_in : m->conv_width[l - 1];
     const int W = m->conv_width[l];
@@ -233,7 +234,7 @@ static int model_forward_h(const gcmi_model_desc* m, const gcmi_graph* g, const 
           RUN(win_gather_sum_fh(g, io->d_atom_features, io->ld_features, (int)w.ngather[0], H(w.S[0]), H(w.xb), w.ldS[0], st));
           xin = H(w.xb);
           ldin = w.ldS[0];
-        } else {
+        } else if (!sum_done) {
           RUN(win_gather_sum_h(g, xin, ldin, K, H(w.S[l]), w.ldS[l], st));
         }
       }
@@ -256,8 +257,15 @@ static int model_forward_h(const gcmi_model_desc* m, const gcmi_graph* g, const 
       }
       {
         TimedScope ts(GCMI_K_GATHER_MAX, st);
-        RUN(win_gather_max_h(g, H(w.gc[l]), W, W, scale, shift, H(w.pool[l]), W,
-                             training ? reinterpret_cast<uint8_t*>(ws + w.arg[l]) : nullptr, st));
+        // GraphPool of this block, and where another GraphConv follows its neighbour sums in the same window pass
+        sum_done = l + 1 < L && m->conv_width[l + 1] == W && win_max_sum_usable_h(g, W);
+        if (sum_done)
+          RUN(win_gather_max_sum_h(g, H(w.gc[l]), W, W, scale, shift, H(w.pool[l]), W,
+                                   training ? reinterpret_cast<uint8_t*>(ws + w.arg[l]) : nullptr, H(w.S[l + 1]),
+                                   w.ldS[l + 1], st));
+        else
+          RUN(win_gather_max_h(g, H(w.gc[l]), W, W, scale, shift, H(w.pool[l]), W,
+                               training ? reinterpret_cast<uint8_t*>(ws + w.arg[l]) : nullptr, st));
       }
     }
     xin = H(w.pool[l]);

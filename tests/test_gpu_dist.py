@@ -341,8 +341,14 @@ def test_bench_gpus_2_runs_two_ranks_or_refuses(tmp_path):
     bad = subprocess.run(base, env=env2, capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "must agree" in (bad.stderr + bad.stdout)
     # strong scaling: a fixed global batch split over the ranks
-    strong = subprocess.run(base + ["--scaling", "strong", "--global-batch", "1024"], env=env, capture_output=True,
+    # ... and the real-Tox21 fit() legs on the ranks (small-batch engine under data parallel: VERDICT r2 item 4)
+    args = [a for a in base]
+    args[args.index("--fit-pipeline") + 1] = "1"
+    strong = subprocess.run(args + ["--scaling", "strong", "--global-batch", "1024"], env=env, capture_output=True,
                             text=True, timeout=800)
     assert strong.returncode == 0, strong.stdout[-2000:] + strong.stderr[-4000:]
     rec = json.loads([l for l in strong.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["scaling"] == "strong" and rec["n_gpus"] == 2 and rec["config"]["molecules_per_gpu_per_step"] == 512
+    real = rec["config"]["tox21_real"]
+    assert real["ranks"] == 2 and real["engine_batch_64_reference"] and real["engine_batch_100_full"]
+    assert real["fit_molecules_per_s_batch_64_reference"] > 0
