@@ -59,7 +59,7 @@ def parse():
                     help="only the large-batch steps (for rocprofv3 passes): no small-batch, fit or CPU legs")
     ap.add_argument("--small-batch", type=int, default=100,
                     help="also report mol/s at the reference's default batch size (0 = skip)")
-    ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--storage", default="fp32", choices=["fp32", "bf16", "bf16+grads"],
                     help="activation storage of the timed step (the headline line is fp32; the default run adds a "
                          "bf16-storage line item beside it; --storage bf16 --profile-only is for the rocprofv3 passes)")
     args = ap.parse_args()
@@ -77,6 +77,11 @@ def gather_sum_bytes(n_atoms, n_edges, n_deg0, feats, accumulate):
     return b
 
 
+def _pmc_tag(name):
+    """Which storage a committed PMC file (profiles/r*_pmc_traffic*.json) was taken in, by its name."""
+    return "bf16+grads" if "bf16g" in name else "bf16" if "bf16" in name else "fp32"
+
+
 def measured_traffic(storage="fp32"):
     """HBM bytes per gather-sum launch from the newest committed rocprofv3 PMC passes (profiles/r*_pmc_traffic.json:
     FETCH_SIZE x2 + WRITE_SIZE per the gfx950 corrections of MI355X_MICROARCH.md, separate passes, tools/pmc_passes.sh
@@ -84,7 +89,7 @@ def measured_traffic(storage="fp32"):
     (bytes per launch, file name) or (None, None)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")))
-    files = [f for f in files if "R1" not in os.path.basename(f) and (("bf16" in os.path.basename(f)) == (storage == "bf16"))]
+    files = [f for f in files if "R1" not in os.path.basename(f) and _pmc_tag(os.path.basename(f)) == storage]
     measured_traffic.step_bytes = None
     for path in reversed(files):
         try:
@@ -131,7 +136,7 @@ def family_traffic(storage="fp32"):
     (FETCH_SIZE x 2 + WRITE_SIZE per launch x launches, over the profiled steps)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")))
-    files = [f for f in files if "R1" not in os.path.basename(f) and (("bf16" in os.path.basename(f)) == (storage == "bf16"))]
+    files = [f for f in files if "R1" not in os.path.basename(f) and _pmc_tag(os.path.basename(f)) == storage]
     for path in reversed(files):
         try:
             with open(path) as f:
@@ -519,7 +524,7 @@ def main():
     n_launch, ms = gather_time
     achieved = (per_step * args.steps) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     traffic, traffic_file = measured_traffic(args.storage)
-    h = args.storage == "bf16"
+    h = args.storage != "fp32"
     if h:  # bf16 rows: 2 bytes per gathered / written element ("replace 4 F by 2 F for feature reads")
         e_b = lambda f: 2 * f
         per_step = (g.n_edges * (4 * 76 + 4) + g.n_atoms * (2 * e_b(80))) + \
@@ -623,45 +628,47 @@ def main():
         # BASELINE config 2 "bf16/fp32": the SAME step with every activation the step writes and reads back stored as
         # bf16 (gcmi_model_* storage = 1; fp32 arithmetic, parameters, gradients, Adam) -- beside the f32 headline,
         # never instead of it
-        mb, db, lb, wb = make_workload(args, rank, device, args.batch, "bf16")
-        run_steps(mb, db, lb, wb, max(args.warmup, 1))
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        run_steps(mb, db, lb, wb, args.steps)
-        torch.cuda.synchronize()
-        wall_b = time.perf_counter() - t1
-        for kid in kernel_ids.values():
-            ops.timing_enable(kid, True)
-            ops.timing_read(kid, reset=True)
-        run_steps(mb, db, lb, wb, breakdown_steps)
-        torch.cuda.synchronize()
-        kt_b = {name: ops.timing_read(kid, reset=True) for name, kid in kernel_ids.items()}
-        for kid in kernel_ids.values():
-            ops.timing_enable(kid, False)
-        tb, tb_file = measured_traffic("bf16")
-        item = {"dtype": "bf16-storage", "value": round(args.batch * args.steps / wall_b, 1), "unit": "molecules/s",
-                "ms_per_step": round(wall_b / args.steps * 1e3, 4), "steps": args.steps,
-                "what": "atom-feature copy, neighbour sums, GraphConv outputs, pooled rows and the dense output stored as "
-                        "bfloat16 (one rounding per stored element); fp32 accumulation, fp64 BatchNorm sums of the "
-                        "rounded values, fp32 parameters / gradients / gradient streams / Adam",
-                "kernel_ms_per_step": {k: round(v[1] / breakdown_steps, 4) for k, v in kt_b.items()}}
-        if measured_traffic.step_bytes:
-            sb = measured_traffic.step_bytes
-            item["step_traffic"] = {"hbm_bytes_per_step": sb, "source": tb_file,
-                                    "achieved": round(sb / (wall_b / args.steps) / 1e9, 1), "unit": "GB/s",
-                                    "frac_of_hbm_peak": round(sb / (wall_b / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
-        else:
-            item["step_traffic"] = None
-        fb, fb_file = family_traffic("bf16")
-        if fb is not None:
-            item["roofline_by_kernel"] = {
-                k: {"ms": round(v[1] / breakdown_steps, 4), "hbm_bytes": fb[k],
-                    "frac_real": round(fb[k] / (v[1] / breakdown_steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 3) if v[1] > 0 else 0.0}
-                for k, v in kt_b.items()}
-            item["roofline_by_kernel_source"] = fb_file
-        out["bf16_storage"] = item
-        del mb, db, lb, wb
-        measured_traffic(args.storage)
+        for st_name, key in (("bf16", "bf16_storage"), ("bf16+grads", "bf16_storage_and_gradient_streams")):
+            mb, db, lb, wb = make_workload(args, rank, device, args.batch, st_name)
+            run_steps(mb, db, lb, wb, max(args.warmup, 1))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_steps(mb, db, lb, wb, args.steps)
+            torch.cuda.synchronize()
+            wall_b = time.perf_counter() - t1
+            for kid in kernel_ids.values():
+                ops.timing_enable(kid, True)
+                ops.timing_read(kid, reset=True)
+            run_steps(mb, db, lb, wb, breakdown_steps)
+            torch.cuda.synchronize()
+            kt_b = {name: ops.timing_read(kid, reset=True) for name, kid in kernel_ids.items()}
+            for kid in kernel_ids.values():
+                ops.timing_enable(kid, False)
+            tb, tb_file = measured_traffic(st_name)
+            item = {"dtype": "bf16-storage" if st_name == "bf16" else "bf16-storage+gradient-streams", "value": round(args.batch * args.steps / wall_b, 1), "unit": "molecules/s",
+                    "ms_per_step": round(wall_b / args.steps * 1e3, 4), "steps": args.steps,
+                    "what": "atom-feature copy, neighbour sums, GraphConv outputs, pooled rows and the dense output stored as "
+                            "bfloat16 (one rounding per stored element); fp32 accumulation, fp64 BatchNorm sums of the "
+                            "rounded values, fp32 parameters / parameter gradients / Adam; gradient streams between kernels "
+                            + ("fp32" if st_name == "bf16" else "bfloat16 too (dpool, dy, dS, dXs)"),
+                    "kernel_ms_per_step": {k: round(v[1] / breakdown_steps, 4) for k, v in kt_b.items()}}
+            if measured_traffic.step_bytes:
+                sb = measured_traffic.step_bytes
+                item["step_traffic"] = {"hbm_bytes_per_step": sb, "source": tb_file,
+                                        "achieved": round(sb / (wall_b / args.steps) / 1e9, 1), "unit": "GB/s",
+                                        "frac_of_hbm_peak": round(sb / (wall_b / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
+            else:
+                item["step_traffic"] = None
+            fb, fb_file = family_traffic(st_name)
+            if fb is not None:
+                item["roofline_by_kernel"] = {
+                    k: {"ms": round(v[1] / breakdown_steps, 4), "hbm_bytes": fb[k],
+                        "frac_real": round(fb[k] / (v[1] / breakdown_steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 3) if v[1] > 0 else 0.0}
+                    for k, v in kt_b.items()}
+                item["roofline_by_kernel_source"] = fb_file
+            out[key] = item
+            del mb, db, lb, wb
+            measured_traffic(args.storage)
 
     if rank == 0 and args.small_batch and world == 1:
         m2, b2, l2, w2 = make_workload(args, 0, device, args.small_batch)

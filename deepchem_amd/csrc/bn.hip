@@ -61,7 +61,8 @@ __device__ __forceinline__ void readout_dy(const ReadoutGrad& rg, int64_t r, int
 // MODE 0: b = a (sum of squares).  MODE 1: b = (x - mean)*invstd (x given), a = dy.
 // MODE 2: as MODE 1 with dy recomputed from the readout gradient (rg) instead of read from a.
 // XH (V == 4, MODE 1): x is stored as bf16 (gcmi_model_desc.storage == 1; ldx counts elements).
-template <int V, int MODE, bool XH = false>
+// AH (with XH): a (the incoming gradient) is stored as bf16 too (storage == 2).
+template <int V, int MODE, bool XH = false, bool AH = false>
 __global__ void __launch_bounds__(kBBlock)
 col_sums_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ x, int64_t ldx,
                 const float* __restrict__ mean, const float* __restrict__ invstd, int64_t n_rows,
@@ -90,7 +91,9 @@ col_sums_kernel(const float* __restrict__ a, int64_t lda, const float* __restric
       if constexpr (MODE == 2) readout_dy<V>(rg, rc, c, n_feat, t.av[u]);
       if constexpr (V == 4) {
         if (MODE != 2) {
-          const float4 t4 = *reinterpret_cast<const float4*>(a + rc * lda + c);
+          float4 t4;
+          if constexpr (AH) t4 = widen4(*reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a) + rc * lda + c));
+          else t4 = *reinterpret_cast<const float4*>(a + rc * lda + c);
           t.av[u][0] = t4.x; t.av[u][1] = t4.y; t.av[u][2] = t4.z; t.av[u][3] = t4.w;
         }
         if (MODE >= 1) {
@@ -335,7 +338,7 @@ bn_bwd_dx_kernel(const float* __restrict__ dy, int64_t lddy, const float* __rest
 static int launch_col_sums(int mode, const float* a, int64_t lda, const float* x, int64_t ldx,
                            const float* mean, const float* invstd, int64_t n_rows, int n_feat,
                            double* sums, bool acc_clean, hipStream_t st, const ReadoutGrad* rgp = nullptr,
-                           const float* only_if_gamma = nullptr, const float* only_if_beta = nullptr, bool x_bf16 = false) {
+                           const float* only_if_gamma = nullptr, const float* only_if_beta = nullptr, int x_bf16 = 0) {
   if (!acc_clean &&
       hipMemsetAsync(sums, 0, sizeof(double) * 2 * n_feat * (1 + kReplicas), st) != hipSuccess) {
     set_error("bn: memset failed");
@@ -349,7 +352,9 @@ static int launch_col_sums(int mode, const float* a, int64_t lda, const float* x
     mode = 2;
     V = (vec_width(x, ldx, n_feat) == 4 && aligned16(rg.g2) && rg.ldg2 % 4 == 0 && aligned16(rg.arg)) ? 4 : 1;
   } else if (x_bf16) {
-    if (mode != 1 || vec_width(a, lda, n_feat) != 4 || (reinterpret_cast<uintptr_t>(x) & 7u) || ldx % 4) {
+    const bool a_ok = x_bf16 == 2 ? ((reinterpret_cast<uintptr_t>(a) & 7u) == 0 && lda % 4 == 0 && n_feat % 4 == 0)
+                                  : vec_width(a, lda, n_feat) == 4;
+    if (mode != 1 || !a_ok || (reinterpret_cast<uintptr_t>(x) & 7u) || ldx % 4) {
       set_error("bn col_sums: bf16 rows need mode 1 and 8-byte addressable rows");
       return GCMI_ERR_UNSUPPORTED;
     }
@@ -371,7 +376,10 @@ static int launch_col_sums(int mode, const float* a, int64_t lda, const float* x
 #define LAUNCH_CS(VV, MM)                                                                     \
   hipLaunchKernelGGL((col_sums_kernel<VV, MM>), dim3(blocks), dim3(kBBlock), 0, st, a, lda, x, \
                      ldx, mean, invstd, n_rows, rpb, n_feat, lpr, lx, sums, rg, rev, only_if_gamma, only_if_beta)
-  if (x_bf16) {
+  if (x_bf16 == 2) {
+    hipLaunchKernelGGL((col_sums_kernel<4, 1, true, true>), dim3(blocks), dim3(kBBlock), 0, st, a, lda, x, ldx, mean, invstd,
+                       n_rows, rpb, n_feat, lpr, lx, sums, rg, rev, only_if_gamma, only_if_beta);
+  } else if (x_bf16) {
     hipLaunchKernelGGL((col_sums_kernel<4, 1, true>), dim3(blocks), dim3(kBBlock), 0, st, a, lda, x, ldx, mean, invstd,
                        n_rows, rpb, n_feat, lpr, lx, sums, rg, rev, only_if_gamma, only_if_beta);
   } else if (V == 4) {
@@ -614,7 +622,7 @@ int bn_bwd_pool_impl(const float* d_dy, int64_t lddy, const float* d_x, int64_t 
   TimedScope ts(GCMI_K_BATCHNORM, st);
   if (d_dy != nullptr) {
     const int rc = launch_col_sums(1, d_dy, lddy, d_x, ldx, d_mean, d_invstd, n_rows, n_feat, d_acc, true, st, nullptr,
-                                   d_gamma, d_beta, x_bf16 != 0);
+                                   d_gamma, d_beta, x_bf16);
     if (rc) return rc;
   }
   static_assert(kReplicas == 32, "bn_bwd_params_pool_kernel: one lane per replica");

@@ -80,9 +80,13 @@ struct FusedArgs {
 // g1 w1 + g1 w2 + g2 w1 (3 instead of 6): the matrix pipe, which two waves per SIMD share and which bounds these
 // kernels together with the split's vector work, does half the work.  Accumulation stays fp32; gradients (dy, the
 // outputs) stay fp32.
-template <int NG, int KT, int NOPS, bool TRANS, bool RD, bool DGRAD, bool HB = false>
+// GB (with HB; storage == 2): the gradient STREAMS are bf16 as well -- dy arrives as 8-byte pieces, the input gradients
+// leave rounded once (the column sums for the BatchNorm below are taken from the rounded values: they describe what the
+// next kernel reads).
+template <int NG, int KT, int NOPS, bool TRANS, bool RD, bool DGRAD, bool HB = false, bool GB = false>
 __global__ void __launch_bounds__(DGRAD ? 512 : 256) __attribute__((amdgpu_waves_per_eu(2)))
 fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
+  static_assert(!GB || HB, "bf16 gradient streams come with bf16 activations");
   constexpr int NT = DGRAD ? 512 : 256;
   constexpr int NJ = NG / 32;                 // 32-column groups of G
   constexpr int KP = KT * 32;                 // padded width of In
@@ -195,7 +199,9 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
     if constexpr (HB) return widen4(v);
     else return v;
   };
-  float4 pdy[GPASS], pgm[RD ? GPASS : 1];
+  using DyV = typename std::conditional<GB && !RD, uint2, float4>::type;  // four incoming gradients
+  DyV pdy[GPASS];
+  float4 pgm[RD ? GPASS : 1];
   ActV px[GPASS], pin[NOPS][IPASS];
   int4 parg[RD ? GPASS : 1];
   int mem1[RD ? GPASS : 1];
@@ -217,7 +223,8 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
         pgm[p] = *reinterpret_cast<const float4*>(a.g2 + (m * (unsigned)a.ldg2 + NG + 4u * gq));
         parg[p] = *reinterpret_cast<const int4*>(a.arg + (m * (unsigned)NG + 4u * gq));
       } else {
-        pdy[p] = *reinterpret_cast<const float4*>(a.dy + (r * (unsigned)a.lddy + 4u * gq));
+        if constexpr (GB) pdy[p] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(a.dy) + (r * (unsigned)a.lddy + 4u * gq));
+        else pdy[p] = *reinterpret_cast<const float4*>(a.dy + (r * (unsigned)a.lddy + 4u * gq));
       }
     }
 #pragma unroll
@@ -314,8 +321,14 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
           const int slot = tid + p * NT;
           const int r = slot / IQ, q = slot - r * IQ;
           if (r < pvalid && 4 * q < a.k_in) {  // k_in % 4 == 0 (launcher)
-            const float4 v = *reinterpret_cast<const float4*>(Outs + r * OP + o * KP + 4 * q);
-            *reinterpret_cast<float4*>(dst + ((unsigned)(prow0 + r) * (unsigned)ldd + 4u * q)) = v;
+            float4 v = *reinterpret_cast<const float4*>(Outs + r * OP + o * KP + 4 * q);
+            if constexpr (GB) {
+              const uint2 h = narrow4(v.x, v.y, v.z, v.w);
+              *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(dst) + ((unsigned)(prow0 + r) * (unsigned)ldd + 4u * q)) = h;
+              v = widen4(h);  // the sums below describe the stored values
+            } else {
+              *reinterpret_cast<float4*>(dst + ((unsigned)(prow0 + r) * (unsigned)ldd + 4u * q)) = v;
+            }
             if (a.psums != nullptr) {
               const float4 in = *reinterpret_cast<const float4*>(Ins + (o * kFRows + r) * IP + 4 * q);
               const float wgt = (NOPS == 2 && o == 0) ? deg : 1.f;
@@ -387,7 +400,10 @@ fused_bwd_kernel(FusedTable st, int n_tiles, FusedArgs a, int rev) {
 #pragma unroll
     for (int p = 0; p < GPASS; ++p) {
       const int r = gr + p * RPP;
-      float dyv[4] = {pdy[p].x, pdy[p].y, pdy[p].z, pdy[p].w};
+      float4 dy4;
+      if constexpr (GB && !RD) dy4 = widen4(pdy[p]);
+      else dy4 = pdy[p];
+      float dyv[4] = {dy4.x, dy4.y, dy4.z, dy4.w};
       const float4 x4 = act4(px[p]);
       const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
       if constexpr (RD) {
@@ -701,13 +717,13 @@ void set_fused_bwd(int on) { g_fused_bwd.store(on ? 1 : 0, std::memory_order_rel
 int get_fused_bwd() { return g_fused_bwd.load(std::memory_order_relaxed); }
 bool fused_bwd_enabled() { return fused_bwd_on() && get_fused_bwd() != 0 && !gemm_exact_mode(); }
 
-template <int NG, int KT, int NOPS, bool TRANS, bool RD, bool DGRAD, bool HB = false>
+template <int NG, int KT, int NOPS, bool TRANS, bool RD, bool DGRAD, bool HB = false, bool GB = false>
 static int launch_fused(const FusedTable& st, int n_tiles, const FusedArgs& a, hipStream_t sm) {
   constexpr int KP = KT * 32;
   size_t shmem = sizeof(float) * kFRows * (NG + 4) + sizeof(float) * (size_t)NOPS * kFRows * (KP + 4);
   if (DGRAD)
     shmem += sizeof(unsigned short) * (size_t)NOPS * 3 * KP * (NG + 8) + sizeof(float) * kFRows * (NOPS * KT * 32 + 8);
-  auto kern = fused_bwd_kernel<NG, KT, NOPS, TRANS, RD, DGRAD, HB>;
+  auto kern = fused_bwd_kernel<NG, KT, NOPS, TRANS, RD, DGRAD, HB, GB>;
   static bool attr_done = false;  // per instantiation
   if (!attr_done) {
     // exactly what is asked for: the kernel also has a few hundred bytes of static LDS (the segment table)
@@ -794,17 +810,21 @@ int fused_conv_bwd(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
   a.psums = dgrad ? d_psums : nullptr;
   if (dgrad) {
     if (k_in % 4 || ldds % 4 || lddxs % 4 || !aligned16(d_ds_out) || !aligned16(d_dxs_out)) return GCMI_ERR_UNSUPPORTED;
+    // (act_bf16 == 2: dy, dS and dXs are bf16 rows too)
     if (k_in > 32 && k_in <= 64)
-      return act_bf16 ? launch_fused<64, 2, 2, false, false, true, true>(st, tiles, a, sm)
-                      : launch_fused<64, 2, 2, false, false, true>(st, tiles, a, sm);
+      return act_bf16 == 2 ? launch_fused<64, 2, 2, false, false, true, true, true>(st, tiles, a, sm)
+             : act_bf16    ? launch_fused<64, 2, 2, false, false, true, true>(st, tiles, a, sm)
+                           : launch_fused<64, 2, 2, false, false, true>(st, tiles, a, sm);
     return GCMI_ERR_UNSUPPORTED;
   }
   if (k_in > 32 && k_in <= 64)
-    return act_bf16 ? launch_fused<64, 2, 2, false, false, false, true>(st, tiles, a, sm)
-                    : launch_fused<64, 2, 2, false, false, false>(st, tiles, a, sm);
+    return act_bf16 == 2 ? launch_fused<64, 2, 2, false, false, false, true, true>(st, tiles, a, sm)
+           : act_bf16    ? launch_fused<64, 2, 2, false, false, false, true>(st, tiles, a, sm)
+                         : launch_fused<64, 2, 2, false, false, false>(st, tiles, a, sm);
   if (k_in > 64 && k_in <= 96)
-    return act_bf16 ? launch_fused<64, 3, 2, false, false, false, true>(st, tiles, a, sm)
-                    : launch_fused<64, 3, 2, false, false, false>(st, tiles, a, sm);
+    return act_bf16 == 2 ? launch_fused<64, 3, 2, false, false, false, true, true>(st, tiles, a, sm)
+           : act_bf16    ? launch_fused<64, 3, 2, false, false, false, true>(st, tiles, a, sm)
+                         : launch_fused<64, 3, 2, false, false, false>(st, tiles, a, sm);
   return GCMI_ERR_UNSUPPORTED;
 }
 
@@ -833,6 +853,7 @@ int fused_dense_bwd(int64_t n_rows, const int32_t* d_membership, const float* d_
   a.psums = d_psums;
   if (act_bf16) {  // d_dense and d_p point to bf16 rows
     if (!aligned16(d_p) || ldp % 4) return GCMI_ERR_UNSUPPORTED;
+    if (act_bf16 == 2) return launch_fused<128, 2, 1, true, true, true, true, true>(st, tiles, a, sm);  // d_dp: bf16 rows
     return launch_fused<128, 2, 1, true, true, true, true>(st, tiles, a, sm);
   }
   return launch_fused<128, 2, 1, true, true, true>(st, tiles, a, sm);

@@ -105,6 +105,15 @@ int win_gather_sum_h(const gcmi_graph* g, const unsigned short* d_x, int64_t ldx
                      int64_t lds, hipStream_t st);
 int win_gather_max_h(const gcmi_graph* g, const unsigned short* d_x, int64_t ldx, int n_feat, const float* d_scale,
                      const float* d_shift, unsigned short* d_out, int64_t ldo, uint8_t* d_arg, hipStream_t st);
+// gradient streams in bf16 (storage == 2)
+bool win_usable_gh(const gcmi_graph* g, int n_feat);
+int win_gather_max_bwd_h(const gcmi_graph* g, const unsigned short* d_dout, int64_t lddo, int n_feat, const uint8_t* d_arg,
+                         unsigned short* d_dx, int64_t lddx, const float* only_if_gamma, const float* only_if_beta,
+                         hipStream_t st);
+bool win_two_stage_usable_h(const gcmi_graph* g, int n_feat);
+int win_gather_sumacc_max_bwd_h(const gcmi_graph* g, const unsigned short* d_ds, int64_t ldds, int n_feat,
+                                unsigned short* d_dxs, int64_t lddxs, const uint8_t* d_arg, unsigned short* d_dy,
+                                int64_t lddy, hipStream_t st);
 bool win_max_sum_usable_h(const gcmi_graph* g, int n_feat);
 int win_gather_max_sum_h(const gcmi_graph* g, const unsigned short* d_x, int64_t ldx, int n_feat, const float* d_scale,
                          const float* d_shift, unsigned short* d_out, int64_t ldo, uint8_t* d_arg, unsigned short* d_s,
@@ -115,6 +124,9 @@ int fwd_h_gemm(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_end, 
                const float* d_w2, const int64_t* w2_off, const float* d_bias, const int64_t* bias_off, int32_t n_out,
                int32_t trans_w, int32_t act, unsigned short* d_out, int64_t ldo, double* d_stats, float* d_wimg_scratch,
                hipStream_t sm);
+int fwd_weight_images(int32_t n_seg, const int64_t* w1_off, const int64_t* w2_off, const float* d_w1, const float* d_w2,
+                      int32_t k_in, int32_t ko, int32_t n_ops, int32_t n_out, int32_t trans_w, float* d_scratch,
+                      hipStream_t sm);
 constexpr int64_t kFwdHWimgFloats = 16 * 20 * 3 * 256;  // scratch of fwd_h_gemm: split weight fragments of <= 16 segments
 
 bool gemm_exact_mode();  // gcmi_set_option(GCMI_OPT_GEMM_EXACT)
@@ -171,7 +183,7 @@ int fwd_fused_gemm(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
                    int32_t k1, const float* d_w1, const int64_t* w1_off, const float* d_a2, int64_t lda2, int32_t k2,
                    const float* d_w2, const int64_t* w2_off, const float* d_bias, const int64_t* bias_off,
                    int32_t n_out, int32_t trans_w, int32_t act, float* d_out, int64_t ldo, double* d_stats,
-                   hipStream_t sm);
+                   hipStream_t sm, float* d_wimg_scratch = nullptr);
 
 // head_bwd.hip: loss + d logits + task-head gradients + tanh' of the readout + the dense BatchNorm's backward sums in
 // one kernel over the molecules; GCMI_ERR_UNSUPPORTED = shape not covered (256-column fingerprint, <= 32 outputs)
@@ -191,7 +203,7 @@ int seg_gemm_stats(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
                    int32_t k1, const float* d_w1, const int64_t* w1_off, const float* d_a2, int64_t lda2, int32_t k2,
                    const float* d_w2, const int64_t* w2_off, const float* d_bias, const int64_t* bias_off,
                    int32_t n_out, int32_t trans_w, int32_t act, float* d_out, int64_t ldo, double* d_stats,
-                   bool* fused, void* stream);
+                   bool* fused, void* stream, float* d_wimg_scratch = nullptr);
 // gcmi_readout_fwd that also leaves the per-molecule sums of the rows before the folded BatchNorm in d_rawsum
 int readout_fwd_impl(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t n_feat, const float* d_scale,
                      const float* d_shift, int32_t act, float* d_out, int64_t ldo, int32_t* d_arg, float* d_rawsum,

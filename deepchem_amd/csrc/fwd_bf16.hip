@@ -671,6 +671,31 @@ static int launch_fwd_hd(const FwdHTable& st, int n_tiles, const FwdHArgs& a, hi
 #endif
 }
 
+// The same images for a caller outside this file (fwd_fused.hip's fwd_reg_kernel): [segment][32-column tile][k-step]
+// [piece][lane] 16-byte entries, (n_seg * (n_out / 32) * (n_ops * ko / 16) * 3 * 64) of them, in d_scratch.
+int fwd_weight_images(int32_t n_seg, const int64_t* w1_off, const int64_t* w2_off, const float* d_w1, const float* d_w2,
+                      int32_t k_in, int32_t ko, int32_t n_ops, int32_t n_out, int32_t trans_w, float* d_scratch,
+                      hipStream_t sm) {
+  if (n_seg > kHMaxSeg || d_scratch == nullptr || !aligned16(d_scratch)) return GCMI_ERR_UNSUPPORTED;
+  if ((int64_t)n_seg * (n_out / 32) * (n_ops * ko / 16) * 3 * 256 > kFwdHWimgFloats) return GCMI_ERR_UNSUPPORTED;
+  FwdHTable st;
+  memset(&st, 0, sizeof(st));
+  st.n_seg = n_seg;
+  for (int s = 0; s < kHMaxSeg; ++s) {
+    st.w_off[0][s] = (s < n_seg && w1_off) ? w1_off[s] : -1;
+    st.w_off[1][s] = (s < n_seg && w2_off && n_ops == 2) ? w2_off[s] : -1;
+  }
+  const int entries = n_seg * (n_out / 32) * (n_ops * ko / 16) * 64;
+  const int blocks = std::min((entries + 255) / 256, 1024);
+  u32x4* wimg = reinterpret_cast<u32x4*>(d_scratch);
+  if (trans_w)
+    hipLaunchKernelGGL(wprep_kernel<true>, dim3(blocks), dim3(256), 0, sm, st, d_w1, d_w2, k_in, ko, n_ops, n_out, wimg);
+  else
+    hipLaunchKernelGGL(wprep_kernel<false>, dim3(blocks), dim3(256), 0, sm, st, d_w1, d_w2, k_in, ko, n_ops, n_out, wimg);
+  GCMI_CHECK_LAUNCH("fwd weight images");
+  return GCMI_OK;
+}
+
 template <int NOPS, int KO, int NOUT, bool TRANS, int NPW>
 static int launch_fwd_h(const FwdHTable& st, int n_tiles, const FwdHArgs& a, hipStream_t sm) {
   constexpr int NC = NOPS * KO;

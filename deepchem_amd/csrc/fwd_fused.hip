@@ -36,6 +36,8 @@ struct FwdArgs {
   int32_t ldo;
   int32_t relu;
   double* stats;         // bn.hip scratch layout, or nullptr
+  const u32x4* wimg;     // fwd_reg_kernel: the segments' weight fragments, split and in lane order (fwd_weight_images,
+                         // csrc/fwd_bf16.hip)
 };
 
 // ROWS rows per tile, NOPS operands of KO (padded) columns each, NOUT output columns; TRANS: weights stored
@@ -452,36 +454,19 @@ fwd_reg_kernel(FwdTable st, int n_tiles, FwdArgs a, int rev) {
   u32x4 wf[TPW][NKS][3];
   float bv[TPW];
   auto load_w = [&](int seg_) {
-    int kin = a.k_in;
-    asm volatile("" : "+s"(kin));  // everything below is formed here, on the rare segment change: hoisted out of the
-                                   // tile loop, its 64 addresses and 64 conditions would live in (spilled) registers
+    // prepared images ([segment][32-column tile][k-step][piece][lane], fwd_weight_images): coalesced 1 KiB wave loads
+    // and ONE wait.  (Read from the fp32 parameter block a fragment was eight strided dword loads per lane, which the
+    // compiler, short of registers, issued one at a time, each behind a full wait: 80 dependent L2 round trips per
+    // reload, 20-40 us that every workgroup paid at its start -- DESIGN 23.3.)
+    const u32x4* base = a.wimg + (size_t)seg_ * TW * NKS * 3 * 64 + lane;
 #pragma unroll
     for (int j = 0; j < TPW; ++j) {
-      int n = (twb + 2 * j) * 32 + l31;
-      asm volatile("" : "+v"(n));
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        const int c0 = ks * 16 + 8 * half;  // eight consecutive contraction indices, inside one operand (KO % 8 == 0)
-        const int o = c0 >= KO ? 1 : 0;
-        const int ck0 = c0 - o * KO;
-        const int64_t woff = t_w_s[o][seg_];
-        const char* wb = reinterpret_cast<const char*>((o == 1 ? a.w[1] : a.w[0]) + (woff >= 0 ? woff : 0));
-        float v[8];
+      for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int ck = ck0 + e;
-          const bool ok = woff >= 0 && ck < kin;
-          const unsigned off = ok ? (unsigned)(TRANS ? n * kin + ck : ck * NOUT + n) * 4u : 0u;
-          const float got = *reinterpret_cast<const float*>(wb + off);  // unconditional load, then select
-          v[e] = ok ? got : 0.f;
-        }
-        const Frag3 f = split_frag(v);
-        wf[j][ks][0] = f.p[0];
-        wf[j][ks][1] = f.p[1];
-        wf[j][ks][2] = f.p[2];
-      }
+        for (int pc = 0; pc < 3; ++pc) wf[j][ks][pc] = base[(size_t)(((twb + 2 * j) * NKS + ks) * 3 + pc) * 64];
       const int64_t boff = t_b_s[seg_];
-      bv[j] = (a.bias != nullptr && boff >= 0) ? a.bias[boff + n] : 0.f;
+      bv[j] = (a.bias != nullptr && boff >= 0) ? a.bias[boff + (twb + 2 * j) * 32 + l31] : 0.f;
     }
   };
 
@@ -653,7 +638,7 @@ int fwd_fused_gemm(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
                    int32_t k1, const float* d_w1, const int64_t* w1_off, const float* d_a2, int64_t lda2, int32_t k2,
                    const float* d_w2, const int64_t* w2_off, const float* d_bias, const int64_t* bias_off,
                    int32_t n_out, int32_t trans_w, int32_t act, float* d_out, int64_t ldo, double* d_stats,
-                   hipStream_t sm) {
+                   hipStream_t sm, float* d_wimg_scratch) {
   if (!fwd_fused_on() || !fused_bwd_enabled() || n_seg > kWMaxSeg || (act != 0 && act != 1)) return GCMI_ERR_UNSUPPORTED;
   const bool two = d_a1 != nullptr && d_a2 != nullptr;
   const bool conv = two && !trans_w && n_out == 64 && k1 == k2 && k1 > 32 && k1 <= 64;
@@ -689,7 +674,14 @@ int fwd_fused_gemm(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
   memset(&a, 0, sizeof(a));
   a.in[0] = d_a1; a.ldin[0] = (int32_t)lda1; a.in[1] = d_a2; a.ldin[1] = (int32_t)lda2; a.k_in = k1;
   a.w[0] = d_w1; a.w[1] = d_w2; a.bias = d_bias; a.out = d_out; a.ldo = (int32_t)ldo; a.relu = act; a.stats = d_stats;
-  if (conv80) return launch_fwd_reg<2, 80, 64, false>(st, (int)tiles, a, sm);
+  if (conv80) {
+    // (needs the caller's scratch for the weight images; without it the shape goes to seg_gemm4_kernel)
+    if (d_wimg_scratch == nullptr ||
+        fwd_weight_images(n_seg, w1_off, w2_off, d_w1, d_w2, k1, 80, 2, 64, 0, d_wimg_scratch, sm) != GCMI_OK)
+      return GCMI_ERR_UNSUPPORTED;
+    a.wimg = reinterpret_cast<const u32x4*>(d_wimg_scratch);
+    return launch_fwd_reg<2, 80, 64, false>(st, (int)tiles, a, sm);
+  }
   if (conv) return launch_fwd<128, 2, 64, 64, false>(st, (int)tiles, a, sm);
   return launch_fwd<64, 1, 64, 128, true>(st, (int)tiles, a, sm);
 }

@@ -106,7 +106,10 @@ struct Layout {
 // Issue the LDS-DMA of one window: rows of `x` (and of the byte matrix `aux`, F bytes per row)
 // and the window's neighbour entries.  Nothing waits here.
 // (x: rows of LPR 16-byte pieces -- 4 floats or 8 bf16 each --, ldx in BYTES: the DMA moves bytes, not elements)
-template <int WT, int LPR, bool AUX>
+// AUX: the byte matrix `aux` (one byte per element) rides along.  Four elements per piece (fp32 rows): one dword per
+// piece, aux32[e].  Eight (bf16 rows, EPP 8): two dwords per piece by two DMA instructions, each of which writes 64
+// lanes x 4 bytes side by side -- so per 64 pieces the image is [64 low dwords][64 high dwords] (aux_lo / aux_hi below).
+template <int WT, int LPR, bool AUX, int EPP = 4>
 __device__ __forceinline__ void stage(char* buf, const Layout& L, const WinMeta& m,
                                       const char* __restrict__ x, int64_t ldx,
                                       const uint8_t* __restrict__ aux,
@@ -122,7 +125,11 @@ __device__ __forceinline__ void stage(char* buf, const Layout& L, const WinMeta&
       const int c = e - slot * LPR;
       const int row = row_of_slot(m, L.maxd, slot);
       glds16(x + (int64_t)row * ldx + c * 16, base + e0 * 16);
-      if (AUX) glds4(aux + (int64_t)row * (LPR * 4) + c * 4, base + L.tile_bytes + e0 * 4);
+      if constexpr (AUX && EPP == 4) glds4(aux + (int64_t)row * (LPR * 4) + c * 4, base + L.tile_bytes + e0 * 4);
+      if constexpr (AUX && EPP == 8) {
+        glds4(aux + (int64_t)row * (LPR * 8) + c * 8, base + L.tile_bytes + (e0 >> 6) * 512);
+        glds4(aux + (int64_t)row * (LPR * 8) + c * 8 + 4, base + L.tile_bytes + (e0 >> 6) * 512 + 256);
+      }
     }
   }
   const int nq = (m.ne + 7) >> 3;  // 16-byte pieces of the neighbour entries
@@ -744,6 +751,198 @@ struct MaxSumOpH {
   }
 };
 
+// ---------------------------------------------------------------- gradient streams in bf16 (storage == 2)
+// The gradients that travel between kernels (dpool, dy, dS, dXs) as bf16 rows: the same ops as MaxBwdOp, SumOp<true> and
+// SumAccMaxBwdOp over pieces of eight elements, sums in fp32, one rounding at the store.  The arg-max bytes of a piece
+// are two dwords in the split image stage() writes (aux_lo / aux_hi).
+__device__ __forceinline__ uint2 aux8(const char* buf, const Layout& L, int e) {
+  const unsigned* a = reinterpret_cast<const unsigned*>(buf + L.tile_bytes) + (e >> 6) * 128 + (e & 63);
+  return make_uint2(a[0], a[64]);
+}
+__device__ __forceinline__ unsigned char aux_byte(const uint2 a, int q) {
+  return (unsigned char)((q < 4 ? a.x >> (8 * q) : a.y >> (8 * (q - 4))) & 255u);
+}
+__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+  uint4 o;
+  o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+  o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+  return o;
+}
+
+// dx[k] = dout[k]*[arg[k]==0] + sum_j dout[i_j]*[arg[i_j] == rev_pos(k,j)+1] over bf16 rows
+struct MaxBwdOpH {
+  bf16_t* __restrict__ dx;
+  int64_t lddx;
+  const float* __restrict__ only_if_gamma;  // optional (bn_bwd_pool_impl): dx only where the pooled sums are ill-conditioned
+  const float* __restrict__ only_if_beta;
+  using State = NoState;
+  static constexpr bool kExtraTile = false;
+  static constexpr int kEPP = 8;
+  __device__ __forceinline__ bool skip(int n_feat) const {
+    return only_if_gamma != nullptr && !bn_pool_ill_conditioned(only_if_gamma, only_if_beta, n_feat);
+  }
+  template <int WT>
+  __device__ __forceinline__ void init(float*, int, State&) const {}
+  template <int WT>
+  __device__ __forceinline__ void finish(char*, int, State&) const {}
+  template <int WT, int LPR>
+  __device__ __forceinline__ void run(const char* buf, const Layout& L, const WinMeta& m, const float*, State&) const {
+    const uint4* tile = reinterpret_cast<const uint4*>(buf);
+    const uint16_t* ent = reinterpret_cast<const uint16_t*>(buf + L.tile_bytes + L.aux_bytes);
+    const int n16 = m.sb[kND] * LPR;
+    for (int e = threadIdx.x; e < n16; e += WT) {
+      const int slot = e / LPR;
+      const int c = e - slot * LPR;
+      int d, row, eloc;
+      locate(m, L.maxd, slot, d, row, eloc);
+      float g[8], acc[8];
+      widen8(tile[e], g);
+      uint2 a = aux8(buf, L, e);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] = aux_byte(a, q) == 0 ? g[q] : 0.f;
+      for (int j = 0; j < d; ++j) {
+        const int en = ent[eloc + j];
+        const int sl = en & GCMI_WIN_MAX_SLOTS;
+        const unsigned char want = (unsigned char)((en >> GCMI_WIN_SLOT_BITS) + 1);
+        widen8(tile[sl * LPR + c], g);
+        a = aux8(buf, L, sl * LPR + c);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += aux_byte(a, q) == want ? g[q] : 0.f;
+      }
+      *reinterpret_cast<uint4*>(dx + (int64_t)row * lddx + c * 8) = pack8(acc);
+    }
+  }
+};
+
+// s += sum of the neighbours' rows, bf16 in and out (the oversized windows of the two-stage pass)
+struct SumAccOpH {
+  bf16_t* __restrict__ s;
+  int64_t lds;
+  using State = NoState;
+  static constexpr bool kExtraTile = false;
+  static constexpr int kEPP = 8;
+  __device__ __forceinline__ bool skip(int) const { return false; }
+  template <int WT>
+  __device__ __forceinline__ void init(float*, int, State&) const {}
+  template <int WT>
+  __device__ __forceinline__ void finish(char*, int, State&) const {}
+  template <int WT, int LPR>
+  __device__ __forceinline__ void run(const char* buf, const Layout& L, const WinMeta& m, const float*, State&) const {
+    const uint4* tile = reinterpret_cast<const uint4*>(buf);
+    const uint16_t* ent = reinterpret_cast<const uint16_t*>(buf + L.tile_bytes + L.aux_bytes);
+    const int n16 = m.sb[kND] * LPR;
+    for (int e = threadIdx.x; e < n16; e += WT) {
+      const int slot = e / LPR;
+      const int c = e - slot * LPR;
+      int d, row, eloc;
+      locate(m, L.maxd, slot, d, row, eloc);
+      bf16_t* dst = s + (int64_t)row * lds + c * 8;
+      const uint4 old = *reinterpret_cast<const uint4*>(dst);
+      float acc[8], v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+      for (int j = 0; j < d; ++j) {
+        widen8(tile[(ent[eloc + j] & GCMI_WIN_MAX_SLOTS) * LPR + c], v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += v[q];
+      }
+      widen8(old, v);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] += v[q];  // same order as SumAccMaxBwdOpH's first stage
+      *reinterpret_cast<uint4*>(dst) = pack8(acc);
+    }
+  }
+};
+
+// SumAccMaxBwdOp over bf16 streams: tile = dS rows, aux = arg rows of the block below, dxs / dy bf16; dX of the window
+// stays fp32 in the third LDS tile (it is never stored, so it is never rounded).  With tiles of half the size two
+// 1 024-thread workgroups... do not fit a CU's thread limit, but two 512-thread ones do.
+struct SumAccMaxBwdOpH {
+  const bf16_t* __restrict__ dxs;  // self part of dX (global rows)
+  int64_t lddxs;
+  bf16_t* __restrict__ dy;
+  int64_t lddy;
+  struct State {
+    char* extra;  // the third tile: [slot][LPR][8] floats
+  };
+  static constexpr bool kExtraTile = true;
+  static constexpr int kExtraScale = 2;  // the third tile is fp32: twice the bytes of the bf16 tile
+  static constexpr int kEPP = 8;
+  __device__ __forceinline__ bool skip(int) const { return false; }
+  template <int WT>
+  __device__ __forceinline__ void init(float*, int, State&) const {}
+  template <int WT>
+  __device__ __forceinline__ void finish(char*, int, State&) const {}
+  template <int WT, int LPR>
+  __device__ __forceinline__ void run(const char* buf, const Layout& L, const WinMeta& m, const float*, State& st) const {
+    const uint4* tile = reinterpret_cast<const uint4*>(buf);
+    const uint16_t* ent = reinterpret_cast<const uint16_t*>(buf + L.tile_bytes + L.aux_bytes);
+    float4* t2 = reinterpret_cast<float4*>(st.extra);  // two float4 per piece
+    const int n16 = m.sb[kND] * LPR;
+    // ---- stage 1: dX of the window -> the third tile
+    for (int e0 = threadIdx.x; e0 < n16; e0 += kPre * WT) {
+      uint4 old[kPre];
+#pragma unroll
+      for (int k = 0; k < kPre; ++k) {
+        const int e = e0 + k * WT < n16 ? e0 + k * WT : n16 - 1;
+        const int slot = e / LPR;
+        const int c = e - slot * LPR;
+        old[k] = *reinterpret_cast<const uint4*>(dxs + (int64_t)row_of_slot(m, L.maxd, slot) * lddxs + c * 8);
+      }
+#pragma unroll
+      for (int k = 0; k < kPre; ++k) {
+        const int e = e0 + k * WT;
+        if (e >= n16) break;
+        const int slot = e / LPR;
+        const int c = e - slot * LPR;
+        int d, row, eloc;
+        locate(m, L.maxd, slot, d, row, eloc);
+        float acc[8], v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+        for (int j = 0; j < d; ++j) {
+          widen8(tile[(ent[eloc + j] & GCMI_WIN_MAX_SLOTS) * LPR + c], v);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc[q] += v[q];
+        }
+        widen8(old[k], v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += v[q];
+        t2[2 * e] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        t2[2 * e + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+      }
+    }
+    __syncthreads();
+    // ---- stage 2: the GraphPool backward over it
+    for (int e = threadIdx.x; e < n16; e += WT) {
+      const int slot = e / LPR;
+      const int c = e - slot * LPR;
+      int d, row, eloc;
+      locate(m, L.maxd, slot, d, row, eloc);
+      float4 g0 = t2[2 * e], g1 = t2[2 * e + 1];
+      uint2 a = aux8(buf, L, e);
+      float acc[8];
+      {
+        const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = aux_byte(a, q) == 0 ? g[q] : 0.f;
+      }
+      for (int j = 0; j < d; ++j) {
+        const int en = ent[eloc + j];
+        const int sl = en & GCMI_WIN_MAX_SLOTS;
+        const unsigned char want = (unsigned char)((en >> GCMI_WIN_SLOT_BITS) + 1);
+        g0 = t2[2 * (sl * LPR + c)];
+        g1 = t2[2 * (sl * LPR + c) + 1];
+        a = aux8(buf, L, sl * LPR + c);
+        const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += aux_byte(a, q) == want ? g[q] : 0.f;
+      }
+      *reinterpret_cast<uint4*>(dy + (int64_t)row * lddy + c * 8) = pack8(acc);
+    }
+  }
+};
+
 // ---------------------------------------------------------------- the persistent window walker
 // Workgroups [0, g_norm) walk the ordinary windows double-buffered; workgroups [g_norm, gridDim)
 // walk the oversized windows (one big molecule each) using both buffers as one.
@@ -769,7 +968,7 @@ win_kernel(const int32_t* __restrict__ meta, const uint16_t* __restrict__ edges,
       if (t < GCMI_WIN_META_INTS) ring[0][t] = meta[(size_t)w * GCMI_WIN_META_INTS + t];
       __syncthreads();
       const WinMeta m = read_meta(ring[0]);
-      stage<WT, LPR, AUX>(smem, Lbig, m, x, ldx, aux, edges);
+      stage<WT, LPR, AUX, Op::kEPP>(smem, Lbig, m, x, ldx, aux, edges);
       wait_dma();
       __syncthreads();
       op.template run<WT, LPR>(smem, Lbig, m, op_lds, ost);
@@ -791,7 +990,7 @@ win_kernel(const int32_t* __restrict__ meta, const uint16_t* __restrict__ edges,
     if (w + 2 * G < n_norm) metareg = meta[widx(w + 2 * G) * GCMI_WIN_META_INTS + t];
   }
   __syncthreads();
-  stage<WT, LPR, AUX>(smem, L, read_meta(ring[0]), x, ldx, aux, edges);
+  stage<WT, LPR, AUX, Op::kEPP>(smem, L, read_meta(ring[0]), x, ldx, aux, edges);
   int it = 0;
   for (;;) {
     wait_dma();
@@ -802,7 +1001,7 @@ win_kernel(const int32_t* __restrict__ meta, const uint16_t* __restrict__ edges,
       if (w + 3 * G < n_norm) metareg = meta[widx(w + 3 * G) * GCMI_WIN_META_INTS + t];
     }
     if (has_next)
-      stage<WT, LPR, AUX>(smem + ((it + 1) & 1) * bb, L, read_meta(ring[(it + 1) % 3]), x, ldx, aux, edges);
+      stage<WT, LPR, AUX, Op::kEPP>(smem + ((it + 1) & 1) * bb, L, read_meta(ring[(it + 1) % 3]), x, ldx, aux, edges);
     op.template run<WT, LPR>(smem + (it & 1) * bb, L, read_meta(ring[it % 3]), op_lds, ost);
     if (!has_next) break;
     w += G;
@@ -824,10 +1023,11 @@ static int env_int(const char* name, int dflt) {
 }
 
 // (n_feat counts FLOATS per tile row: a bf16 row of n elements is a tile row of n / 2 "floats")
-static Layout make_layout(int alloc, int ecap, int maxd, int n_feat, bool aux) {
+// aux: 0 none, 4 / 8 = aux bytes per 16-byte piece (fp32 / bf16 rows; stage())
+static Layout make_layout(int alloc, int ecap, int maxd, int n_feat, int aux) {
   Layout L;
   L.tile_bytes = alloc * n_feat * 4;
-  L.aux_bytes = aux ? (alloc * n_feat + 15) / 16 * 16 : 0;
+  L.aux_bytes = aux == 4 ? (alloc * n_feat + 15) / 16 * 16 : aux == 8 ? (alloc * (n_feat / 4) + 63) / 64 * 512 : 0;
   L.edge_bytes = (ecap > 8 ? ecap : 8) * 2;
   L.maxd = maxd;
   return L;
@@ -840,7 +1040,7 @@ struct WinPlan {
 };
 
 // LDS shapes: the two buffers of the ordinary windows must also hold one oversized window.
-static WinPlan make_plan(const gcmi_graph* g, int n_feat, bool aux) {
+static WinPlan make_plan(const gcmi_graph* g, int n_feat, int aux) {
   int maxd = 0;
   for (int d = 1; d <= g->max_deg; ++d)
     if (g->deg_start[d + 1] > g->deg_start[d]) maxd = d;
@@ -863,8 +1063,14 @@ bool win_usable(const gcmi_graph* g, int n_feat, bool aux) {
   if (windows_disabled() || g->d_win_meta == nullptr || g->n_win <= 0) return false;
   if (g->d_win_edges == nullptr || g->n_win_big < 0 || g->n_win_big > g->n_win) return false;
   if (n_feat % 4 != 0 || n_feat > 256) return false;
-  return make_plan(g, n_feat, aux).ok;
+  return make_plan(g, n_feat, aux ? 4 : 0).ok;
 }
+
+// bytes of an op's third LDS tile in units of the window tile (1 unless the op says otherwise: kExtraScale)
+template <class Op>
+static constexpr auto extra_scale(int) -> decltype(Op::kExtraScale) { return Op::kExtraScale; }
+template <class Op>
+static constexpr int extra_scale(long) { return 1; }
 
 template <int WT, int LPR, bool AUX, class Op>
 static int launch_wt(const gcmi_graph* g, const WinPlan& p, const char* x, int64_t ldx, const uint8_t* aux,
@@ -888,7 +1094,7 @@ static int launch_wt(const gcmi_graph* g, const WinPlan& p, const char* x, int64
       set_error("%s: oversized windows are not handled by the two-stage form", what);
       return GCMI_ERR_UNSUPPORTED;
     }
-    shmem += (size_t)p.L.tile_bytes;
+    shmem += (size_t)p.L.tile_bytes * extra_scale<Op>(0);
     if (shmem > (size_t)kLdsPerCU) return GCMI_ERR_UNSUPPORTED;
   }
   const int by_lds = (int)((size_t)kLdsPerCU / shmem);
@@ -907,9 +1113,13 @@ template <int LPR, bool AUX, class Op>
 static int launch_lpr(const gcmi_graph* g, const WinPlan& p, const char* x, int64_t ldx, const uint8_t* aux,
                       const Op& op, hipStream_t st, const char* what, int which) {
   static const int wt = env_int("GCMI_WIN_THREADS", 512);
-  if constexpr (Op::kExtraTile) {  // one workgroup per CU by LDS: make it a full one
-    static const int wt2 = env_int("GCMI_WIN_THREADS_TWO_STAGE", 1024);
-    if (wt2 == 1024) return launch_wt<1024, LPR, AUX, Op>(g, p, x, ldx, aux, op, st, what, which);
+  if constexpr (Op::kExtraTile) {
+    // fp32 tiles: one workgroup per CU by LDS, so make it a full one (1 024 threads: 292 us against 346 at 512).  bf16
+    // tiles are half the size and two 512-thread workgroups share a CU: 288 us against 367 at 1 024 (SumAccMaxBwdOpH)
+    static const int wt2 = env_int("GCMI_WIN_THREADS_TWO_STAGE", 0);
+    const int want = wt2 ? wt2 : (Op::kEPP == 8 ? 512 : 1024);
+    if (want == 1024) return launch_wt<1024, LPR, AUX, Op>(g, p, x, ldx, aux, op, st, what, which);
+    if (want == 512) return launch_wt<512, LPR, AUX, Op>(g, p, x, ldx, aux, op, st, what, which);
   }
   if (wt == 1024) return launch_wt<1024, LPR, AUX, Op>(g, p, x, ldx, aux, op, st, what, which);
   if (wt == 256) return launch_wt<256, LPR, AUX, Op>(g, p, x, ldx, aux, op, st, what, which);
@@ -919,7 +1129,7 @@ static int launch_lpr(const gcmi_graph* g, const WinPlan& p, const char* x, int6
 template <bool AUX, class Op>
 static int launch(const gcmi_graph* g, int n_feat, const float* x, int64_t ldx, const uint8_t* aux,
                   const Op& op, hipStream_t st, const char* what, int which = 0) {
-  const WinPlan p = make_plan(g, n_feat, AUX);
+  const WinPlan p = make_plan(g, n_feat, AUX ? 4 : 0);
   const char* xb = reinterpret_cast<const char*>(x);
   switch (n_feat / 4) {
     case 16: return launch_lpr<16, AUX, Op>(g, p, xb, ldx * 4, aux, op, st, what, which);
@@ -932,15 +1142,15 @@ static int launch(const gcmi_graph* g, int n_feat, const float* x, int64_t ldx, 
 }
 
 // rows of bf16: n_feat elements = n_feat / 8 pieces (64 -> 8, 80 -> 10, 128 -> 16)
-template <class Op>
+template <class Op, bool AUX = false>
 static int launch_h(const gcmi_graph* g, int n_feat, const bf16_t* x, int64_t ldx, const Op& op, hipStream_t st,
-                    const char* what, int which = 0) {
-  const WinPlan p = make_plan(g, n_feat / 2, false);
+                    const char* what, int which = 0, const uint8_t* aux = nullptr) {
+  const WinPlan p = make_plan(g, n_feat / 2, AUX ? 8 : 0);
   const char* xb = reinterpret_cast<const char*>(x);
   switch (n_feat / 8) {
-    case 8: return launch_lpr<8, false, Op>(g, p, xb, ldx * 2, nullptr, op, st, what, which);
-    case 10: return launch_lpr<10, false, Op>(g, p, xb, ldx * 2, nullptr, op, st, what, which);
-    case 16: return launch_lpr<16, false, Op>(g, p, xb, ldx * 2, nullptr, op, st, what, which);
+    case 8: return launch_lpr<8, AUX, Op>(g, p, xb, ldx * 2, aux, op, st, what, which);
+    case 10: return launch_lpr<10, AUX, Op>(g, p, xb, ldx * 2, aux, op, st, what, which);
+    case 16: return launch_lpr<16, AUX, Op>(g, p, xb, ldx * 2, aux, op, st, what, which);
     default: break;
   }
   set_error("%s: no bf16 window kernel for %d features", what, n_feat);
@@ -986,7 +1196,7 @@ bool win_usable_h(const gcmi_graph* g, int n_feat) {
   if (windows_disabled() || g->d_win_meta == nullptr || g->n_win <= 0) return false;
   if (g->d_win_edges == nullptr || g->n_win_big < 0 || g->n_win_big > g->n_win) return false;
   if (n_feat != 64 && n_feat != 80 && n_feat != 128) return false;
-  return make_plan(g, n_feat / 2, false).ok;
+  return make_plan(g, n_feat / 2, 0).ok;
 }
 
 // fp32 rows of n_feat (76) columns -> bf16 neighbour sums and a bf16 copy of the rows, both `ldo` (80) wide
@@ -1016,6 +1226,38 @@ int win_gather_max_h(const gcmi_graph* g, const bf16_t* d_x, int64_t ldx, int n_
   return launch_h(g, n_feat, d_x, ldx, op, st, "win_gather_max (bf16)");
 }
 
+// ---- gradient streams in bf16 (storage == 2)
+bool win_usable_gh(const gcmi_graph* g, int n_feat) {
+  if (windows_disabled() || g->d_win_meta == nullptr || g->n_win <= 0) return false;
+  if (g->d_win_edges == nullptr || g->n_win_big < 0 || g->n_win_big > g->n_win || n_feat != 64) return false;
+  return make_plan(g, n_feat / 2, 8).ok;
+}
+
+int win_gather_max_bwd_h(const gcmi_graph* g, const bf16_t* d_dout, int64_t lddo, int n_feat, const uint8_t* d_arg,
+                         bf16_t* d_dx, int64_t lddx, const float* only_if_gamma, const float* only_if_beta, hipStream_t st) {
+  MaxBwdOpH op{d_dx, lddx, only_if_gamma, only_if_beta};
+  return launch_h<MaxBwdOpH, true>(g, n_feat, d_dout, lddo, op, st, "win_gather_max_bwd (bf16)", 0, d_arg);
+}
+
+bool win_two_stage_usable_h(const gcmi_graph* g, int n_feat) {
+  if (!win_usable_gh(g, n_feat)) return false;
+  const WinPlan p = make_plan(g, n_feat / 2, 8);
+  return p.shmem + (size_t)2 * p.L.tile_bytes <= (size_t)kLdsPerCU;
+}
+
+// d_dxs holds the self part of dX on entry (bf16); on return d_dy holds the GraphPool backward of the complete dX.
+int win_gather_sumacc_max_bwd_h(const gcmi_graph* g, const bf16_t* d_ds, int64_t ldds, int n_feat, bf16_t* d_dxs,
+                                int64_t lddxs, const uint8_t* d_arg, bf16_t* d_dy, int64_t lddy, hipStream_t st) {
+  SumAccMaxBwdOpH op{d_dxs, lddxs, d_dy, lddy};
+  int rc = launch_h<SumAccMaxBwdOpH, true>(g, n_feat, d_ds, ldds, op, st, "win_gather_sumacc_max_bwd (bf16)", 1, d_arg);
+  if (rc || g->n_win_big == 0) return rc;
+  SumAccOpH acc{d_dxs, lddxs};
+  rc = launch_h(g, n_feat, d_ds, ldds, acc, st, "win_gather_sum (bf16, accumulate, oversized windows)", 2);
+  if (rc) return rc;
+  MaxBwdOpH mb{d_dy, lddy, nullptr, nullptr};
+  return launch_h<MaxBwdOpH, true>(g, n_feat, d_dxs, lddxs, mb, st, "win_gather_max_bwd (bf16, oversized windows)", 2, d_arg);
+}
+
 // GraphPool of this block + sum_neigh of the next in one window pass (MaxSumOpH); the oversized windows (a molecule
 // above the window cap each) take the two separate ops over their own rows
 bool win_max_sum_usable_h(const gcmi_graph* g, int n_feat) {
@@ -1024,7 +1266,7 @@ bool win_max_sum_usable_h(const gcmi_graph* g, int n_feat) {
   // default, GCMI_FUSED_POOL_SUM=1 switches it on
   static const bool on = getenv("GCMI_FUSED_POOL_SUM") && atoi(getenv("GCMI_FUSED_POOL_SUM")) != 0;
   if (!on || !win_usable_h(g, n_feat)) return false;
-  const WinPlan p = make_plan(g, n_feat / 2, false);
+  const WinPlan p = make_plan(g, n_feat / 2, 0);
   return p.shmem + (size_t)p.L.tile_bytes <= (size_t)kLdsPerCU;
 }
 
@@ -1056,7 +1298,7 @@ int win_gather_max_sum_h(const gcmi_graph* g, const bf16_t* d_x, int64_t ldx, in
 // the batch, or no LDS for the third tile.
 bool win_two_stage_usable(const gcmi_graph* g, int n_feat) {
   if (!win_has_width(n_feat) || !win_usable(g, n_feat, true)) return false;
-  const WinPlan p = make_plan(g, n_feat, true);
+  const WinPlan p = make_plan(g, n_feat, 4);
   return p.shmem + (size_t)p.L.tile_bytes <= (size_t)kLdsPerCU;
 }
 

@@ -815,7 +815,7 @@ int seg_gemm_stats(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
                    int32_t k1, const float* d_w1, const int64_t* w1_off, const float* d_a2, int64_t lda2, int32_t k2,
                    const float* d_w2, const int64_t* w2_off, const float* d_bias, const int64_t* bias_off,
                    int32_t n_out, int32_t trans_w, int32_t act, float* d_out, int64_t ldo, double* d_stats,
-                   bool* fused, void* stream) {
+                   bool* fused, void* stream, float* d_wimg_scratch) {
   *fused = false;
   const bool allow = g_fused_bn_stats.load(std::memory_order_relaxed) != 0;  // GCMI_OPT_FUSED_BN_STATS
   static const bool v3 = getenv("GCMI_GEMM_V3") && atoi(getenv("GCMI_GEMM_V3")) == 1;
@@ -830,7 +830,7 @@ int seg_gemm_stats(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
     TimedScope ts(GCMI_K_SEG_GEMM, sm);
     double* stats = (allow && d_stats) ? d_stats : nullptr;
     const int rc = fwd_fused_gemm(n_seg, seg_begin, seg_end, d_a1, lda1, k1, d_w1, w1_off, d_a2, lda2, k2, d_w2, w2_off,
-                                  d_bias, bias_off, n_out, trans_w, act, d_out, ldo, stats, sm);
+                                  d_bias, bias_off, n_out, trans_w, act, d_out, ldo, stats, sm, d_wimg_scratch);
     if (rc != GCMI_ERR_UNSUPPORTED) {
       *fused = rc == GCMI_OK && stats != nullptr;
       return rc;

@@ -49,7 +49,7 @@ struct Ws {
   int64_t ldS[kMaxL], ngather[kMaxL];
   int64_t dense, arg_r, rsum, dfp, tA, tB, tC, tD, tE, total;
   int64_t xb;    // storage == 1: bf16 copy of the atom features (ld = ldS[0])
-  int64_t wimg;  // storage == 1: scratch of fwd_h_gemm (split weight fragments, rebuilt by every launch)
+  int64_t wimg;  // scratch of the forward products (split weight fragments in lane order, rebuilt by every launch)
   // one region the backward zeroes with a single memset: [dlogits | dbsum per layer | lacc | acc]
   int64_t dlogits, dbsum[kMaxL], lacc, acc, acc2, z_end;
 };
@@ -67,7 +67,7 @@ static Ws carve(const gcmi_model_desc* m, int64_t N, int64_t B, int64_t ld_featu
   };
   // storage == 1: the matrices the step writes and reads back (S, gc, pool, dense, and a copy of the atom features)
   // are bf16: rows of ld ELEMENTS with ld a multiple of 8, half the floats of the workspace per element
-  const bool h = m->storage == 1;
+  const bool h = m->storage >= 1;
   auto take_act = [&](int64_t rows, int64_t ld) { return take(h ? (rows * ld + 1) / 2 : rows * ld); };
   const int L = m->n_layers;
   int64_t wmax = m->dense_width, kmax = up4(m->n_feat_in);
@@ -80,10 +80,8 @@ static Ws carve(const gcmi_model_desc* m, int64_t N, int64_t B, int64_t ld_featu
     w.ldS[l] = h ? up8(w.ngather[l]) : up4(w.ngather[l]);
     const int64_t wd = m->conv_width[l];
     w.S[l] = take_act(N, w.ldS[l]);
-    if (h && l == 0) {
-      w.xb = take_act(N, w.ldS[0]);
-      w.wimg = take(kFwdHWimgFloats);
-    }
+    if (h && l == 0) w.xb = take_act(N, w.ldS[0]);
+    if (l == 0) w.wimg = take(kFwdHWimgFloats);
     w.gc[l] = take_act(N, wd);
     w.pool[l] = take_act(N, wd);
     w.arg[l] = take((N * wd + 3) / 4);
@@ -125,7 +123,9 @@ static int check_desc(const gcmi_model_desc* m) {
   if (m->storage != 0) {
     // bf16 activation storage in the streaming kernels (fwd_bf16.hip, bwd_fused.hip HB, gather_lds.hip *OpH): the
     // default shapes -- GraphConv widths 64 over 65..80 input columns, dense width 128, BatchNorm on
-    bool ok = m->storage == 1 && m->batch_norm && m->dense_width == 128 && m->n_feat_in > 64 && m->n_feat_in <= 80;
+    // (2 = the gradient streams between the kernels are bf16 as well)
+    bool ok = (m->storage == 1 || m->storage == 2) && m->batch_norm && m->dense_width == 128 && m->n_feat_in > 64 &&
+              m->n_feat_in <= 80;
     for (int l = 0; l < m->n_layers; ++l) ok = ok && m->conv_width[l] == 64;
     if (!ok) {
       set_error("gcmi_model_*: bf16 activation storage covers graph_conv_layers of width 64 over 65..80 atom features, "
@@ -195,6 +195,10 @@ static int require_h(const gcmi_model_desc* m, const gcmi_graph* g, const gcmi_m
     }
     if (!fused_bwd_enabled()) {
       set_error("bf16 activation storage: the one-pass block kernels are switched off (GCMI_OPT_FUSED_BWD)");
+      return GCMI_ERR_UNSUPPORTED;
+    }
+    if (m->storage == 2 && !win_usable_gh(g, 64)) {
+      set_error("bf16 gradient streams: the graph carries no usable molecule-window plan");
       return GCMI_ERR_UNSUPPORTED;
     }
   }
@@ -376,6 +380,9 @@ static int model_loss_backward_h(const gcmi_model_desc* m, const gcmi_graph* g, 
   const int Wl = m->conv_width[L - 1];
   float* dpool = ws + w.tC;
   const float* coef = ws + w.acc;
+  // storage == 2: dpool, dy, dS and dXs are bf16 rows (in the same fp32-sized workspace blocks, ld in elements)
+  const bool gb = m->storage == 2;
+  auto HG = [](float* p) { return reinterpret_cast<bf16_t*>(p); };
   // ---- dense block: BatchNorm sums from per-molecule data, then one pass (dense and pool rows arrive as bf16)
   if (head_sums) {
     RUN(bn_bwd_params_impl(N, D, d_params + m->off_bn_gamma[L], bnvL, bnvL + D, d_grads + m->off_bn_gamma[L],
@@ -393,7 +400,7 @@ static int model_loss_backward_h(const gcmi_model_desc* m, const gcmi_graph* g, 
     const int rc = fused_dense_bwd(N, g->d_membership, ws + w.dfp, 2 * D, reinterpret_cast<const int32_t*>(ws + w.arg_r),
                                    HF(w.dense), D, coef, D, HF(w.pool[L - 1]), Wl, Wl, d_params + m->off_dense_w,
                                    d_grads + m->off_dense_w, d_grads + m->off_dense_b, dpool, Wl,
-                                   reinterpret_cast<double*>(ws + w.acc2), st, 1);
+                                   reinterpret_cast<double*>(ws + w.acc2), st, gb ? 2 : 1);
     if (rc == GCMI_ERR_UNSUPPORTED) set_error("bf16 activation storage: the dense block has no one-pass backward");
     RUN(rc);
   }
@@ -413,6 +420,11 @@ static int model_loss_backward_h(const gcmi_model_desc* m, const gcmi_graph* g, 
     // dy itself only when the GraphConv below trains, or where the pooled sums are ill-conditioned
     if (dy_ready) {
       // (left by win_gather_sumacc_max_bwd below, one iteration ago)
+    } else if (gb) {
+      TimedScope ts(GCMI_K_GATHER_MAX_BWD, st);
+      RUN(win_gather_max_bwd_h(g, HG(dpool), W, W, reinterpret_cast<const uint8_t*>(ws + w.arg[l]), HG(dy), W,
+                               full ? nullptr : d_params + m->off_bn_gamma[l], full ? nullptr : d_params + m->off_bn_beta[l],
+                               st));
     } else if (full) {
       RUN(gcmi_gather_max_bwd(g, dpool, W, W, reinterpret_cast<const uint8_t*>(ws + w.arg[l]), dy, W, stream));
     } else {
@@ -422,7 +434,7 @@ static int model_loss_backward_h(const gcmi_model_desc* m, const gcmi_graph* g, 
     }
     RUN(bn_bwd_pool_impl(dy, W, HF(w.gc[l]), W, N, W, d_params + m->off_bn_gamma[l], d_params + m->off_bn_beta[l], bnv, bnv + W,
                          d_grads + m->off_bn_gamma[l], d_grads + m->off_bn_beta[l], reinterpret_cast<double*>(ws + w.acc2),
-                         reinterpret_cast<double*>(ws + w.acc), stream, 1));
+                         reinterpret_cast<double*>(ws + w.acc), stream, gb ? 2 : 1));
     dy_ready = false;
     if (!full) break;  // reference semantics: nothing in front of a GraphConv output trains
     {
@@ -431,7 +443,7 @@ static int model_loss_backward_h(const gcmi_model_desc* m, const gcmi_graph* g, 
                                     HF(w.S[l]), w.ldS[l], reinterpret_cast<const float*>(xin), ldx, K,
                                     d_params + m->off_conv_w[l], d_grads + m->off_conv_w[l], ws + w.dbsum[l],
                                     l > 0 ? dS : nullptr, K, l > 0 ? dX : nullptr, K,
-                                    l > 0 ? reinterpret_cast<double*>(ws + w.acc2) : nullptr, st, 1);
+                                    l > 0 ? reinterpret_cast<double*>(ws + w.acc2) : nullptr, st, gb ? 2 : 1);
       if (rc == GCMI_ERR_UNSUPPORTED) set_error("bf16 activation storage: GraphConv %d has no one-pass backward", l);
       RUN(rc);
     }
@@ -441,7 +453,16 @@ static int model_loss_backward_h(const gcmi_model_desc* m, const gcmi_graph* g, 
     if (l == 0) break;  // the atom features need no gradient
     // dX holds the self part; the neighbour part is added onto it, and where the window kernels can hold a third tile
     // the GraphPool backward of the block below runs in the same pass
-    if (win_two_stage_usable(g, K) && aligned16(dS) && aligned16(dX) && aligned16(ws + w.tD)) {
+    if (gb) {
+      if (!win_two_stage_usable_h(g, K)) {
+        set_error("bf16 gradient streams: no LDS for the two-stage window pass");
+        return GCMI_ERR_UNSUPPORTED;
+      }
+      TimedScope ts(GCMI_K_GATHER_MAX_BWD, st);
+      RUN(win_gather_sumacc_max_bwd_h(g, HG(dS), K, K, HG(dX), K, reinterpret_cast<const uint8_t*>(ws + w.arg[l - 1]),
+                                      HG(ws + w.tD), K, st));
+      dy_ready = true;
+    } else if (win_two_stage_usable(g, K) && aligned16(dS) && aligned16(dX) && aligned16(ws + w.tD)) {
       TimedScope ts(GCMI_K_GATHER_MAX_BWD, st);
       RUN(win_gather_sumacc_max_bwd(g, dS, K, K, dX, K, reinterpret_cast<const uint8_t*>(ws + w.arg[l - 1]), ws + w.tD, K, st));
       dy_ready = true;
@@ -475,7 +496,7 @@ int gcmi_model_forward(const gcmi_model_desc* m, const gcmi_graph* g, const floa
   GCMI_CHECK_ARG(g->n_mols > 1, "graph_gather requires batches larger than 1");
   GCMI_CHECK_ARG(g->n_atoms == 0 || io->d_atom_features, "model_forward: NULL atom features");
   GCMI_CHECK_ARG(io->ld_features >= m->n_feat_in, "ld_features < n_feat_in");
-  if (m->storage == 1) return model_forward_h(m, g, d_params, io, training, stream);
+  if (m->storage >= 1) return model_forward_h(m, g, d_params, io, training, stream);
   hipStream_t st = (hipStream_t)stream;
   const int L = m->n_layers;
   const int64_t N = g->n_atoms, B = g->n_mols;
@@ -505,7 +526,7 @@ int gcmi_model_forward(const gcmi_model_desc* m, const gcmi_graph* g, const floa
                          sg.w_rel, x, ldx, K, d_params + m->off_conv_w[l], sg.w_self, ws + w.bsum[l],
                          sg.b_off, W, 0, 1, ws + w.gc[l], W,
                          (m->batch_norm && training) ? reinterpret_cast<double*>(ws + w.acc) : nullptr,
-                         &stats_fused, stream));
+                         &stats_fused, stream, ws + w.wimg));
     }
     float* scale = nullptr;
     float* shift = nullptr;
@@ -602,7 +623,7 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
                  "model_loss_backward: NULL buffer");
   GCMI_CHECK_ARG(n_rows > 0 && n_rows <= g->n_mols, "n_rows %lld outside (0, n_mols=%d]", (long long)n_rows,
                  g->n_mols);
-  if (m->storage == 1)
+  if (m->storage >= 1)
     return model_loss_backward_h(m, g, d_params, d_grads, io, d_labels, d_weights, n_rows, grad_lo, grad_hi, stream);
   hipStream_t st = (hipStream_t)stream;
   const int L = m->n_layers;

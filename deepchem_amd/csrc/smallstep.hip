@@ -1545,7 +1545,8 @@ static int small_check(const gcmi_model_desc* m) {
   GCMI_CHECK_ARG(m->max_deg >= 0 && m->max_deg <= GCMI_MAX_DEG, "small: bad max_deg");
   GCMI_CHECK_ARG(m->n_feat_in > 0 && m->n_tasks > 0 && m->n_classes > 0, "small: bad widths");
   GCMI_CHECK_ARG(m->mode == 0 || (m->mode == 1 && m->n_classes == 1), "small: bad mode / n_classes");
-  GCMI_CHECK_ARG(m->storage == 0 || m->storage == 1, "small: storage must be 0 (fp32) or 1 (bf16 activations)");
+  GCMI_CHECK_ARG(m->storage >= 0 && m->storage <= 2,
+                 "small: storage must be 0 (fp32), 1 (bf16 activations) or 2 (and bf16 gradient streams: same as 1 here)");
   for (int l = 0; l < m->n_layers; ++l)
     if (m->conv_width[l] <= 0 || m->conv_width[l] % 64 || m->conv_width[l] > 256) {
       set_error("small: GraphConv width %d is not a multiple of 64 in [64, 256]", m->conv_width[l]);
@@ -1999,7 +2000,7 @@ int gcmi_small_fit_dp(const gcmi_model_desc* m, float* d_params, float* d_grads,
     GCMI_CHECK_ARG(b->graph.max_deg == m->max_deg, "small_fit: graph max_deg %d != model max_deg %d", b->graph.max_deg,
                    m->max_deg);
     SRUN(make_small_graph(&b->graph, true, &graphs[(size_t)i]));
-    graphs[(size_t)i].bf16 = m->storage == 1 ? 1 : 0;
+    graphs[(size_t)i].bf16 = m->storage >= 1 ? 1 : 0;  // (2: gradient streams too -- no such streams here, the batch lives in L2)
   }
   auto slot_of = [](int64_t i) { return (int)(((i / kAhead) & 1) * kAhead + i % kAhead); };
   const int64_t n_groups = (n_batches + kAhead - 1) / kAhead;
@@ -2138,7 +2139,7 @@ int gcmi_small_predict(const gcmi_model_desc* m, const float* d_params, const gc
     GCMI_CHECK_ARG(b->graph.max_deg == m->max_deg, "small_predict: graph max_deg != model max_deg");
     SmallGraph g;
     SRUN(make_small_graph(&b->graph, false, &g));
-    g.bf16 = m->storage == 1 ? 1 : 0;
+    g.bf16 = m->storage >= 1 ? 1 : 0;
     SRUN(small_forward_body(c, g, b->d_atom_features, b->ld_features));
     ReadoutArgs ra;
     memset(&ra, 0, sizeof(ra));

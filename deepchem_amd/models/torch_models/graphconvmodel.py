@@ -88,8 +88,9 @@ class _GraphConvTorchModel(nn.Module):
         super(_GraphConvTorchModel, self).__init__()
         if mode not in ['classification', 'regression']:
             raise ValueError("mode must be either 'classification' or 'regression'")
-        if activation_storage not in ("fp32", "bf16"):
-            raise ValueError("activation_storage must be 'fp32' or 'bf16'")
+        # "bf16": the activations a step writes and reads back; "bf16+grads": also the gradient streams between kernels
+        if activation_storage not in ("fp32", "bf16", "bf16+grads"):
+            raise ValueError("activation_storage must be 'fp32', 'bf16' or 'bf16+grads'")
         # "bf16": every matrix a step writes and reads back (GraphConv outputs, pooled rows, dense output) is kept
         # as bfloat16, arithmetic and accumulation stay fp32 (the reference has no such mode).  Opt-in.
         self.activation_storage = activation_storage

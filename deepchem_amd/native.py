@@ -153,7 +153,7 @@ class NativeNet:
         d.off_head_w = self.offsets[head + ".weight"]
         d.off_head_b = self.offsets[head + ".bias"]
         d.n_params = self.flat.numel()
-        d.storage = 1 if getattr(m, "activation_storage", "fp32") == "bf16" else 0
+        d.storage = {"fp32": 0, "bf16": 1, "bf16+grads": 2}[getattr(m, "activation_storage", "fp32")]
 
     def refresh(self, quick: bool = False):
         """Re-flatten if someone replaced parameters (``layer.W_list = ...``, ``p.data = ...``) or

@@ -484,9 +484,15 @@ typedef struct gcmi_model_desc {
   int64_t off_bn_gamma[GCMI_MAX_CONV_LAYERS + 1], off_bn_beta[GCMI_MAX_CONV_LAYERS + 1];
   int64_t off_dense_w, off_dense_b, off_head_w, off_head_b;
   int64_t n_params;
-  int32_t storage;                       /* activations the step writes and reads back: 0 fp32, 1 bfloat16 (fp32
-                                            arithmetic and accumulation either way; gcmi_small_* only: gcmi_model_*
-                                            rejects 1 with GCMI_ERR_UNSUPPORTED)                                   */
+  int32_t storage;                       /* what a step writes and reads back: 0 fp32; 1 the activations as bfloat16 (a
+                                            copy of the atom features, neighbour sums, GraphConv outputs, pooled rows,
+                                            the dense output: one rounding per stored element); 2 also the gradient
+                                            STREAMS between kernels (dpool, dy, dS, dXs).  fp32 arithmetic and
+                                            accumulation, fp64 BatchNorm sums of the rounded values, fp32 parameters,
+                                            parameter gradients and Adam state in every mode.  gcmi_small_*: 1 and 2 are
+                                            the same (its gradients never leave L2).  gcmi_model_*: the default shapes
+                                            only (widths 64 over 65..80 features, dense 128, BatchNorm on), else
+                                            GCMI_ERR_UNSUPPORTED                                                   */
   int32_t reserved_;
 } gcmi_model_desc;
 

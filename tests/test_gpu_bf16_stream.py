@@ -35,7 +35,7 @@ def _native_step(packed, y, w, tasks, grad_mode, state, storage, train=True):
                                                   grad_mode=grad_mode, device=DEV, activation_storage=storage)
     model.model.load_state_dict({k: v.clone() for k, v in state.items()})
     native = model.model._native_net()
-    assert native is not None and native.desc.storage == (1 if storage == "bf16" else 0)
+    assert native is not None and native.desc.storage == {"fp32": 0, "bf16": 1, "bf16+grads": 2}[storage]
     g = dbatch.graph
     g.set_mols(n)
     assert g.c.n_win > 0
@@ -120,22 +120,26 @@ def batch_4096():
     return packed, y, w, tasks, O.init_state(cfg, 17)
 
 
+@pytest.mark.parametrize("storage", ["bf16", "bf16+grads"])
 @pytest.mark.parametrize("grad_mode", ["full", "reference"])
-def test_streaming_step_in_bf16_storage_against_the_oracle(batch_4096, grad_mode):
+def test_streaming_step_in_bf16_storage_against_the_oracle(batch_4096, grad_mode, storage):
+    """``bf16``: the activations; ``bf16+grads``: also the gradient streams between kernels (dpool, dy, dS, dXs), which
+    the restated oracle does NOT round -- so for that mode the gradient bounds against it are looser by the rounding of
+    three to five gradient matrices (2^-9 each, averaged out in the weight gradients)."""
     packed, y, w, tasks, state = batch_4096
-    native = _native_step(packed, y, w, tasks, grad_mode, state, "bf16")
+    native = _native_step(packed, y, w, tasks, grad_mode, state, storage)
     same = _deviations(native, _oracle_step(packed, y, w, tasks, grad_mode, state, bf16=True))
     plain = _deviations(native, _oracle_step(packed, y, w, tasks, grad_mode, state, bf16=False))
     fp32 = _deviations(_native_step(packed, y, w, tasks, grad_mode, state, "fp32"),
                        _oracle_step(packed, y, w, tasks, grad_mode, state, bf16=False))
-    print(grad_mode, "| bf16 storage vs the oracle with the same rounding:", _fmt(same))
-    print(grad_mode, "| bf16 storage vs the float32 oracle:              ", _fmt(plain))
-    print(grad_mode, "| fp32 storage vs the float32 oracle:              ", _fmt(fp32))
+    print(grad_mode, storage, "| vs the oracle with the same rounding:", _fmt(same))
+    print(grad_mode, storage, "| vs the float32 oracle:              ", _fmt(plain))
+    print(grad_mode, "fp32 storage | vs the float32 oracle:      ", _fmt(fp32))
     assert fp32["loss"] != plain["loss"]  # the mode is really on
     # (1) WHERE the kernels round: against the oracle with the same rounding restated the step is several times closer
     # than against plain float32 -- a kernel that rounded somewhere else, twice, or by truncation would not be
     assert same["fp_mean"] <= 0.35 * plain["fp_mean"] and same["logits_mean"] <= 0.35 * plain["logits_mean"], (same, plain)
-    assert same["grad_l2"] <= 0.5 * plain["grad_l2"], (same, plain)
+    assert same["grad_l2"] <= (0.5 if storage == "bf16" else 0.8) * plain["grad_l2"], (same, plain)
     assert same["loss"] <= 1e-4
     # (2) against float32: bf16 resolution.  A stored matrix carries 2^-9 relative rounding, five of them lie between
     # the input and the loss; the loss and the gradient vector average it out, single fingerprint entries do not
@@ -176,7 +180,7 @@ def test_streaming_fit_in_bf16_storage_follows_fp32():
     y, w = synthetic_labels(n, tasks, "classification", 23, pos_rate=0.3)
     state = O.init_state(O.ModelConfig(tasks, batch_size=B), 5)
     runs = {}
-    for storage in ("fp32", "bf16"):
+    for storage in ("fp32", "bf16", "bf16+grads"):
         model = dc.models.torch_models.GraphConvModel(tasks, number_input_features=[75, 64], batch_size=B, device=DEV,
                                                       grad_mode="full", learning_rate=1e-3, activation_storage=storage,
                                                       log_frequency=1)
@@ -188,11 +192,13 @@ def test_streaming_fit_in_bf16_storage_follows_fp32():
         probs = model.predict(ds)
         runs[storage] = (np.array(losses), probs)
     l32, p32 = runs["fp32"]
-    l16, p16 = runs["bf16"]
-    print("fit losses fp32", l32, "bf16", l16, "max |dprob| %.3f mean %.4f" % (np.abs(p16 - p32).max(), np.abs(p16 - p32).mean()))
-    assert len(l32) == len(l16) > 0 and not np.array_equal(l32, l16)
-    assert np.allclose(l16, l32, rtol=2e-2), (l16, l32)
-    assert np.abs(p16 - p32).mean() < 2e-2
+    for storage in ("bf16", "bf16+grads"):
+        l16, p16 = runs[storage]
+        print("fit losses fp32", l32, storage, l16, "max |dprob| %.3f mean %.4f" % (np.abs(p16 - p32).max(), np.abs(p16 - p32).mean()))
+        assert len(l32) == len(l16) > 0 and not np.array_equal(l32, l16)
+        assert np.allclose(l16, l32, rtol=2e-2), (storage, l16, l32)
+        assert np.abs(p16 - p32).mean() < 2e-2
+    assert not np.array_equal(runs["bf16"][0], runs["bf16+grads"][0])  # the second mode is really another one
 
 
 @pytest.mark.parametrize("run", ["b64", "b100"])
