@@ -722,6 +722,33 @@ def main():
         out["config"]["fit_molecules_per_s_batch_%d_atom_codes" % args.batch] = round(
             fit_epochs * big.n_mols / (time.perf_counter() - t1), 1)
 
+    if not args.profile_only and args.scaling == "weak" and not (args.batch == 8192 and args.tasks == 128):
+        # BASELINE config 3's per-GPU shape beside the Tox21 headline: 8 192 molecules x 128 two-class tasks per rank,
+        # same step (fwd + bwd + Adam, one flat all-reduce per step for N > 1), same timing rules (collective leg)
+        import copy
+        pa = copy.copy(args)
+        pa.tasks = 128
+        pm, pb, pl, pw = make_workload(pa, rank, device, 8192, args.storage)
+        if world > 1:
+            from deepchem_amd.dist import shard_model
+            shard_model(pm)
+        run_steps(pm, pb, pl, pw, 3)
+        barrier()
+        t1 = time.perf_counter()
+        p_steps = 20
+        run_steps(pm, pb, pl, pw, p_steps)
+        barrier()
+        p_wall = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([p_wall], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            p_wall = float(t.item())
+        if rank == 0:
+            out["config"]["pcba_shape"] = {
+                "workload": "PCBA-like: 8 192 synthetic molecules x 128 binary tasks per GPU, GraphConvModel [64,64]/dense 128",
+                "molecules_per_s": round(8192 * world * p_steps / p_wall, 1), "ms_per_step": round(p_wall / p_steps * 1e3, 4),
+                "steps": p_steps, "n_gpus": world, "grad_mode": args.grad_mode}
+        del pm, pb, pl, pw
     if rank == 0 and world == 1 and not args.profile_only and args.gemm_mode == "fast":
         # the same step on the exact-fp32 matrix-core chain (the arithmetic whose trajectories track the reference)
         deepchem_amd.set_gemm_mode("exact")

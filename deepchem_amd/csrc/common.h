@@ -186,13 +186,20 @@ int fwd_fused_gemm(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
                    hipStream_t sm, float* d_wimg_scratch = nullptr);
 
 // head_bwd.hip: loss + d logits + task-head gradients + tanh' of the readout + the dense BatchNorm's backward sums in
-// one kernel over the molecules; GCMI_ERR_UNSUPPORTED = shape not covered (256-column fingerprint, <= 32 outputs)
+// one kernel over the molecules (<= 32 outputs), or two on the matrix cores (33..256 outputs, d_dl_scratch = n_mols x
+// outputs floats); GCMI_ERR_UNSUPPORTED = shape not covered (256-column fingerprint)
 int head_bwd_fused(int32_t kind, const float* d_logits, const float* d_labels, const float* d_weights, int64_t n_rows,
                    int32_t n_tasks, int32_t n_classes, int64_t n_mols, const float* d_fp, int64_t ldfp,
                    const float* d_w, float* d_dw, float* d_db, float* d_g2, int64_t ldg2, double* d_loss_acc,
                    const int32_t* d_runs, int32_t n_deg, const int32_t* d_arg, const float* d_rawsum,
-                   const float* d_mean, const float* d_invstd, double* d_sums, int32_t dense_width, hipStream_t st);
-int loss_finalize_impl(double* d_acc, float inv_count, float* d_loss, void* stream);
+                   const float* d_mean, const float* d_invstd, double* d_sums, int32_t dense_width, hipStream_t st,
+                   float* d_dl_scratch = nullptr);
+// ... and the forward head with 33..256 outputs (one segment, 256-column rows, nn.Linear weight, no activation)
+int head_fwd_wide(const float* d_in, int64_t ldin, int64_t n_rows, int32_t k, const float* d_w, const float* d_bias,
+                  int32_t n_out, int32_t act, float* d_out, int64_t ldo, hipStream_t st);
+// replicas of the loss accumulator (doubles) that head_bwd_fused adds into; loss_finalize_impl sums and clears them
+constexpr int kLossRep = 16;
+int loss_finalize_impl(double* d_acc, float inv_count, float* d_loss, void* stream, int n_rep = 1);
 
 // accumulator replicas of the BatchNorm column sums (same-address fp64 atomics serialise); scratch layout in
 // doubles: [0, 2F) backward coefficient vectors, then kBnReplicas blocks of [sum(F) | sum of squares(F)]

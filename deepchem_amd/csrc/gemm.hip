@@ -644,6 +644,13 @@ int gcmi_seg_gemm(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_en
   const bool exact = gemm_exact_mode();
   // GCMI_GEMM_V4=0 disables the LDS-staged split-bf16 kernel (default path)
   static const bool v4 = !(getenv("GCMI_GEMM_V4") && atoi(getenv("GCMI_GEMM_V4")) == 0);
+  if (!exact && n_seg == 1 && d_a2 == nullptr && trans_w && seg_begin[0] == 0 && w1_off[0] >= 0) {
+    // the task head with more than 32 outputs (head_bwd.hip)
+    const int rc = head_fwd_wide(d_a1, lda1, seg_end[0], k1, d_w1 + w1_off[0],
+                                 (d_bias && bias_off && bias_off[0] >= 0) ? d_bias + bias_off[0] : nullptr, n_out, act, d_out,
+                                 ldo, sm);
+    if (rc != GCMI_ERR_UNSUPPORTED) return rc;
+  }
   if (v4 && !v3 && !exact) {
     const int rc = launch_seg_gemm4(n_seg, seg_begin, seg_end, d_a1, lda1, k1, d_w1, w1_off, d_a2, lda2, k2,
                                     d_w2, w2_off, d_bias, bias_off, n_out, trans_w, act, d_out, ldo, sm);

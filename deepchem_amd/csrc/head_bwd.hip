@@ -13,6 +13,7 @@
 #include <math.h>
 
 #include "common.h"
+#include "split_bf16.h"
 
 namespace gcmi {
 
@@ -195,15 +196,570 @@ __global__ void __launch_bounds__(kHB) head_bwd_kernel(HeadArgs a) {
   }
 }
 
-// GCMI_ERR_UNSUPPORTED: other widths than a 256-column fingerprint, more than 32 task outputs
+// ---------------------------------------------------------------- more than 32 task outputs (PCBA: 128 tasks x 2)
+// With up to 256 outputs the two head products are real matrix products (8 192 x 256 x 256 at PCBA's per-GPU batch)
+// and go to the matrix cores in the arithmetic of every other product of the library (three-way bf16 split, six
+// products per term, fp32 accumulation).  Two kernels:
+//   head_bwd_wide_kernel   one workgroup per 32 molecules: loss and d logits (split once, pieces in LDS; fp32 copy to
+//                          global for the weight gradient), d fingerprint = d logits . W on the matrix cores with W's
+//                          fragments split on the way in from L2, then from the accumulators the tanh derivative, the
+//                          rows of g2 and the dense BatchNorm's backward sums, as head_bwd_kernel above;
+//   head_wgrad_wide_kernel dW = d logits^T . fingerprint: 64 x 64 blocks of dW times slabs of molecules, both
+//                          operands read column-wise (a lane = a column: coalesced rows), split in registers.
+// They replace loss_kernel + wgrad_kernel + seg_gemm4_kernel + readout_grad_prep + readout_bn_sums (126 us at 8 192
+// molecules x 256 outputs).
+constexpr int kWTC = 256;        // most task outputs
+constexpr int kWP = kWTC + 8;    // LDS pitch of a row of d logits pieces (bf16): 528 bytes, 16-byte reads conflict-free
+
+__device__ __forceinline__ f32x16 six_products(const u32x4 (&r)[3], const Frag3& c, f32x16 acc) {
+  // rows fragment r (lane = row), columns fragment c (lane = column); small terms first
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(r[2]), as_bf16x8(c.p[0]), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(r[0]), as_bf16x8(c.p[2]), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(r[1]), as_bf16x8(c.p[1]), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(r[1]), as_bf16x8(c.p[0]), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(r[0]), as_bf16x8(c.p[1]), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(r[0]), as_bf16x8(c.p[0]), acc, 0, 0, 0);
+  return acc;
+}
+
+#ifdef GCMI_HEAD_DIAG_BUILD  // diagnostic build only (tools/head_diag.sh): phase clocks of workgroup 0, thread 0
+__device__ unsigned long long g_head_clk[3][8];
+#define HD_BEGIN() unsigned long long hd_t0 = 0, hd_t1 = 0; const bool hd_on = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0; \
+  if (hd_on) hd_t0 = __builtin_amdgcn_s_memtime()
+#define HD_T(kern, k) do { if (hd_on) { hd_t1 = __builtin_amdgcn_s_memtime(); g_head_clk[kern][k] = hd_t1 - hd_t0; hd_t0 = hd_t1; } } while (0)
+#else
+#define HD_BEGIN() do { } while (0)
+#define HD_T(kern, k) do { } while (0)
+#endif
+
+constexpr int kWT = 512;         // threads of the wide kernels: eight waves, one 32-column tile of the fingerprint each
+
+// (the wide kernel spreads its loss over kLossRep accumulators, common.h: same-address fp64 atomics serialise at ~14 ns
+// each, and 256 workgroups on one address -- plus 256 on each entry of the bias gradient -- were 7 us of tail)
+
+__global__ void __launch_bounds__(kWT) head_bwd_wide_kernel(HeadArgs a, float* __restrict__ dl_out) {
+  __shared__ __attribute__((aligned(16))) unsigned short dlp[3][kHM][kWP];
+  __shared__ int n_s[kHM];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  constexpr int D = kHB / 2;
+  const int TC = a.tc;
+  const int TCP = (TC + 15) & ~15;
+  const int nks = TCP / 16;
+  const int64_t c0 = (int64_t)blockIdx.x * kHM;
+  const int nm = (int)((a.n_mols - c0) < kHM ? (a.n_mols - c0) : kHM);
+  HD_BEGIN();
+  // the padding columns of the pieces
+  for (int i = tid; i < kHM * (TCP - TC); i += kWT) {
+    const int m = i / (TCP - TC), c = TC + i - m * (TCP - TC);
+    dlp[0][m][c] = dlp[1][m][c] = dlp[2][m][c] = 0;
+  }
+  // ---- phase 1: d logits of the 32 molecules (rows beyond n_rows: padding molecules, no loss; the expressions of
+  // head_bwd_kernel).  A wave takes four molecules, a lane the tasks lane, lane + 64, ...: no division, and the inputs
+  // of eight (molecule, task) items are in flight before the first is worked on.  (The first version mapped items to
+  // threads by division and wrote every d logit with its own split and stores: 35 000 cycles of VALU work.)
+  double loss_local = 0.0;
+  const int C = a.n_classes;
+  // this wave's fragments of W (TC x 256, lane = fingerprint column k, eight consecutive outputs per k-step; every load
+  // instruction is two whole 128-byte rows): half of them issued behind phase 1's input loads and ahead of its
+  // arithmetic, the other half behind phase 1 -- a load per k-step would run the product loop at L2 latency
+  const int k = wave * 32 + l31, f = k & (D - 1);
+  const int part = wave >> 2;  // 0: the sum half of the fingerprint, 1: the max half
+  float wr[kWTC / 16][8];
+  auto load_w = [&](const int ks0, const int ks1) {
+    const float* wcol = a.w + k;
+#pragma unroll
+    for (int ks = 0; ks < kWTC / 16; ++ks) {
+      if (ks >= ks0 && ks < ks1 && ks < nks) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int tc = ks * 16 + 8 * half + i;
+          const float x = wcol[(tc < TC ? tc : TC - 1) * kHB];
+          wr[ks][i] = tc < TC ? x : 0.f;
+        }
+      }
+    }
+  };
+  if (a.kind == 1 || C == 2) {
+    const int E = a.kind == 0 ? 2 : 1;  // outputs per task
+    auto round = [&](const int t0, const bool first_round) {
+      float x0[8], x1[8], y0[8], y1[8], wv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int m = wave * 4 + (u & 3), t = t0 + 64 * (u >> 2);
+        const int64_t b = c0 + m;
+        const bool live = t < a.n_tasks && m < nm && b < a.n_rows;
+        const int64_t item = live ? b * a.n_tasks + t : 0;
+        wv[u] = a.weights ? a.weights[item] : 1.f;
+        if (a.kind == 0) {
+          const float2 xv = *reinterpret_cast<const float2*>(a.logits + item * 2);
+          const float2 yv = *reinterpret_cast<const float2*>(a.labels + item * 2);
+          x0[u] = xv.x; x1[u] = xv.y; y0[u] = yv.x; y1[u] = yv.y;
+        } else {
+          x0[u] = a.logits[item]; y0[u] = a.labels[item];
+          x1[u] = y1[u] = 0.f;
+        }
+      }
+      if (first_round) load_w(0, kWTC / 32);  // the first half of the fragments; the second half follows phase 1 (registers)
+      if (first_round) { HD_T(0, 0); }
+      if (first_round) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        HD_T(0, 1);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int m = wave * 4 + (u & 3), t = t0 + 64 * (u >> 2);
+        if (t >= a.n_tasks) continue;
+        const bool live = m < nm && c0 + m < a.n_rows;
+        const float w = live ? wv[u] : 1.f;
+        float d0 = 0.f, d1 = 0.f;
+        if (a.kind == 0) {
+          if (live) {
+            // two-class softmax cross entropy with one exponential and one logarithm: with d = x_other - x_max <= 0,
+            // log p_max = -log(1 + e^d), log p_other = d - log(1 + e^d), p_max = 1 / (1 + e^d), p_other = e^d / (1 + e^d)
+            // (the general loop below, five transcendental calls per item, was 12 us of VALU work at 2 M items)
+            const bool first = x0[u] >= x1[u];
+            const float dd = first ? x1[u] - x0[u] : x0[u] - x1[u];
+            const float e = expf(dd);
+            const float se = 1.f + e;
+            const float lse = logf(se);
+            const float inv = 1.f / se;
+            const float lp_max = -lse, lp_oth = dd - lse;
+            const float p_max = inv, p_oth = e * inv;
+            const float lp0 = first ? lp_max : lp_oth, lp1 = first ? lp_oth : lp_max;
+            const float p0 = first ? p_max : p_oth, p1 = first ? p_oth : p_max;
+            const float ysum = y0[u] + y1[u];
+            const float l = -(y0[u] * lp0) - y1[u] * lp1;
+            d0 = w * (p0 * ysum - y0[u]) * a.inv_count;
+            d1 = w * (p1 * ysum - y1[u]) * a.inv_count;
+            loss_local += (double)(w * l);
+          }
+        } else if (live) {
+          const float dlt = x0[u] - y0[u];
+          loss_local += (double)(w * dlt * dlt);
+          d0 = 2.f * dlt * w * a.inv_count;
+        }
+        unsigned p1, p2, p3;
+        split3_pair(d0, d1, p1, p2, p3);  // low half = d0
+        if (E == 2) {
+          *reinterpret_cast<unsigned*>(&dlp[0][m][2 * t]) = p1;
+          *reinterpret_cast<unsigned*>(&dlp[1][m][2 * t]) = p2;
+          *reinterpret_cast<unsigned*>(&dlp[2][m][2 * t]) = p3;
+          if (m < nm) *reinterpret_cast<float2*>(dl_out + (c0 + m) * TC + 2 * t) = make_float2(d0, d1);
+        } else {
+          dlp[0][m][t] = (unsigned short)p1;
+          dlp[1][m][t] = (unsigned short)p2;
+          dlp[2][m][t] = (unsigned short)p3;
+          if (m < nm) dl_out[(c0 + m) * TC + t] = d0;
+        }
+      }
+    };
+    round(lane, true);
+    HD_T(0, 2);
+    for (int t0 = lane + 128; t0 < a.n_tasks; t0 += 128) round(t0, false);
+  } else {
+    auto put = [&](int m, int col, float v, bool in_batch) {
+      unsigned p1, p2, p3;
+      split3(v, p1, p2, p3);
+      dlp[0][m][col] = (unsigned short)(p1 >> 16);
+      dlp[1][m][col] = (unsigned short)(p2 >> 16);
+      dlp[2][m][col] = (unsigned short)(p3 >> 16);
+      if (in_batch) dl_out[(c0 + m) * TC + col] = v;
+    };
+    for (int it = tid; it < kHM * a.n_tasks; it += kWT) {
+      const int m = it / a.n_tasks, t = it - m * a.n_tasks;
+      const int64_t b = c0 + m;
+      const bool live = m < nm && b < a.n_rows;
+      const int64_t item = b * a.n_tasks + t;
+      const float w = (live && a.weights) ? a.weights[item] : 1.f;
+      if (live) {
+        const float* x = a.logits + item * C;
+        const float* y = a.labels + item * C;
+        float mx = -INFINITY;
+        for (int c = 0; c < C; ++c) mx = fmaxf(mx, x[c]);
+        float se = 0.f, ysum = 0.f;
+        for (int c = 0; c < C; ++c) {
+          se += expf(x[c] - mx);
+          ysum += y[c];
+        }
+        const float lse = logf(se);
+        float l = 0.f;
+        for (int c = 0; c < C; ++c) {
+          const float logp = x[c] - mx - lse;
+          const float p = expf(logp);
+          l -= y[c] * logp;
+          put(m, t * C + c, w * (p * ysum - y[c]) * a.inv_count, true);
+        }
+        loss_local += (double)(w * l);
+      } else {
+        for (int c = 0; c < C; ++c) put(m, t * C + c, 0.f, m < nm);
+      }
+    }
+  }
+  if (a.sums != nullptr && tid < kHM) {
+    int n = 0;
+    if (tid < nm) {
+      const int32_t* r = a.runs + ((c0 + tid) * a.n_deg) * 2;
+      for (int d = 0; d < a.n_deg; ++d) n += r[2 * d + 1] - r[2 * d];
+    }
+    n_s[tid] = n;
+  }
+  HD_T(0, 3);
+  if (!(a.kind == 1 || C == 2)) load_w(0, kWTC / 32);
+  load_w(kWTC / 32, kWTC / 16);
+  // ---- what phase 3 reads per molecule
+  float fv[16], rsv[16];
+  int av[16];
+  {
+    const int mb = nm - 1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int64_t b = c0 + (m < nm ? m : mb);
+      fv[r] = a.fp[b * a.ldfp + k];
+      rsv[r] = 0.f;
+      av[r] = 0;
+      if (a.sums != nullptr) {
+        rsv[r] = a.rawsum[b * 2 * D + k];                  // [row sums | arg-max row's value]
+        if (part == 1) av[r] = a.arg[b * D + f];
+      }
+    }
+  }
+  __syncthreads();
+  HD_T(0, 4);
+  // ---- phase 2: d fingerprint[32 x 256] = d logits[32 x TC] . W[TC x 256], this wave's 32 columns
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < kWTC / 16; ++ks) {
+    if (ks < nks) {
+      u32x4 r[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) r[p] = *reinterpret_cast<const u32x4*>(&dlp[p][l31][ks * 16 + 8 * half]);
+      acc = six_products(r, split_frag(wr[ks]), acc);
+    }
+  }
+  HD_T(0, 5);
+  // ---- phase 3: from the accumulators (lane = column, registers = molecules) the tanh derivative, g2 and the sums
+  {
+    const double mu = a.sums ? (double)a.mean[f] : 0.0, is = a.sums ? (double)a.invstd[f] : 0.0;
+    double t1 = 0.0, t2 = 0.0;
+    float* grow = a.g2 + c0 * a.ldg2 + k;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (m < nm) {
+        const float g = acc[r] * (1.f - fv[r] * fv[r]);
+        grow[m * a.ldg2] = g;
+        if (a.sums != nullptr) {
+          if (part == 0) {
+            const double n = (double)n_s[m];
+            const double xs = ((double)rsv[r] - n * mu) * is;
+            t1 += n * (double)g;
+            t2 += (double)g * xs;
+          } else if (av[r] >= 0) {
+            const double xa = ((double)rsv[r] - mu) * is;
+            t1 += (double)g;
+            t2 += (double)g * xa;
+          }
+        }
+      }
+    }
+    if (a.sums != nullptr) {
+      t1 += __shfl_xor(t1, 32);
+      t2 += __shfl_xor(t2, 32);
+      if (half == 0) {
+        double* rep = a.sums + (size_t)2 * D * (1 + (blockIdx.x % kBnReplicas));
+        atomicAdd(rep + f, t1);
+        atomicAdd(rep + D + f, t2);
+      }
+    }
+  }
+  HD_T(0, 6);
+  // ---- this wave's loss into one of the replicas (the bias gradient is the weight-gradient kernel's: it reads d logits)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) loss_local += __shfl_xor(loss_local, o);
+  if (lane == 0 && loss_local != 0.0) atomicAdd(a.loss_acc + ((blockIdx.x * (kWT / 64) + wave) % kLossRep), loss_local);
+  HD_T(0, 7);
+}
+
+// dW[tc][k] += sum over the slab's molecules of dl[b][tc] * fp[b][k], db[tc] += sum of dl[b][tc]; grid (slabs, tc blocks
+// of 64, 4 column blocks).  Both operands are read column-wise (lane = a column, eight consecutive molecules per k-step:
+// every load instruction is two whole 128-byte rows) and split in registers; three workgroups share a CU, so one's
+// loads overlap another's products.  Addresses are a pointer per operand and constant multiples of the row pitch: with
+// 64-bit index arithmetic per load the loop was bound by the address VALU work (12 700 cycles per 32 molecules).
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
+head_wgrad_wide_kernel(const float* __restrict__ dl, int TC, const float* __restrict__ fp, int ldfp, int64_t n_mols,
+                       int rows_per_slab, float* __restrict__ dw, float* __restrict__ db) {
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int tc = blockIdx.y * 64 + (wave & 1) * 32 + l31;
+  const int tcc = tc < TC ? tc : TC - 1;
+  const int k = blockIdx.z * 64 + (wave >> 1) * 32 + l31;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_slab;
+  const int64_t r1 = (r0 + rows_per_slab) < n_mols ? (r0 + rows_per_slab) : n_mols;
+  if ((blockIdx.y * 64 + (wave & 1) * 32) >= TC) return;  // (a whole wave: no barrier below)
+  const bool bias_wave = db != nullptr && blockIdx.z == 0 && (wave >> 1) == 0;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float dbacc = 0.f;
+  HD_BEGIN();
+  const float* pa = dl + (r0 + 8 * half) * TC + tcc;
+  const float* pb = fp + (r0 + 8 * half) * ldfp + k;
+  const float keep = tc < TC ? 1.f : 0.f;
+  int64_t b0 = r0;
+  // two k-steps (32 molecules) per round; the next round's 32 loads per lane are in flight during this round's products
+  float ca[2][8], cb[2][8], na[2][8], nb[2][8];
+  auto load_round = [&](float (&va)[2][8], float (&vb)[2][8]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        va[s][i] = pa[(16 * s + i) * TC];
+        vb[s][i] = pb[(16 * s + i) * ldfp];
+      }
+    pa += 32 * TC;
+    pb += 32 * ldfp;
+  };
+  if (b0 + 32 <= r1) load_round(ca, cb);
+  for (; b0 + 32 <= r1; b0 += 32) {
+    if (b0 + 64 <= r1) load_round(na, nb);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ca[s][i] *= keep;
+      if (bias_wave) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dbacc += ca[s][i];
+      }
+      const Frag3 fa = split_frag(ca[s]);
+      const Frag3 fb = split_frag(cb[s]);
+      const u32x4 r[3] = {fa.p[0], fa.p[1], fa.p[2]};
+      acc = six_products(r, fb, acc);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        ca[s][i] = na[s][i];
+        cb[s][i] = nb[s][i];
+      }
+  }
+  if (b0 < r1) {  // the last slab's ragged end: clamped addresses, zeroed values
+    float va[2][8], vb[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int64_t b = b0 + 16 * s + 8 * half + i;
+        const int64_t bc = b < r1 ? b : r1 - 1;
+        const float x = dl[bc * TC + tcc], y = fp[bc * ldfp + k];
+        va[s][i] = b < r1 ? x * keep : 0.f;
+        vb[s][i] = b < r1 ? y : 0.f;
+      }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (bias_wave) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dbacc += va[s][i];
+      }
+      const Frag3 fa = split_frag(va[s]);
+      const Frag3 fb = split_frag(vb[s]);
+      const u32x4 r[3] = {fa.p[0], fa.p[1], fa.p[2]};
+      acc = six_products(r, fb, acc);
+    }
+  }
+  HD_T(1, 0);
+  const int row0 = blockIdx.y * 64 + (wave & 1) * 32 + 4 * half;
+  float* dcol = dw + k;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = row0 + (r & 3) + 8 * (r >> 2);
+    if (row < TC && acc[r] != 0.f) atomicAdd(dcol + row * kHB, acc[r]);
+  }
+  if (bias_wave) {
+    dbacc += __shfl_xor(dbacc, 32);
+    if (half == 0 && tc < TC && dbacc != 0.f) atomicAdd(db + tc, dbacc);
+  }
+  HD_T(1, 1);
+}
+
+// ---------------------------------------------------------------- forward head with more than 32 outputs
+// out[rows x TC] = fingerprint[rows x 256] . W^T + b (graphconvmodel.py:177-179): one workgroup per 32 rows -- 256
+// workgroups at PCBA's 8 192 molecules per GPU, one per CU -- eight waves, a 32-column tile of the output each.  The 32
+// rows are split once into their three bf16 pieces in LDS.  The weights (TC x 256, nn.Linear) pass through LDS as well,
+// one k-step (16 contraction columns) at a time through two buffers: read 16 bytes per lane along the rows of W (every
+// thread's pieces of all chunks in flight from the start), split once per workgroup, and picked up by the waves as
+// 16-byte fragments.  (Fragments straight from global -- a lane = an output
+// column = a row of W, 32 bytes per k-step -- are 64 different lines per load instruction: 22 000 cycles of a 35 000
+// cycle kernel went into that.)
+constexpr int kFWC = 16;          // contraction columns per weight chunk: one k-step
+constexpr int kFWP = kFWC + 8;    // LDS pitch of a weight row's pieces (bf16): 48 bytes, 16-byte reads conflict-free
+
+__global__ void __launch_bounds__(kWT) head_fwd_wide_kernel(const float* __restrict__ in, int64_t ldin, int64_t n_rows,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            int TC, float* __restrict__ out, int64_t ldo) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char head_lds[];
+  typedef unsigned short (*ApT)[kHM][kWP];
+  typedef unsigned short (*WpT)[3][kWTC][kFWP];
+  ApT ap = reinterpret_cast<ApT>(head_lds);                                             // [3][32][264]
+  WpT wp = reinterpret_cast<WpT>(head_lds + sizeof(unsigned short) * 3 * kHM * kWP);   // [2][3][256][24]: two chunks
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int64_t row0 = (int64_t)blockIdx.x * kHM;
+  const int valid = (int)((n_rows - row0) < kHM ? (n_rows - row0) : kHM);
+  const int n = wave * 32 + l31;                 // this lane's output column
+  const bool tile = wave * 32 < TC;              // (wave-uniform)
+  HD_BEGIN();
+  const float bv = (bias != nullptr && n < TC) ? bias[n] : 0.f;
+  // a chunk of W: 256 rows x 16 columns = 1 024 float4, two per thread; thread -> (row, 16-byte piece), four threads per
+  // 64-byte half line (the other half is the next chunk's: an L1 hit)
+  constexpr int WPT = kWTC * (kFWC / 4) / kWT;
+  constexpr int NCH = kHB / kFWC;
+  float4 wreg[NCH][WPT];
+  bool wok[WPT];
+#pragma unroll
+  for (int p = 0; p < WPT; ++p) wok[p] = ((tid + p * kWT) >> 2) < TC;
+  auto load_chunks = [&]() {  // this thread's pieces of ALL chunks: one exposure of the L2 latency
+#pragma unroll
+    for (int p = 0; p < WPT; ++p) {
+      const int slot = tid + p * kWT;
+      const int r = slot >> 2, q = slot & 3;
+      const float* src = w + (r < TC ? r : TC - 1) * kHB + 4 * q;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) wreg[c][p] = *reinterpret_cast<const float4*>(src + c * kFWC);
+    }
+  };
+  auto store_chunk = [&](int c) {
+#pragma unroll
+    for (int p = 0; p < WPT; ++p) {
+      const int slot = tid + p * kWT;
+      const int r = slot >> 2, q = slot & 3;
+      float4 v = wreg[c][p];
+      if (!wok[p]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      unsigned a1, a2, a3, b1, b2, b3;
+      split3_pair(v.x, v.y, a1, a2, a3);
+      split3_pair(v.z, v.w, b1, b2, b3);
+      *reinterpret_cast<uint2*>(&wp[c & 1][0][r][4 * q]) = make_uint2(a1, b1);
+      *reinterpret_cast<uint2*>(&wp[c & 1][1][r][4 * q]) = make_uint2(a2, b2);
+      *reinterpret_cast<uint2*>(&wp[c & 1][2][r][4 * q]) = make_uint2(a3, b3);
+    }
+  };
+  // the rows first (their loads return first), the weights behind them
+  float4 ain[kHM * (kHB / 4) / kWT];
+#pragma unroll
+  for (int p = 0; p < kHM * (kHB / 4) / kWT; ++p) {
+    const int slot = tid + p * kWT;
+    const int r = slot >> 6, q = slot & 63;
+    ain[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < valid) ain[p] = *reinterpret_cast<const float4*>(in + (row0 + r) * ldin + 4 * q);
+  }
+  load_chunks();
+#pragma unroll
+  for (int p = 0; p < kHM * (kHB / 4) / kWT; ++p) {
+    const int slot = tid + p * kWT;
+    const int r = slot >> 6, q = slot & 63;
+    unsigned a1, a2, a3, b1, b2, b3;
+    split3_pair(ain[p].x, ain[p].y, a1, a2, a3);
+    split3_pair(ain[p].z, ain[p].w, b1, b2, b3);
+    *reinterpret_cast<uint2*>(&ap[0][r][4 * q]) = make_uint2(a1, b1);
+    *reinterpret_cast<uint2*>(&ap[1][r][4 * q]) = make_uint2(a2, b2);
+    *reinterpret_cast<uint2*>(&ap[2][r][4 * q]) = make_uint2(a3, b3);
+  }
+  store_chunk(0);
+  __syncthreads();
+  HD_T(2, 0);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // one barrier per k-step: while a wave multiplies chunk c, the others split chunk c + 1 into the other buffer
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if (c + 1 < NCH) store_chunk(c + 1);
+    if (tile) {
+      u32x4 r[3];
+      Frag3 fw;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        r[p] = *reinterpret_cast<const u32x4*>(&ap[p][l31][c * kFWC + 8 * half]);
+        fw.p[p] = *reinterpret_cast<const u32x4*>(&wp[c & 1][p][n][8 * half]);
+      }
+      acc = six_products(r, fw, acc);
+    }
+    __syncthreads();
+  }
+  HD_T(2, 1);
+  if (tile && n < TC) {
+    float* ocol = out + row0 * ldo + n;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (m < valid) ocol[m * ldo] = acc[r] + bv;
+    }
+  }
+  HD_T(2, 2);
+}
+
+#ifdef GCMI_HEAD_DIAG_BUILD
+static void head_diag_print(const char* what, int kern, hipStream_t st) {
+  static int printed = 0;
+  unsigned long long h[3][8];
+  if (printed++ < 9 && hipStreamSynchronize(st) == hipSuccess &&
+      hipMemcpyFromSymbol(h, HIP_SYMBOL(g_head_clk), sizeof(h)) == hipSuccess)
+    fprintf(stderr, "head_diag %s: %llu %llu %llu %llu %llu %llu %llu %llu (s_memtime ticks per phase, workgroup 0)\n", what,
+            h[kern][0], h[kern][1], h[kern][2], h[kern][3], h[kern][4], h[kern][5], h[kern][6], h[kern][7]);
+}
+#define HD_PRINT(what, kern, st) head_diag_print(what, kern, st)
+#else
+#define HD_PRINT(what, kern, st) do { } while (0)
+#endif
+
+static bool head_wide_enabled() {
+  static const bool on = !(getenv("GCMI_HEAD_WIDE") && atoi(getenv("GCMI_HEAD_WIDE")) == 0);
+  return on && !gemm_exact_mode();
+}
+
+// GCMI_ERR_UNSUPPORTED: not (one segment of 256-column rows times an nn.Linear weight with 33..256 outputs, no activation)
+int head_fwd_wide(const float* d_in, int64_t ldin, int64_t n_rows, int32_t k, const float* d_w, const float* d_bias,
+                  int32_t n_out, int32_t act, float* d_out, int64_t ldo, hipStream_t st) {
+  if (!head_wide_enabled() || k != kHB || n_out <= kHT || n_out > kWTC || act != 0 || ldin % 4 != 0 || !aligned16(d_in) ||
+      !aligned16(d_w) || n_rows <= 0)
+    return GCMI_ERR_UNSUPPORTED;
+  constexpr size_t shmem = sizeof(unsigned short) * 3 * (kHM * kWP + 2 * kWTC * kFWP);
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(head_fwd_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)shmem) != hipSuccess) {
+      (void)hipGetLastError();
+      return GCMI_ERR_UNSUPPORTED;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(head_fwd_wide_kernel, dim3((unsigned)((n_rows + kHM - 1) / kHM)), dim3(kWT), shmem, st, d_in, ldin,
+                     n_rows, d_w, d_bias, n_out, d_out, ldo);
+  GCMI_CHECK_LAUNCH("head_fwd_wide");
+  HD_PRINT("fwd_wide", 2, st);
+  return GCMI_OK;
+}
+
+// GCMI_ERR_UNSUPPORTED: other widths than a 256-column fingerprint; more than 32 task outputs without d_dl_scratch
+// (n_mols x outputs floats) or more than 256
 int head_bwd_fused(int32_t kind, const float* d_logits, const float* d_labels, const float* d_weights, int64_t n_rows,
                    int32_t n_tasks, int32_t n_classes, int64_t n_mols, const float* d_fp, int64_t ldfp,
                    const float* d_w, float* d_dw, float* d_db, float* d_g2, int64_t ldg2, double* d_loss_acc,
                    const int32_t* d_runs, int32_t n_deg, const int32_t* d_arg, const float* d_rawsum,
-                   const float* d_mean, const float* d_invstd, double* d_sums, int32_t dense_width, hipStream_t st) {
+                   const float* d_mean, const float* d_invstd, double* d_sums, int32_t dense_width, hipStream_t st,
+                   float* d_dl_scratch) {
   static const bool on = !(getenv("GCMI_FUSED_HEAD") && atoi(getenv("GCMI_FUSED_HEAD")) == 0);
   const int tc = n_tasks * (kind == 0 ? n_classes : 1);
-  if (!on || !fused_bwd_enabled() || 2 * dense_width != kHB || tc > kHT || tc < 1 || n_mols <= 0) return GCMI_ERR_UNSUPPORTED;
+  if (!on || !fused_bwd_enabled() || 2 * dense_width != kHB || tc < 1 || n_mols <= 0) return GCMI_ERR_UNSUPPORTED;
+  const bool wide = tc > kHT;
+  if (wide && (tc > kWTC || d_dl_scratch == nullptr || !head_wide_enabled())) return GCMI_ERR_UNSUPPORTED;
   if (d_sums != nullptr && (!d_runs || !d_arg || !d_rawsum || !d_mean || !d_invstd)) return GCMI_ERR_UNSUPPORTED;
   HeadArgs a;
   memset(&a, 0, sizeof(a));
@@ -213,6 +769,23 @@ int head_bwd_fused(int32_t kind, const float* d_logits, const float* d_labels, c
   a.w = d_w; a.dw = d_dw; a.db = d_db; a.g2 = d_g2; a.ldg2 = ldg2; a.loss_acc = d_loss_acc;
   a.runs = d_runs; a.n_deg = n_deg; a.arg = d_arg; a.rawsum = d_rawsum; a.mean = d_mean; a.invstd = d_invstd;
   a.sums = d_sums;
+  if (wide) {
+    hipLaunchKernelGGL(head_bwd_wide_kernel, dim3((unsigned)((n_mols + kHM - 1) / kHM)), dim3(kWT), 0, st, a, d_dl_scratch);
+    GCMI_CHECK_LAUNCH("head_bwd_wide");
+    HD_PRINT("bwd_wide", 0, st);
+    // slabs: four workgroups per CU over all blocks of dW (all resident), never below 64 molecules
+    static const int wg_env = getenv("GCMI_HEAD_WGRAD_WGS") ? atoi(getenv("GCMI_HEAD_WGRAD_WGS")) : 1024;
+    const int blocks = ((tc + 63) / 64) * 4;
+    int64_t slabs = std::max<int64_t>(1, wg_env / blocks);
+    slabs = std::min<int64_t>(slabs, (n_mols + 63) / 64);
+    const int rps = (int)(((n_mols + slabs - 1) / slabs + 31) / 32 * 32);
+    slabs = (n_mols + rps - 1) / rps;
+    hipLaunchKernelGGL(head_wgrad_wide_kernel, dim3((unsigned)slabs, (unsigned)((tc + 63) / 64), 4), dim3(256), 0, st,
+                       d_dl_scratch, tc, d_fp, (int)ldfp, n_mols, rps, d_dw, d_db);
+    GCMI_CHECK_LAUNCH("head_wgrad_wide");
+    HD_PRINT("wgrad_wide", 1, st);
+    return GCMI_OK;
+  }
   // three workgroups are resident per CU (~130 VGPRs): 3 x 256 CUs, every workgroup in the first wave.  Measured at
   // 65 536 molecules: 256 workgroups 149 us, 512: 97, 768: 90, 1 024: 107, 2 048: 111.
   const int grid = (int)std::min<int64_t>(768, (n_mols + kHM - 1) / kHM);

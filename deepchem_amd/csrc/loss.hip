@@ -66,10 +66,14 @@ loss_kernel(int kind, const float* __restrict__ logits, const float* __restrict_
 }
 
 __global__ void loss_finalize_kernel(double* __restrict__ acc, float inv_count,
-                                     float* __restrict__ loss) {
+                                     float* __restrict__ loss, int n_rep) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    *loss = (float)(*acc * (double)inv_count);
-    *acc = 0.0;  // a scratch that starts clean stays clean
+    double t = 0.0;
+    for (int i = 0; i < n_rep; ++i) {
+      t += acc[i];
+      acc[i] = 0.0;  // a scratch that starts clean stays clean
+    }
+    *loss = (float)(t * (double)inv_count);
   }
 }
 
@@ -124,14 +128,15 @@ int loss_impl(int32_t kind, const float* d_logits, const float* d_labels, const 
                      d_logits, d_labels, d_weights, n_items, kind == 0 ? n_classes : 1, inv_count,
                      d_dlogits, kind == 0 ? d_probs : nullptr, d_acc);
   GCMI_CHECK_LAUNCH("loss");
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, d_acc, inv_count, d_loss);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, d_acc, inv_count, d_loss, 1);
   GCMI_CHECK_LAUNCH("loss_finalize");
   return GCMI_OK;
 }
 
-// *d_loss = *d_acc * inv_count, and the accumulator is left clean (head_bwd.hip adds to it itself)
-int loss_finalize_impl(double* d_acc, float inv_count, float* d_loss, void* stream) {
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_acc, inv_count, d_loss);
+// *d_loss = (sum of the n_rep accumulator replicas) * inv_count, and the accumulators are left clean (head_bwd.hip adds
+// to them itself)
+int loss_finalize_impl(double* d_acc, float inv_count, float* d_loss, void* stream, int n_rep) {
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_acc, inv_count, d_loss, n_rep);
   GCMI_CHECK_LAUNCH("loss_finalize");
   return GCMI_OK;
 }

@@ -104,7 +104,7 @@ static Ws carve(const gcmi_model_desc* m, int64_t N, int64_t B, int64_t ld_featu
   w.tE = take(N * kmax);
   w.dlogits = take(B * TC);
   for (int l = 0; l < L; ++l) w.dbsum[l] = take((int64_t)(m->max_deg + 1) * m->conv_width[l]);
-  w.lacc = take(4);
+  w.lacc = take(2 * kLossRep);
   w.acc = take(2 * GCMI_BN_ACC_DOUBLES(wmax));
   w.acc2 = take(2 * GCMI_BN_ACC_DOUBLES(wmax));  // pooled BatchNorm-backward sums of the block below (bwd_fused.hip)
   w.z_end = off;
@@ -360,10 +360,10 @@ static int model_loss_backward_h(const gcmi_model_desc* m, const gcmi_graph* g, 
                                   d_grads + m->off_head_b, ws + w.dfp, 2 * D, reinterpret_cast<double*>(ws + w.lacc),
                                   g->d_mol_runs, g->max_deg + 1, reinterpret_cast<const int32_t*>(ws + w.arg_r), ws + w.rsum,
                                   bnvL, bnvL + D, (N > 0 && g->d_mol_runs) ? reinterpret_cast<double*>(ws + w.acc) : nullptr,
-                                  D, st);
+                                  D, st, ws + w.dlogits);
     if (rc == GCMI_OK) {
       head_sums = N > 0 && g->d_mol_runs != nullptr;
-      RUN(loss_finalize_impl(reinterpret_cast<double*>(ws + w.lacc), 1.f / (float)(n_rows * m->n_tasks), io->d_loss, stream));
+      RUN(loss_finalize_impl(reinterpret_cast<double*>(ws + w.lacc), 1.f / (float)(n_rows * m->n_tasks), io->d_loss, stream, kLossRep));
     } else if (rc != GCMI_ERR_UNSUPPORTED) {
       return rc;
     } else {
@@ -665,12 +665,12 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
                                   reinterpret_cast<double*>(ws + w.lacc), g->d_mol_runs, g->max_deg + 1,
                                   reinterpret_cast<const int32_t*>(ws + w.arg_r), ws + w.rsum, bnvL, bnvL + D,
                                   (dense_fused_next && g->d_mol_runs) ? reinterpret_cast<double*>(ws + w.acc) : nullptr, D,
-                                  st);
+                                  st, ws + w.dlogits);
     if (rc == GCMI_OK) {
       head_done = true;
       head_sums = dense_fused_next && g->d_mol_runs != nullptr;
       RUN(loss_finalize_impl(reinterpret_cast<double*>(ws + w.lacc), 1.f / (float)(n_rows * m->n_tasks), io->d_loss,
-                             stream));
+                             stream, kLossRep));
     } else if (rc != GCMI_ERR_UNSUPPORTED) {
       return rc;
     }
