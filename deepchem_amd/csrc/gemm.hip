@@ -725,7 +725,10 @@ int gcmi_seg_gemm_wgrad(int32_t n_seg, const int32_t* seg_begin, const int32_t* 
   // CU for K <= 32 / 64 / 96 / 128 (registers); 1 880 slabs of 640 rows ran as 1.8 (2.4) rounds of workgroups.
   const int kt = (k + 31) / 32;
   const int64_t resident = 256 * (kt <= 2 ? 4 : (kt == 3 ? 3 : 2)) - n_seg;  // every segment may add a partial slab
-  int64_t slab = (total_rows + resident - 1) / resident;
+  // (more than four k-tiles: the split kernel runs ceil(kt / 4) chunks per slab, so slabs are that much longer)
+  static const bool wg3_on = !(getenv("GCMI_WGRAD_V3") && atoi(getenv("GCMI_WGRAD_V3")) == 0);
+  const int64_t chunks = (kt > 4 && wg3_on && !gemm_exact_mode()) ? (kt + 3) / 4 : 1;
+  int64_t slab = (total_rows * chunks + resident - 1) / resident;
   slab = ((slab + 63) / 64) * 64;
   if (slab < 256) slab = 256;
   if (slab > 4096) slab = 4096;
@@ -737,7 +740,7 @@ int gcmi_seg_gemm_wgrad(int32_t n_seg, const int32_t* seg_begin, const int32_t* 
     const int64_t floor_rows = floor_env >= 64 && floor_env % 64 == 0 ? floor_env : 256;
     const int nt_all = (n + 31) / 32;
     const int64_t col_groups = nt_all >= 3 ? (nt_all + 3) / 4 : 1;
-    while (slab > floor_rows && ((total_rows + slab - 1) / slab + n_seg - 1) * col_groups < 256) slab -= 64;
+    while (slab > floor_rows && ((total_rows + slab - 1) / slab + n_seg - 1) * col_groups * chunks < 256) slab -= 64;
   }
   st.slab_rows = (int32_t)slab;
   int64_t slabs = 0;

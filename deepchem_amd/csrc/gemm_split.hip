@@ -717,7 +717,7 @@ wgrad3_kernel(SlabTable st, const float* __restrict__ a, int64_t lda, int k, con
   int kcol[KT];
 #pragma unroll
   for (int t = 0; t < KT; ++t) {
-    kcol[t] = t * 32 + (lane & 31);
+    kcol[t] = blockIdx.z * (KT * 32) + t * 32 + (lane & 31);  // (grid.z: chunks of KT tiles when k > 128 columns)
     k_ok[t] = kcol[t] < k;
   }
   // 16 rows per step: this lane's rows r + 8*half .. + 7; clamped unconditional loads, zeroed by selects
@@ -811,13 +811,13 @@ wgrad3_kernel(SlabTable st, const float* __restrict__ a, int64_t lda, int k, con
           const int nc = nt * 32 + rix;
           if (nc < n && k_ok[t]) atomicAdd(dw + woff + (int64_t)nc * k + kcol[t], acc[t][reg]);
         } else {
-          const int kf = t * 32 + rix;
+          const int kf = blockIdx.z * (KT * 32) + t * 32 + rix;
           if (kf < k && n_ok) atomicAdd(dw + woff + (int64_t)kf * n + ncol, acc[t][reg]);
         }
       }
     }
   }
-  if (dbias != nullptr) {
+  if (dbias != nullptr && blockIdx.z == 0) {
     const int64_t boff = pick3(st.db_off, s);
     bsum += __shfl_xor(bsum, 32);
     if (half == 0 && n_ok && boff >= 0) atomicAdd(dbias + boff + ncol, bsum);
@@ -826,11 +826,15 @@ wgrad3_kernel(SlabTable st, const float* __restrict__ a, int64_t lda, int k, con
 
 int launch_wgrad3(const SlabTable& st, int slabs, const float* d_a, int64_t lda, int k, const float* d_g, int64_t ldg,
                   int n, float* d_dw, float* d_dbias, int trans_w, hipStream_t sm) {
-  const int KT = (k + 31) / 32;
-  if (KT > 4 || st.slab_rows % 64) return GCMI_ERR_UNSUPPORTED;  // wider K: the fp32 kernel's k-passes
+  const int KT_all = (k + 31) / 32;
+  if (st.slab_rows % 64) return GCMI_ERR_UNSUPPORTED;
+  // wider K (EdgeNetwork's 900 moment columns): chunks of four tiles in grid.z, every chunk re-reading g.  (They used
+  // to fall to the fp32 kernel's k-passes: four launches of 229 us each for 73 000 rows x 900 x 100.)
+  const int KT = KT_all > 4 ? 4 : KT_all;
+  const int chunks = (KT_all + KT - 1) / KT;
   const int NT = (n + 31) / 32;
   const int ntw = NT >= 3 ? 4 : NT;
-  dim3 grid((unsigned)slabs, (unsigned)((NT + ntw - 1) / ntw));
+  dim3 grid((unsigned)slabs, (unsigned)((NT + ntw - 1) / ntw), (unsigned)chunks);
   const int rev = next_sweep_direction();
 #define LAUNCH_W3(KK)                                                                               \
   do {                                                                                              \

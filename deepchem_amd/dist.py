@@ -80,7 +80,7 @@ class FlatGradArena:
     gradients of a step land side by side and the data-parallel exchange is ``FlatGradAllReduce.reduce_flat`` on the
     arena -- one collective, no copy in, no copy out.  (``GraphConvModel`` has its own arena in ``native.NativeNet``.)"""
 
-    def __init__(self, module: torch.nn.Module):
+    def __init__(self, module: torch.nn.Module, home_params: bool = False):
         ps = [p for p in module.parameters() if p.requires_grad]
         if not ps:
             raise ValueError("the module has no trainable parameters")
@@ -90,10 +90,28 @@ class FlatGradArena:
         sizes = [((p.numel() + 3) // 4) * 4 for p in ps]  # every block 16-byte aligned
         self.flat = torch.zeros(sum(sizes), dtype=dt, device=dev)
         self.views = []
+        self.slices = []
         off = 0
         for p, n in zip(ps, sizes):
             self.views.append((p, self.flat[off:off + p.numel()].view_as(p)))
+            self.slices.append((off, p.numel()))
             off += n
+        # home_params: the parameters themselves move into one flat buffer of the same layout, so that the optimizer
+        # step is ONE launch over [params | grads | moments] (GcmiAdam.attach_flat / step_flat) instead of one per tensor
+        self.pflat = None
+        if home_params:
+            self.pflat = torch.zeros_like(self.flat)
+            with torch.no_grad():
+                for p, (o, n) in zip(ps, self.slices):
+                    v = self.pflat[o:o + n].view_as(p)
+                    v.copy_(p.data)
+                    p.data = v
+
+    def params_homed(self) -> bool:
+        """Are the parameters still the views of ``pflat`` they were made (``load_state_dict`` copies in place and keeps
+        them; ``module.to(...)`` or an assignment to ``p.data`` does not)?"""
+        return self.pflat is not None and all(
+            p.data_ptr() == self.pflat.data_ptr() + 4 * o for (p, _), (o, _n) in zip(self.views, self.slices))
 
     def attach(self) -> None:
         """Instead of ``optimizer.zero_grad()``: every gradient a zeroed view of the arena."""
@@ -124,6 +142,8 @@ def shard_model(model, group=None) -> None:
     model._grad_sync = FlatGradAllReduce(group=group)
     # models whose backward runs through autograd get one flat gradient arena, so that their exchange is the same single
     # zero-copy all-reduce (GraphConvModel's native step brings its own)
+    if getattr(model, "_grad_arena", None) is not None and model._grad_arena.covers(model.model):
+        return  # (MPNNModel builds its own, with the parameters homed as well)
     model._grad_arena = None
     if not hasattr(model.model, "_native_net"):
         try:

@@ -50,6 +50,7 @@ class MatmulFn(torch.autograd.Function):
                            [0] if dual else None, None if b is None else b.contiguous(), None if b is None else [0],
                            n_out, False, False, n, k, x2.shape[1] if dual else 0)
         ctx.dual, ctx.has_bias = dual, b is not None
+        ctx.params = (W, b, W2)
         ctx.save_for_backward(x, W, x2 if dual else x, W2 if dual else W)
         return out
 
@@ -64,22 +65,27 @@ class MatmulFn(torch.autograd.Function):
             return ops.seg_gemm([0], [n], g, Wm.reshape(-1), [0], None, None, None, None, None, Wm.shape[0], True, False,
                                 n, n_out, 0)
 
-        def wgrad(a, Wm, want_bias):
-            dw = torch.zeros_like(Wm)
-            db = torch.zeros(n_out, dtype=torch.float32, device=dev) if want_bias else None
+        def wgrad(a, Wm, want_bias, pW, pb):
+            # (the kernels add into their outputs: with ops.direct_param_grads on, straight into p.grad)
+            tw, tb = ops.grad_target(pW), ops.grad_target(pb) if want_bias else None
+            dw = tw if tw is not None else torch.zeros_like(Wm)
+            db = None
+            if want_bias:
+                db = tb if tb is not None else torch.zeros(n_out, dtype=torch.float32, device=dev)
             if n > 0:
                 ops.seg_gemm_wgrad([0], [n], a, g, dw, [0], db, [0] if want_bias else None, False)
-            return dw, db
+            return (None if tw is not None else dw), (None if tb is not None else db)
 
+        pW, pb, pW2 = ctx.params
         dx = dgrad(W) if ctx.needs_input_grad[0] else None
         dW = db = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dW, db = wgrad(x, W, ctx.has_bias)
+            dW, db = wgrad(x, W, ctx.has_bias, pW, pb)
         dx2 = dW2 = None
         if ctx.dual:
             dx2 = dgrad(W2) if ctx.needs_input_grad[3] else None
             if ctx.needs_input_grad[4]:
-                dW2, _ = wgrad(x2, W2, False)
+                dW2, _ = wgrad(x2, W2, False, pW2, None)
         return dx, dW, db, dx2, dW2
 
 
@@ -202,44 +208,75 @@ class PairPlan:
         self.pf_t = pair_features.index_select(0, perm).contiguous()
 
 
+class EdgeMatsFn(torch.autograd.Function):
+    """(W (K, d d), b (d d)) -> M (d, (K+1) d) with M[r, k d + c] = W_k[r, c] (k = K: the bias block): the matrix the
+    per-atom moments are multiplied with.  Built ONCE per forward, not per message round; its backward folds the
+    gradient accumulated over the T rounds back into W's and b's layouts."""
+
+    @staticmethod
+    def forward(ctx, W, b, d: int):
+        K = W.shape[0]
+        blocks = torch.cat([W.reshape(K, d, d), b.reshape(1, d, d)])  # [k][r][c]
+        ctx.K, ctx.d = K, d
+        return blocks.permute(1, 0, 2).reshape(d, (K + 1) * d).contiguous()
+
+    @staticmethod
+    def backward(ctx, dM):
+        K, d = ctx.K, ctx.d
+        dB = dM.reshape(d, K + 1, d).permute(1, 0, 2)
+        return dB[:K].reshape(K, d * d).contiguous(), dB[K].reshape(d * d).contiguous(), None
+
+
+class EdgeAccum:
+    """Per forward pass: M, its transposed twin for the backward (M2[c, k d + r] = W_k[r, c]), and ONE accumulator
+    that the T rounds' weight-gradient launches add into; the round that runs its backward last hands it to autograd."""
+
+    def __init__(self, M: torch.Tensor, K: int, d: int):
+        self.M, self.K, self.d = M, K, d
+        self.M2 = None
+        self.dM = None
+        self.pending = 0
+
+
 class EdgeNetworkFn(torch.autograd.Function):
     """m_i = sum_{pairs (i, j)} A(pf_ij) h_j with A(pf) = reshape(pf . W + b, (d, d))
     (models/layers.py:3744-3752), computed as moments + one product, both ways."""
 
     @staticmethod
-    def forward(ctx, h, W, b, plan: PairPlan):
+    def forward(ctx, h, M, plan: PairPlan, acc: EdgeAccum):
         h = ops.rowmajor(h)
-        d = h.shape[1]
-        K = W.shape[0]
+        d, K = acc.d, acc.K
         T = ops.edge_network_moments(h, plan.pf, plan.dst_ptr, plan.src)
-        blocks = torch.cat([W.reshape(K, d, d), b.reshape(1, d, d)])  # [k][r][c]
-        M = blocks.permute(1, 0, 2).reshape(d, (K + 1) * d).contiguous()  # M[r, k d + c]
         n = T.shape[0]
         m = ops.seg_gemm([0], [n], T, M.reshape(-1), [0], None, None, None, None, None, d, True, False, n, (K + 1) * d, 0)
-        ctx.plan, ctx.K, ctx.d = plan, K, d
-        ctx.save_for_backward(T, blocks)
+        ctx.plan, ctx.acc = plan, acc
+        acc.pending += 1
+        ctx.save_for_backward(T, M)
         return m
 
     @staticmethod
     def backward(ctx, dm):
-        T, blocks = ctx.saved_tensors
-        plan, K, d = ctx.plan, ctx.K, ctx.d
+        T, M = ctx.saved_tensors
+        plan, acc = ctx.plan, ctx.acc
+        K, d = acc.K, acc.d
         dm = ops.rowmajor(dm)
         n = dm.shape[0]
-        dh = dW = db = None
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            dM = torch.zeros((d, (K + 1) * d), dtype=torch.float32, device=dm.device)  # dM[r, k d + c] = sum_i dm_ir T_i[k d + c]
-            if n > 0:
-                ops.seg_gemm_wgrad([0], [n], T, dm, dM, [0], None, None, True)
-            dB = dM.reshape(d, K + 1, d).permute(1, 0, 2)
-            dW = dB[:K].reshape(K, d * d).contiguous()
-            db = dB[K].reshape(d * d).contiguous()
+        dh = dM = None
+        acc.pending -= 1
+        if ctx.needs_input_grad[1]:
+            if acc.dM is None:
+                acc.dM = torch.zeros((d, (K + 1) * d), dtype=torch.float32, device=dm.device)
+            if n > 0:  # dM[r, k d + c] += sum_i dm_ir T_i[k d + c]
+                ops.seg_gemm_wgrad([0], [n], T, dm, acc.dM, [0], None, None, True)
+            if acc.pending == 0:
+                dM, acc.dM = acc.dM, None
         if ctx.needs_input_grad[0]:
+            if acc.M2 is None:
+                acc.M2 = M.reshape(d, K + 1, d).permute(2, 1, 0).reshape(d, (K + 1) * d).contiguous()
             Tt = ops.edge_network_moments(dm, plan.pf_t, plan.src_ptr, plan.dst_of_sorted)  # [sum_i pf_ijk dm_i | sum_i dm_i]
-            M2 = blocks.permute(2, 0, 1).reshape(d, (K + 1) * d).contiguous()  # M2[c, k d + r] = W_k[r, c]
-            dh = ops.seg_gemm([0], [n], Tt, M2.reshape(-1), [0], None, None, None, None, None, d, True, False, n,
+            dh = ops.seg_gemm([0], [n], Tt, acc.M2.reshape(-1), [0], None, None, None, None, None, d, True, False, n,
                               (K + 1) * d, 0)
-        return dh, dW, db, None
+        return dh, dM, None, None
 
 
 # ---------------------------------------------------------------------------------------------- the network
@@ -296,8 +333,10 @@ class _MPNNTorchModel(nn.Module):
         mol_ptr = torch.from_numpy(_csr_from_sorted(np.asarray(split, np.int64), self.batch_size, "atom_split")).to(dev)  # int32
         h = torch.zeros((n, d), dtype=torch.float32, device=dev)
         h[:, :self.n_atom_feat] = x  # zero padding up to n_hidden (MessagePassing.call, :3697-3706)
+        edge_M = EdgeMatsFn.apply(self.edge_W, self.edge_b, d)
+        edge_acc = EdgeAccum(edge_M, self.n_pair_feat, d)
         for _ in range(self.T):
-            m = EdgeNetworkFn.apply(h, self.edge_W, self.edge_b, plan)
+            m = EdgeNetworkFn.apply(h, edge_M, plan, edge_acc)
             zp = MatmulFn.apply(m, self.gru_Wz, self.gru_bz, h, self.gru_Uz)
             rp = MatmulFn.apply(m, self.gru_Wr, self.gru_br, h, self.gru_Ur)
             z, r, hr = GruGatesFn.apply(zp, rp, h)
@@ -364,6 +403,7 @@ class MPNNModel(TorchModel):
         else:
             output_types, loss = ['prediction'], L2Loss()
         super(MPNNModel, self).__init__(model, loss, output_types=output_types, batch_size=batch_size, **kwargs)
+        self._flat_step = True  # parameters, gradients and Adam moments in flat buffers (TorchModel._ensure_built)
 
     def _to_device(self, x):
         # index arrays stay on the host: the pair plan (two CSR directions) is built there

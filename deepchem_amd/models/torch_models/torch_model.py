@@ -253,6 +253,16 @@ class TorchModel(Model):
         self._global_step = 0
         self._pytorch_optimizer = self.optimizer._create_pytorch_optimizer(self.model.parameters())
         self._lr_schedule = self._new_schedule(self._pytorch_optimizer)
+        if getattr(self, "_flat_step", False) and hasattr(self._pytorch_optimizer, "attach_flat"):
+            # models whose backward is autograd over libgcmi.so kernels (MPNNModel): parameters, gradients and Adam
+            # moments in flat buffers -- one memset, gradients written in place, one Adam launch per step
+            from deepchem_amd.dist import FlatGradArena
+            try:
+                arena = FlatGradArena(self.model, home_params=True)
+                self._pytorch_optimizer.attach_flat(arena.pflat, arena.flat, arena.slices)
+                self._grad_arena = arena
+            except ValueError:
+                self._grad_arena = None
 
     def _optimizer_and_schedule(self, variables):
         """The model-wide optimizer, or one per distinct ``variables`` subset (kept across calls so
@@ -306,9 +316,11 @@ class TorchModel(Model):
         """One optimizer step on one prepared batch (torch_model.py:435-443): zero_grad, forward,
         loss over the loss outputs, backward, gradient all-reduce on data-parallel ranks, step.
         Subclasses replace this by a fused native step."""
-        arena = getattr(self, "_grad_arena", None) if self._grad_sync is not None else None
+        arena = getattr(self, "_grad_arena", None)
+        if arena is not None and self._grad_sync is None and not getattr(self, "_flat_step", False):
+            arena = None
         if arena is not None and not arena.covers(self.model):
-            arena = None  # somebody replaced parameters since shard_model: the per-tensor exchange handles any set
+            arena = None  # somebody replaced parameters since the arena was built: the per-tensor paths handle any set
         if arena is not None:
             arena.attach()  # zeroed views of one flat buffer behind every p.grad (deepchem_amd.dist.FlatGradArena)
         else:
@@ -317,13 +329,20 @@ class TorchModel(Model):
         if self._roles.declared:
             outputs = [outputs[i] for i in self._roles.loss]
         batch_loss = loss(outputs, labels, weights)
-        batch_loss.backward()
+        from deepchem_amd.ops import direct_param_grads
+        with direct_param_grads(arena is not None):  # weight gradients land in the arena as the kernels produce them
+            batch_loss.backward()
+        intact = arena is not None and arena.intact()
         if self._grad_sync is not None:
-            if arena is not None and arena.intact() and hasattr(self._grad_sync, "reduce_flat"):
+            if intact and hasattr(self._grad_sync, "reduce_flat"):
                 self._grad_sync.reduce_flat(arena.flat)  # ONE zero-copy collective
             else:
                 self._grad_sync(self.model)
-        optimizer.step()
+        flat = getattr(optimizer, "_flat", None)
+        if intact and flat is not None and flat.get("g") is arena.flat and arena.params_homed():
+            optimizer.step_flat(0, arena.flat.numel())  # ONE launch over every parameter
+        else:
+            optimizer.step()
         return batch_loss
 
     def fit_on_batch(self, X: Sequence, y: Sequence, w: Sequence, variables=None, loss=None,

@@ -610,6 +610,39 @@ class ReadoutFn(torch.autograd.Function):
         return (dx, dgamma, dbeta) + (None,) * 10
 
 
+# ---- parameter gradients straight into ``p.grad``
+# The weight-gradient kernels ADD into their output.  When a training step has put a zeroed view of one flat arena
+# behind every ``p.grad`` (deepchem_amd.dist.FlatGradArena.attach) and switches this on around ``backward()``, the
+# autograd functions below and in models/torch_models hand the kernels ``p.grad`` itself and return no gradient for
+# the parameter: a weight that is used T times (the message rounds of MPNN share theirs) then costs neither T
+# temporaries with their zero fills nor T - 1 additions by the autograd engine.
+_DIRECT_GRAD = [False]
+
+
+class direct_param_grads:
+    def __init__(self, on: bool = True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = _DIRECT_GRAD[0]
+        _DIRECT_GRAD[0] = self.on
+        return self
+
+    def __exit__(self, *exc):
+        _DIRECT_GRAD[0] = self.prev
+        return False
+
+
+def grad_target(p):
+    """``p.grad`` if gradients of ``p`` may be accumulated in place right now, else None."""
+    if not _DIRECT_GRAD[0] or p is None or not isinstance(p, torch.nn.Parameter):
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape:
+        return None
+    return g
+
+
 class LinearFn(torch.autograd.Function):
     """act(x . W^T + b) with nn.Linear's (out, in) weight layout."""
 
@@ -624,6 +657,7 @@ class LinearFn(torch.autograd.Function):
                        None if bias is None else bias.contiguous(), [0], n_out, True, relu, n, k, 0)
         ctx.relu = relu and not grad_masked
         ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)
         ctx.save_for_backward(x, weight, out)
         return out
 
@@ -637,10 +671,17 @@ class LinearFn(torch.autograd.Function):
             g = relu_bwd_(g.clone(), out)
         dw = db = dx = None
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw = torch.zeros_like(weight)
-            db = torch.zeros(n_out, dtype=torch.float32, device=g.device) if ctx.has_bias else None
+            tw, tb = grad_target(ctx.params[0]), grad_target(ctx.params[1])
+            dw = tw if tw is not None else torch.zeros_like(weight)
+            db = None
+            if ctx.has_bias:
+                db = tb if tb is not None else torch.zeros(n_out, dtype=torch.float32, device=g.device)
             if n > 0:
                 seg_gemm_wgrad([0], [n], x, g, dw, [0], db, [0], True)
+            if tw is not None:
+                dw = None
+            if tb is not None:
+                db = None
         if ctx.needs_input_grad[0]:
             dx = seg_gemm([0], [n], g, weight, [0], None, None, None, None, None, k, False, False, n,
                           n_out, 0)
