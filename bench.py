@@ -160,7 +160,7 @@ def family_traffic(storage="fp32"):
 measured_traffic.step_bytes = None
 
 
-def make_workload(args, rank, device, batch, storage="fp32"):
+def make_workload(args, rank, device, batch, storage="fp32", widths=(64, 64), dense=128):
     import deepchem_amd as dc
     from deepchem_amd.data.collate import collate_to_device
     from deepchem_amd.metrics import to_one_hot
@@ -171,7 +171,8 @@ def make_workload(args, rank, device, batch, storage="fp32"):
     labels = torch.as_tensor(to_one_hot(y.flatten(), 2).reshape(-1, args.tasks, 2).astype(np.float32),
                              device=device)
     weights = torch.as_tensor(w.astype(np.float32), device=device)
-    model = dc.models.torch_models.GraphConvModel(args.tasks, number_input_features=[75, 64],
+    model = dc.models.torch_models.GraphConvModel(args.tasks, number_input_features=[75] + list(widths[:-1]),
+                                                  graph_conv_layers=list(widths), dense_layer_size=dense,
                                                   batch_size=batch, mode="classification",
                                                   grad_mode=args.grad_mode, device=device,
                                                   learning_rate=1e-3, log_frequency=10**9, activation_storage=storage)
@@ -749,6 +750,20 @@ def main():
                 "molecules_per_s": round(8192 * world * p_steps / p_wall, 1), "ms_per_step": round(p_wall / p_steps * 1e3, 4),
                 "steps": p_steps, "n_gpus": world, "grad_mode": args.grad_mode}
         del pm, pb, pl, pw
+    if rank == 0 and world == 1 and not args.profile_only and args.storage == "fp32":
+        # MolNet's preset widths ([128, 128] GraphConv layers, dense 256: molnet/preset_hyper_parameters.py:128-135) at the
+        # headline batch: these shapes run on the general product / gradient kernels, not the one-pass block kernels
+        wm, wb, wl, ww = make_workload(args, rank, device, args.batch, "fp32", widths=(128, 128), dense=256)
+        run_steps(wm, wb, wl, ww, 2)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(wm, wb, wl, ww, 5)
+        torch.cuda.synchronize()
+        w_wall = time.perf_counter() - t1
+        out["config"]["widths_128_128_dense_256"] = {"molecules_per_s": round(args.batch * 5 / w_wall, 1),
+                                                     "ms_per_step": round(w_wall / 5 * 1e3, 4), "steps": 5,
+                                                     "molecules_per_step": args.batch}
+        del wm, wb, wl, ww
     if rank == 0 and world == 1 and not args.profile_only and args.gemm_mode == "fast":
         # the same step on the exact-fp32 matrix-core chain (the arithmetic whose trajectories track the reference)
         deepchem_amd.set_gemm_mode("exact")

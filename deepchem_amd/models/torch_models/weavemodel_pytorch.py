@@ -239,6 +239,7 @@ class WeaveModel(TorchModel):
                                          batch_size=batch_size,
                                          regularization_loss=weight_penalty if weight_decay_penalty != 0.0 else None,
                                          **kwargs)
+        self._flat_step = True  # parameters, gradients and Adam moments in flat buffers (TorchModel._ensure_built)
 
     def compute_features_on_batch(self, X_b):
         """WeaveMol objects -> ``(atom_feat, pair_feat, pair_split, atom_split, atom_to_pair)``

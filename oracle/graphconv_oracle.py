@@ -279,8 +279,15 @@ def init_state(cfg: ModelConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
         for k in range(2 * MAX_DEG + 1):
             st["graph_convs.%d.b_list.%d" % (li, k)] = torch.from_numpy(
                 rng.uniform(-0.1, 0.1, size=(width,)).astype(np.float32))
+    # Widths.  The reference's torch model hard-codes 64 in two places -- BatchNorm1d(num_features=64)
+    # (graphconvmodel.py:151) and nn.Linear(64, dense_layer_size) (:172) -- so it cannot run graph_conv_layers other than
+    # 64 wide at all (MolNet's regression preset [128, 128] / 256, molnet/preset_hyper_parameters.py:128-135, is a
+    # preset of the Keras model, whose BatchNormalization and Dense take their width from the layer before them).  For
+    # 64-wide layers this is the reference's construction, number for number; for other widths it is the Keras model's
+    # rule, and such runs are parity against the restated ALGORITHM only (tests say so).
+    last = cfg.graph_conv_layers[-1]
     if cfg.batch_normalize:
-        widths = [64] * len(cfg.graph_conv_layers) + [cfg.dense_layer_size]  # graphconvmodel.py:151
+        widths = list(cfg.graph_conv_layers) + [cfg.dense_layer_size]  # 64-wide layers: graphconvmodel.py:151
         for i, wdt in enumerate(widths):
             st["batch_norms.%d.weight" % i] = torch.from_numpy(
                 rng.uniform(0.5, 1.5, size=(wdt,)).astype(np.float32))
@@ -290,7 +297,7 @@ def init_state(cfg: ModelConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
             st["batch_norms.%d.running_var" % i] = torch.ones(wdt)
             st["batch_norms.%d.num_batches_tracked" % i] = torch.tensor(0, dtype=torch.int64)
     d = cfg.dense_layer_size
-    st["dense.weight"] = xavier(64, d, (d, 64))  # nn.Linear(64, dense) graphconvmodel.py:172
+    st["dense.weight"] = xavier(last, d, (d, last))  # nn.Linear(64, dense) graphconvmodel.py:172
     st["dense.bias"] = torch.from_numpy(rng.uniform(-0.1, 0.1, size=(d,)).astype(np.float32))
     if cfg.mode == "classification":
         o = cfg.n_tasks * cfg.n_classes

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
 
 
-def _native_step(packed, y, w, tasks, grad_mode, state, use_codes=False):
+def _native_step(packed, y, w, tasks, grad_mode, state, use_codes=False, widths=(64, 64), dense=128, mode="classification"):
     """forward + loss + backward through the whole-model C entry points on ONE natively collated batch.
     Returns loss, logits, fingerprint, the gradient arena, (name, slice) pairs, the trained range, running stats."""
     import deepchem_amd as dc
@@ -24,10 +24,14 @@ def _native_step(packed, y, w, tasks, grad_mode, state, use_codes=False):
     from deepchem_amd.metrics import to_one_hot
     n = packed.n_mols
     dbatch = collate_to_device(packed, None, DEV)
-    labels = torch.as_tensor(to_one_hot(y.flatten(), 2).reshape(-1, tasks, 2).astype(np.float32), device=DEV)
+    if mode == "classification":
+        labels = torch.as_tensor(to_one_hot(y.flatten(), 2).reshape(-1, tasks, 2).astype(np.float32), device=DEV)
+    else:
+        labels = torch.as_tensor(y.astype(np.float32), device=DEV)
     weights = torch.as_tensor(w.astype(np.float32), device=DEV)
-    model = dc.models.torch_models.GraphConvModel(tasks, number_input_features=[75, 64], batch_size=n, grad_mode=grad_mode,
-                                                  device=DEV)
+    model = dc.models.torch_models.GraphConvModel(tasks, number_input_features=[75] + list(widths[:-1]),
+                                                  graph_conv_layers=list(widths), dense_layer_size=dense, mode=mode,
+                                                  batch_size=n, grad_mode=grad_mode, device=DEV)
     model.model.load_state_dict({k: v.clone() for k, v in state.items()})
     native = model.model._native_net()
     assert native is not None
@@ -44,14 +48,15 @@ def _native_step(packed, y, w, tasks, grad_mode, state, use_codes=False):
             native.grad_range, stats, g)
 
 
-def _oracle_step(packed, y, w, tasks, grad_mode, state, double=False):
+def _oracle_step(packed, y, w, tasks, grad_mode, state, double=False, widths=(64, 64), dense=128, mode="classification"):
     """One training-mode forward + loss + backward of the oracle.  ``double``: the same op sequence in float64 (the
     yardstick: how far the reference's own float32 accumulation is from exact arithmetic at this batch size)."""
     import contextlib
     from oracle import graphconv_oracle as O
     from tests.util import oracle_batch, oracle_convmols
     n = packed.n_mols
-    cfg = O.ModelConfig(tasks, batch_size=n)
+    cfg = O.ModelConfig(tasks, graph_conv_layers=tuple(widths), number_input_features=(75,) + tuple(widths[:-1]),
+                        dense_layer_size=dense, mode=mode, batch_size=n)
     inputs, labels, weights = oracle_batch(cfg, oracle_convmols(packed), y, w, np.arange(n), n, True)
     if double:
         state = {k: (v.double() if v.is_floating_point() else v) for k, v in state.items()}
@@ -64,7 +69,7 @@ def _oracle_step(packed, y, w, tasks, grad_mode, state, double=False):
     return float(ref.detach()), [o.detach() for o in outs], tr.grads(), tr
 
 
-def _check(native, oracle32, oracle64, tol=1e-4):
+def _check(native, oracle32, oracle64, tol=1e-4, slack=1.0):
     """Every tensor T of the step in three versions: GPU, the oracle in the reference's float32, the oracle in float64
     (same op sequence; the yardstick).  In units of each tensor's scale: e_gpu = |GPU - float64|, e_ref = |float32
     oracle - float64|.
@@ -82,7 +87,14 @@ def _check(native, oracle32, oracle64, tol=1e-4):
         every gradient       e_gpu <= max(1e-4, worst e_ref of any gradient)
         number of gradients with e_gpu > 1e-4  <=  number with e_ref > 1e-4
         whole gradient vector, relative L2:  GPU vs float64  <=  max(1e-4, float32 oracle vs float64)
-    Where the reference's own e_ref stays below 1e-4 this is the plain 1e-4 bound (tests at <= 4 096 molecules)."""
+    Where the reference's own e_ref stays below 1e-4 this is the plain 1e-4 bound (tests at <= 4 096 molecules).
+
+    ``slack`` > 1 (the split-bf16 products at widths where they are not the default shapes): the gradient bounds are
+    ``slack`` times the float32 oracle's own distances -- the products' rounding is a few times fp32's, and the number
+    of flipped routes grows with it.  (A flip is not local: the rerouted gradient passes through W^T of the dense layer
+    and the GraphConv below, so it moves every feature of a neighbourhood of atoms and with them every entry of the
+    early layers' gradients a little -- a per-tensor median does not tell it from lost precision; the small-batch tests,
+    where nothing flips, are what pins the products to 1e-4.)"""
     loss, logits, fp, grads, slices, rng, stats, _ = native
     report = {}
 
@@ -120,10 +132,10 @@ def _check(native, oracle32, oracle64, tol=1e-4):
         print("   %-28s GPU-f64 %.2e  GPU-f32 %.2e  f32-f64 %.2e" % (name, e64, e32, er))
     for k in outputs:  # (the exact-fp32 product chain IS the reference's arithmetic and inherits part of its distance)
         assert report[k][0] <= max(tol, 0.5 * report[k][2]), (k, report[k])
-    bad = [(k,) + tuple("%.2e" % x for x in v) for k, v in gr.items() if v[0] > max(tol, worst_ref)]
+    bad = [(k,) + tuple("%.2e" % x for x in v) for k, v in gr.items() if v[0] > max(tol, slack * worst_ref)]
     assert not bad, bad
-    assert n_gpu <= max(n_ref, 0), (n_gpu, n_ref)
-    assert l2_gpu <= max(tol, l2_ref), (l2_gpu, l2_ref)
+    assert n_gpu <= max(slack * n_ref, 0), (n_gpu, n_ref)
+    assert l2_gpu <= max(tol, slack * l2_ref), (l2_gpu, l2_ref)
     return checked, report
 
 
@@ -194,6 +206,42 @@ def test_pcba_shape_meets_the_oracle():
     native = _native_step(packed, y, w, tasks, "full", state)
     checked, _ = _check(native, _oracle_step(packed, y, w, tasks, "full", state),
                         _oracle_step(packed, y, w, tasks, "full", state, double=True))
+    assert checked > 40
+
+
+@pytest.mark.parametrize("gemm", ["fast", "exact"])
+def test_regression_preset_widths_meet_the_oracle(gemm):
+    """MolNet's regression preset (graph_conv_layers [128, 128], dense 256, molnet/preset_hyper_parameters.py:128-135)
+    on the streaming path, BatchNorm on, complete backward.  The reference's TORCH model cannot run these widths at all
+    (BatchNorm1d(64) and nn.Linear(64, .) are hard-coded, graphconvmodel.py:151,172); the oracle sizes both by the
+    layer before them, as the Keras model the preset belongs to does -- parity against the restated algorithm.
+    ``exact`` (the fp32 matrix-core chain) meets the strict bounds of ``_check``; ``fast`` (split-bf16 products on the
+    general kernels: these widths have no one-pass block kernels) within 4 x the float32 oracle's own distance from
+    float64 (measured: whole gradient vector 1.9e-4 against the
+    oracle's 6.8e-5, worst tensor 3.6e-3 against 2.4e-3, outputs 1e-6 .. 5e-5)."""
+    import deepchem_amd as dc
+    from oracle import graphconv_oracle as O
+    from deepchem_amd.utils.synthetic import (concat_packed, single_atom_and_edge_cases, synthetic_labels,
+                                              synthetic_molecules)
+    widths, dense, tasks = (128, 128), 256, 1
+    packed = concat_packed([synthetic_molecules(4096, seed=11), single_atom_and_edge_cases(75, seed=3)])
+    n = packed.n_mols
+    y, w = synthetic_labels(n, tasks, "regression", 11)
+    cfg = O.ModelConfig(tasks, graph_conv_layers=widths, number_input_features=(75, 128), dense_layer_size=dense,
+                        mode="regression", batch_size=n)
+    state = O.init_state(cfg, 5)
+    kw = dict(widths=widths, dense=dense, mode="regression")
+    dc.set_gemm_mode(gemm)
+    try:
+        native = _native_step(packed, y, w, tasks, "full", state, **kw)
+    finally:
+        dc.set_gemm_mode("fast")
+
+    def as_classification(o):  # _check reads outs[1] (outputs) and outs[2] (fingerprint)
+        return o[0], [None, o[1][0], o[1][1]], o[2], o[3]
+    checked, _ = _check(native, as_classification(_oracle_step(packed, y, w, tasks, "full", state, **kw)),
+                        as_classification(_oracle_step(packed, y, w, tasks, "full", state, double=True, **kw)),
+                        slack=4.0 if gemm == "fast" else 1.0)
     assert checked > 40
 
 
