@@ -1,0 +1,48 @@
+"""The task head with 33..256 outputs on the matrix cores (csrc/head_bwd.hip: head_fwd_wide_kernel,
+head_bwd_wide_kernel, head_wgrad_wide_kernel) at the shapes its indexing has to survive: outputs that are no multiple
+of 16 or 32, a last tile of fewer than 32 molecules, one output per task (regression), three classes per task (the
+general loss loop), more tasks than one round of the loss phase covers, and one output beyond what the kernels take
+(the former launches must still be right).  Each case: loss, logits, fingerprint and every gradient of the complete
+backward against the float32 and float64 oracles (tests/test_gpu_scale.py:_check; nothing flips at these sizes, so the
+bound is the plain 1e-4)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.test_gpu_scale import _check, _native_step, _oracle_step
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # mode, tasks, classes, molecules
+    ("classification", 20, 2, 75),    # 40 outputs: padded to 48 columns; 75 = 2 x 32 + 11 molecules
+    ("classification", 100, 2, 40),   # 200 outputs
+    ("classification", 128, 2, 33),   # 256 outputs: the most; a last tile of one molecule
+    ("classification", 15, 3, 50),    # 45 outputs, three classes: the general loss loop
+    ("regression", 33, 1, 50),        # one output per task, odd count
+    ("regression", 200, 1, 37),       # more tasks than one round of the loss phase (128)
+    ("classification", 130, 2, 40),   # 260 outputs: beyond the kernels, the separate launches
+]
+
+
+@pytest.mark.parametrize("mode,tasks,classes,n", CASES)
+def test_wide_head_meets_the_oracle(mode, tasks, classes, n):
+    from oracle import graphconv_oracle as O
+    from deepchem_amd.utils.synthetic import synthetic_labels, synthetic_molecules
+    packed = synthetic_molecules(n, seed=tasks + n, max_atoms=40)
+    rng = np.random.RandomState(tasks)
+    if mode == "classification":
+        y = rng.randint(0, classes, size=(n, tasks)).astype(np.float64)
+        w = (rng.rand(n, tasks) < 0.9).astype(np.float64) * (0.5 + rng.rand(n, tasks))
+    else:
+        y, w = synthetic_labels(n, tasks, "regression", tasks)
+    cfg = O.ModelConfig(tasks, mode=mode, n_classes=classes, batch_size=n)
+    state = O.init_state(cfg, 9)
+    kw = dict(mode=mode, n_classes=classes)
+    native = _native_step(packed, y, w, tasks, "full", state, **kw)
+
+    def outs(o):  # _check reads outs[1] (outputs) and outs[2] (fingerprint)
+        return o if mode == "classification" else (o[0], [None, o[1][0], o[1][1]], o[2], o[3])
+    checked, report = _check(native, outs(_oracle_step(packed, y, w, tasks, "full", state, **kw)),
+                             outs(_oracle_step(packed, y, w, tasks, "full", state, double=True, **kw)))
+    assert checked > 40
