@@ -21,6 +21,19 @@
 
 namespace gcmi {
 
+// 16-byte row stores of the window operations.  -DGCMI_WIN_NT=1 (A/B switch, tools/win_nt_ab.sh): as non-temporal stores
+// (streamed past the caches: every output row of a window pass is written once and read by ANOTHER kernel).
+typedef float win_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void win_store4(float* p, const float4 v) {
+#if defined(GCMI_WIN_NT) && GCMI_WIN_NT
+  const win_f4 t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<win_f4*>(p));
+#else
+  *reinterpret_cast<float4*>(p) = v;
+#endif
+}
+
+
 constexpr int kND = GCMI_MAX_DEG + 1;
 constexpr int kLdsPerCU = 160 * 1024;
 constexpr int kRingBytes = 320;                 // 3 descriptors of GCMI_WIN_META_INTS ints, 16-byte padded
@@ -39,8 +52,13 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
   lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);  // wave-uniform by construction
+#if defined(GCMI_WIN_NT) && GCMI_WIN_NT >= 2  // (A/B switch: the row loads non-temporal as well)
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+#else
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+#endif
 }
 __device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_dst) {
   unsigned keep;
@@ -195,7 +213,7 @@ struct SumOp {
         if constexpr (ACC) {
           acc.x += old[k].x; acc.y += old[k].y; acc.z += old[k].z; acc.w += old[k].w;
         }
-        *reinterpret_cast<float4*>(s + (int64_t)row * lds + c * 4) = acc;
+        win_store4(s + (int64_t)row * lds + c * 4, acc);
       }
     }
   }
@@ -259,7 +277,7 @@ struct MaxOp {
         if (v.z > best.z) { best.z = v.z; ba.z = a; }
         if (v.w > best.w) { best.w = v.w; ba.w = a; }
       }
-      *reinterpret_cast<float4*>(out + (int64_t)row * ldo + c * 4) = best;
+      win_store4(out + (int64_t)row * ldo + c * 4, best);
       if (arg) *reinterpret_cast<uchar4*>(arg + (int64_t)row * (LPR * 4) + c * 4) = ba;
     }
   }
@@ -347,7 +365,7 @@ struct MaxBwdOp {
           acc.z += a.z == want ? g.z : 0.f;
           acc.w += a.w == want ? g.w : 0.f;
         }
-        *reinterpret_cast<float4*>(dx + (int64_t)row * lddx + c * 4) = acc;
+        win_store4(dx + (int64_t)row * lddx + c * 4, acc);
         if constexpr (STATS) {
           const float4 mu = *reinterpret_cast<const float4*>(sh_lds + c * 4);
           const float4 is = *reinterpret_cast<const float4*>(sh_lds + 256 + c * 4);
@@ -467,7 +485,7 @@ struct SumAccMaxBwdOp {
         acc.z += a.z == want ? g.z : 0.f;
         acc.w += a.w == want ? g.w : 0.f;
       }
-      *reinterpret_cast<float4*>(dy + (int64_t)row * lddy + c * 4) = acc;
+      win_store4(dy + (int64_t)row * lddy + c * 4, acc);
     }
     // (the walker's barrier at the top of the next window comes before the third tile is written again)
   }
