@@ -193,10 +193,13 @@ int head_bwd_fused(int32_t kind, const float* d_logits, const float* d_labels, c
                    const float* d_w, float* d_dw, float* d_db, float* d_g2, int64_t ldg2, double* d_loss_acc,
                    const int32_t* d_runs, int32_t n_deg, const int32_t* d_arg, const float* d_rawsum,
                    const float* d_mean, const float* d_invstd, double* d_sums, int32_t dense_width, hipStream_t st,
-                   float* d_dl_scratch = nullptr);
-// ... and the forward head with 33..256 outputs (one segment, 256-column rows, nn.Linear weight, no activation)
+                   float* d_dl_scratch = nullptr, const float* d_img = nullptr);
+// ... and the forward head with 33..256 outputs (one segment, 256-column rows, nn.Linear weight, no activation); d_img:
+// the fragment images head_prep made of d_w (kHeadImgFloats floats: forward order, then backward order), or nullptr
+constexpr int kHeadImgFloats = 2 * 8 * 16 * 3 * 64 * 4;
+int head_prep(const float* d_w, int32_t n_out, float* d_img, hipStream_t st);
 int head_fwd_wide(const float* d_in, int64_t ldin, int64_t n_rows, int32_t k, const float* d_w, const float* d_bias,
-                  int32_t n_out, int32_t act, float* d_out, int64_t ldo, hipStream_t st);
+                  int32_t n_out, int32_t act, float* d_out, int64_t ldo, hipStream_t st, const float* d_img = nullptr);
 // replicas of the loss accumulator (doubles) that head_bwd_fused adds into; loss_finalize_impl sums and clears them
 constexpr int kLossRep = 16;
 int loss_finalize_impl(double* d_acc, float inv_count, float* d_loss, void* stream, int n_rep = 1);

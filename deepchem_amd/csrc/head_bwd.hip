@@ -210,6 +210,10 @@ __global__ void __launch_bounds__(kHB) head_bwd_kernel(HeadArgs a) {
 // molecules x 256 outputs).
 constexpr int kWTC = 256;        // most task outputs
 constexpr int kWP = kWTC + 8;    // LDS pitch of a row of d logits pieces (bf16): 528 bytes, 16-byte reads conflict-free
+// the head matrix as fragment images (head_prep_kernel below): [tile][k-step][piece][lane] 16-byte entries
+constexpr int kImgTiles = kHB / 32, kImgKs = kWTC / 16;
+constexpr int kImgEntries = kImgTiles * kImgKs * 3 * 64;  // u32x4 entries of one image (393 KB)
+static_assert(kHeadImgFloats == 2 * kImgEntries * 4, "common.h: workspace floats of the two head images");
 
 __device__ __forceinline__ f32x16 six_products(const u32x4 (&r)[3], const Frag3& c, f32x16 acc) {
   // rows fragment r (lane = row), columns fragment c (lane = column); small terms first
@@ -237,8 +241,15 @@ constexpr int kWT = 512;         // threads of the wide kernels: eight waves, on
 // (the wide kernel spreads its loss over kLossRep accumulators, common.h: same-address fp64 atomics serialise at ~14 ns
 // each, and 256 workgroups on one address -- plus 256 on each entry of the bias gradient -- were 7 us of tail)
 
-__global__ void __launch_bounds__(kWT) head_bwd_wide_kernel(HeadArgs a, float* __restrict__ dl_out) {
-  __shared__ __attribute__((aligned(16))) unsigned short dlp[3][kHM][kWP];
+__global__ void __launch_bounds__(kWT) head_bwd_wide_kernel(HeadArgs a, float* __restrict__ dl_out,
+                                                            const u32x4* __restrict__ img) {
+  // img: the backward image of head_prep_kernel ([tile of 32 fingerprint columns][k-step over the outputs][piece][lane])
+  extern __shared__ __attribute__((aligned(16))) unsigned char head_lds[];
+  typedef unsigned short (*DlpT)[kHM][kWP];
+  DlpT dlp = reinterpret_cast<DlpT>(head_lds);                                   // [3][32][264] pieces of d logits
+  float* fp_s = reinterpret_cast<float*>(head_lds + sizeof(unsigned short) * 3 * kHM * kWP);   // [32][256] fingerprint rows
+  float* rs_s = fp_s + kHM * kHB;                                                // [32][256] [row sums | arg-max values]
+  int* arg_s = reinterpret_cast<int*>(rs_s + kHM * kHB);                         // [32][128]
   __shared__ int n_s[kHM];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -250,6 +261,15 @@ __global__ void __launch_bounds__(kWT) head_bwd_wide_kernel(HeadArgs a, float* _
   const int64_t c0 = (int64_t)blockIdx.x * kHM;
   const int nm = (int)((a.n_mols - c0) < kHM ? (a.n_mols - c0) : kHM);
   HD_BEGIN();
+  // atoms per molecule (the row sums' BatchNorm terms): one (molecule, degree) run per thread, added up in LDS
+  if (tid < kHM) n_s[tid] = 0;
+  __syncthreads();
+  if (a.sums != nullptr) {
+    for (int i = tid; i < nm * a.n_deg; i += kWT) {
+      const int2 r = *reinterpret_cast<const int2*>(a.runs + (c0 * a.n_deg + i) * 2);
+      atomicAdd(&n_s[i / a.n_deg], r.y - r.x);
+    }
+  }
   // the padding columns of the pieces
   for (int i = tid; i < kHM * (TCP - TC); i += kWT) {
     const int m = i / (TCP - TC), c = TC + i - m * (TCP - TC);
@@ -261,23 +281,42 @@ __global__ void __launch_bounds__(kWT) head_bwd_wide_kernel(HeadArgs a, float* _
   // threads by division and wrote every d logit with its own split and stores: 35 000 cycles of VALU work.)
   double loss_local = 0.0;
   const int C = a.n_classes;
-  // this wave's fragments of W (TC x 256, lane = fingerprint column k, eight consecutive outputs per k-step; every load
-  // instruction is two whole 128-byte rows): half of them issued behind phase 1's input loads and ahead of its
-  // arithmetic, the other half behind phase 1 -- a load per k-step would run the product loop at L2 latency
+  // this wave's fragments of W from the prepared image (lane = fingerprint column k, eight consecutive outputs per
+  // k-step, already split): half of them issued behind phase 1's input loads and ahead of its arithmetic, the other
+  // half behind phase 1
   const int k = wave * 32 + l31, f = k & (D - 1);
   const int part = wave >> 2;  // 0: the sum half of the fingerprint, 1: the max half
-  float wr[kWTC / 16][8];
+  u32x4 wr[kWTC / 16][3];
+  const u32x4* wsrc = img + ((size_t)wave * kImgKs * 3) * 64 + lane;
   auto load_w = [&](const int ks0, const int ks1) {
-    const float* wcol = a.w + k;
 #pragma unroll
     for (int ks = 0; ks < kWTC / 16; ++ks) {
       if (ks >= ks0 && ks < ks1 && ks < nks) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int tc = ks * 16 + 8 * half + i;
-          const float x = wcol[(tc < TC ? tc : TC - 1) * kHB];
-          wr[ks][i] = tc < TC ? x : 0.f;
-        }
+        for (int p = 0; p < 3; ++p) wr[ks][p] = wsrc[(ks * 3 + p) * 64];
+      }
+    }
+  };
+  // the rows phase 3 needs of the 32 molecules -- fingerprint, BatchNorm inputs, arg-max -- as 16-byte loads into LDS
+  // (a lane = a column reading them itself is 48 dword loads per lane)
+  auto stage_rows = [&]() {
+    const int mb = nm - 1;
+#pragma unroll
+    for (int p = 0; p < kHM * (kHB / 4) / kWT; ++p) {
+      const int slot = tid + p * kWT;
+      const int r = slot >> 6, q = slot & 63;
+      const int64_t b = c0 + (r < nm ? r : mb);
+      *reinterpret_cast<float4*>(fp_s + r * kHB + 4 * q) = *reinterpret_cast<const float4*>(a.fp + b * a.ldfp + 4 * q);
+      if (a.sums != nullptr)
+        *reinterpret_cast<float4*>(rs_s + r * kHB + 4 * q) = *reinterpret_cast<const float4*>(a.rawsum + b * kHB + 4 * q);
+    }
+    if (a.sums != nullptr) {
+#pragma unroll
+      for (int p = 0; p < kHM * (D / 4) / kWT; ++p) {
+        const int slot = tid + p * kWT;
+        const int r = slot >> 5, q = slot & 31;
+        const int64_t b = c0 + (r < nm ? r : mb);
+        *reinterpret_cast<int4*>(arg_s + r * D + 4 * q) = *reinterpret_cast<const int4*>(a.arg + b * D + 4 * q);
       }
     }
   };
@@ -397,35 +436,11 @@ __global__ void __launch_bounds__(kWT) head_bwd_wide_kernel(HeadArgs a, float* _
       }
     }
   }
-  if (a.sums != nullptr && tid < kHM) {
-    int n = 0;
-    if (tid < nm) {
-      const int32_t* r = a.runs + ((c0 + tid) * a.n_deg) * 2;
-      for (int d = 0; d < a.n_deg; ++d) n += r[2 * d + 1] - r[2 * d];
-    }
-    n_s[tid] = n;
-  }
   HD_T(0, 3);
   if (!(a.kind == 1 || C == 2)) load_w(0, kWTC / 32);
   load_w(kWTC / 32, kWTC / 16);
   // ---- what phase 3 reads per molecule
-  float fv[16], rsv[16];
-  int av[16];
-  {
-    const int mb = nm - 1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int64_t b = c0 + (m < nm ? m : mb);
-      fv[r] = a.fp[b * a.ldfp + k];
-      rsv[r] = 0.f;
-      av[r] = 0;
-      if (a.sums != nullptr) {
-        rsv[r] = a.rawsum[b * 2 * D + k];                  // [row sums | arg-max row's value]
-        if (part == 1) av[r] = a.arg[b * D + f];
-      }
-    }
-  }
+  stage_rows();
   __syncthreads();
   HD_T(0, 4);
   // ---- phase 2: d fingerprint[32 x 256] = d logits[32 x TC] . W[TC x 256], this wave's 32 columns
@@ -438,7 +453,10 @@ __global__ void __launch_bounds__(kWT) head_bwd_wide_kernel(HeadArgs a, float* _
       u32x4 r[3];
 #pragma unroll
       for (int p = 0; p < 3; ++p) r[p] = *reinterpret_cast<const u32x4*>(&dlp[p][l31][ks * 16 + 8 * half]);
-      acc = six_products(r, split_frag(wr[ks]), acc);
+      Frag3 fw;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fw.p[p] = wr[ks][p];
+      acc = six_products(r, fw, acc);
     }
   }
   HD_T(0, 5);
@@ -451,16 +469,18 @@ __global__ void __launch_bounds__(kWT) head_bwd_wide_kernel(HeadArgs a, float* _
     for (int r = 0; r < 16; ++r) {
       const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
       if (m < nm) {
-        const float g = acc[r] * (1.f - fv[r] * fv[r]);
+        const float fvr = fp_s[m * kHB + k];
+        const float g = acc[r] * (1.f - fvr * fvr);
         grow[m * a.ldg2] = g;
         if (a.sums != nullptr) {
+          const float rsvr = rs_s[m * kHB + k];            // [row sums | arg-max row's value]
           if (part == 0) {
             const double n = (double)n_s[m];
-            const double xs = ((double)rsv[r] - n * mu) * is;
+            const double xs = ((double)rsvr - n * mu) * is;
             t1 += n * (double)g;
             t2 += (double)g * xs;
-          } else if (av[r] >= 0) {
-            const double xa = ((double)rsv[r] - mu) * is;
+          } else if (arg_s[m * D + f] >= 0) {
+            const double xa = ((double)rsvr - mu) * is;
             t1 += (double)g;
             t2 += (double)g * xa;
           }
@@ -705,6 +725,122 @@ __global__ void __launch_bounds__(kWT) head_fwd_wide_kernel(const float* __restr
   HD_T(2, 2);
 }
 
+// ---------------------------------------------------------------- the head matrix, prepared once per step
+// What the phase clocks of the kernels above say: splitting W in every workgroup is most of the forward,
+// and reading W[tc][k] for a lane = a column k (the backward's operand) is 128 dword loads per lane at ~22 cycles of
+// the CU's memory pipe each.  head_prep_kernel splits W ONCE into the two fragment orders -- [tile][k-step][piece][lane]
+// 16-byte entries, for the forward (a lane = an output, eight consecutive fingerprint columns) and for the backward (a
+// lane = a fingerprint column, eight consecutive outputs) -- so that a wave fetches its operand as 3 x 16 whole 1 KiB
+// lines and multiplies without any VALU work on it.
+
+__global__ void __launch_bounds__(256) head_prep_kernel(const float* __restrict__ w, int TC, u32x4* __restrict__ img) {
+  const int id = blockIdx.x * 256 + threadIdx.x;  // (image, tile, k-step, lane)
+  const int which = id / (kImgTiles * kImgKs * 64);
+  const int rem = id - which * (kImgTiles * kImgKs * 64);
+  const int tile = rem / (kImgKs * 64), ks = (rem / 64) % kImgKs, lane = rem & 63;
+  const int half = lane >> 5, l31 = lane & 31;
+  float v[8];
+  if (which == 0) {  // forward: lane = output n, contraction along the fingerprint
+    const int n = tile * 32 + l31;
+    const float* src = w + (int64_t)(n < TC ? n : TC - 1) * kHB + ks * 16 + 8 * half;
+    const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+    const float keep = n < TC ? 1.f : 0.f;
+    v[0] = a.x * keep; v[1] = a.y * keep; v[2] = a.z * keep; v[3] = a.w * keep;
+    v[4] = b.x * keep; v[5] = b.y * keep; v[6] = b.z * keep; v[7] = b.w * keep;
+  } else {           // backward: lane = fingerprint column k, contraction along the outputs
+    const int k = tile * 32 + l31;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int tc = ks * 16 + 8 * half + i;
+      const float x = w[(int64_t)(tc < TC ? tc : TC - 1) * kHB + k];
+      v[i] = tc < TC ? x : 0.f;
+    }
+  }
+  const Frag3 f = split_frag(v);
+  u32x4* dst = img + (size_t)which * kImgEntries + ((size_t)(tile * kImgKs + ks) * 3) * 64 + lane;
+  dst[0] = f.p[0];
+  dst[64] = f.p[1];
+  dst[128] = f.p[2];
+}
+
+// The forward over the prepared image: a workgroup = 32 rows, eight waves = the eight 32-column tiles of the output;
+// rows split once into LDS pieces; the wave's 48 weight fragments straight from the image, half of them in flight
+// while the other half is multiplied.
+__global__ void __launch_bounds__(kWT) head_fwd_img_kernel(const float* __restrict__ in, int64_t ldin, int64_t n_rows,
+                                                           const u32x4* __restrict__ img, const float* __restrict__ bias,
+                                                           int TC, float* __restrict__ out, int64_t ldo) {
+  __shared__ __attribute__((aligned(16))) unsigned short ap[3][kHM][kWP];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int64_t row0 = (int64_t)blockIdx.x * kHM;
+  const int valid = (int)((n_rows - row0) < kHM ? (n_rows - row0) : kHM);
+  const int n = wave * 32 + l31;
+  const bool tile = wave * 32 < TC;  // (wave-uniform)
+  HD_BEGIN();
+  float4 ain[kHM * (kHB / 4) / kWT];
+#pragma unroll
+  for (int p = 0; p < kHM * (kHB / 4) / kWT; ++p) {
+    const int slot = tid + p * kWT;
+    const int r = slot >> 6, q = slot & 63;
+    ain[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < valid) ain[p] = *reinterpret_cast<const float4*>(in + (row0 + r) * ldin + 4 * q);
+  }
+  const float bv = (bias != nullptr && n < TC) ? bias[n] : 0.f;
+  constexpr int NKS = kHB / 16, HK = NKS / 2;
+  const u32x4* wsrc = img + ((size_t)wave * kImgKs * 3) * 64 + lane;
+  u32x4 wa[HK][3], wb[HK][3];
+  if (tile) {
+#pragma unroll
+    for (int ks = 0; ks < HK; ++ks)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) wa[ks][p] = wsrc[(ks * 3 + p) * 64];
+  }
+#pragma unroll
+  for (int p = 0; p < kHM * (kHB / 4) / kWT; ++p) {
+    const int slot = tid + p * kWT;
+    const int r = slot >> 6, q = slot & 63;
+    unsigned a1, a2, a3, b1, b2, b3;
+    split3_pair(ain[p].x, ain[p].y, a1, a2, a3);
+    split3_pair(ain[p].z, ain[p].w, b1, b2, b3);
+    *reinterpret_cast<uint2*>(&ap[0][r][4 * q]) = make_uint2(a1, b1);
+    *reinterpret_cast<uint2*>(&ap[1][r][4 * q]) = make_uint2(a2, b2);
+    *reinterpret_cast<uint2*>(&ap[2][r][4 * q]) = make_uint2(a3, b3);
+  }
+  if (tile) {
+#pragma unroll
+    for (int ks = 0; ks < HK; ++ks)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) wb[ks][p] = wsrc[((HK + ks) * 3 + p) * 64];
+  }
+  __syncthreads();
+  HD_T(2, 0);
+  if (!tile) return;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    u32x4 r[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) r[p] = *reinterpret_cast<const u32x4*>(&ap[p][l31][ks * 16 + 8 * half]);
+    Frag3 fw;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) fw.p[p] = ks < HK ? wa[ks < HK ? ks : 0][p] : wb[ks >= HK ? ks - HK : 0][p];
+    acc = six_products(r, fw, acc);
+  }
+  HD_T(2, 1);
+  if (n < TC) {
+    float* ocol = out + row0 * ldo + n;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (m < valid) ocol[m * ldo] = acc[r] + bv;
+    }
+  }
+  HD_T(2, 2);
+}
+
 #ifdef GCMI_HEAD_DIAG_BUILD
 static void head_diag_print(const char* what, int kern, hipStream_t st) {
   static int printed = 0;
@@ -724,12 +860,30 @@ static bool head_wide_enabled() {
   return on && !gemm_exact_mode();
 }
 
-// GCMI_ERR_UNSUPPORTED: not (one segment of 256-column rows times an nn.Linear weight with 33..256 outputs, no activation)
+// the two fragment images of the head matrix (kHeadImgFloats floats at d_img); GCMI_ERR_UNSUPPORTED: outside 33..256 outputs
+int head_prep(const float* d_w, int32_t n_out, float* d_img, hipStream_t st) {
+  if (!head_wide_enabled() || n_out <= kHT || n_out > kWTC || d_img == nullptr || !aligned16(d_w) || !aligned16(d_img))
+    return GCMI_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(head_prep_kernel, dim3(2 * kImgTiles * kImgKs * 64 / 256), dim3(256), 0, st, d_w, n_out,
+                     reinterpret_cast<u32x4*>(d_img));
+  GCMI_CHECK_LAUNCH("head_prep");
+  return GCMI_OK;
+}
+
+// GCMI_ERR_UNSUPPORTED: not (one segment of 256-column rows times an nn.Linear weight with 33..256 outputs, no activation).
+// d_img: the images head_prep made of THIS d_w (the forward one is read), or nullptr: the weights are split per workgroup
 int head_fwd_wide(const float* d_in, int64_t ldin, int64_t n_rows, int32_t k, const float* d_w, const float* d_bias,
-                  int32_t n_out, int32_t act, float* d_out, int64_t ldo, hipStream_t st) {
+                  int32_t n_out, int32_t act, float* d_out, int64_t ldo, hipStream_t st, const float* d_img) {
   if (!head_wide_enabled() || k != kHB || n_out <= kHT || n_out > kWTC || act != 0 || ldin % 4 != 0 || !aligned16(d_in) ||
       !aligned16(d_w) || n_rows <= 0)
     return GCMI_ERR_UNSUPPORTED;
+  if (d_img != nullptr) {
+    hipLaunchKernelGGL(head_fwd_img_kernel, dim3((unsigned)((n_rows + kHM - 1) / kHM)), dim3(kWT), 0, st, d_in, ldin, n_rows,
+                       reinterpret_cast<const u32x4*>(d_img), d_bias, n_out, d_out, ldo);
+    GCMI_CHECK_LAUNCH("head_fwd_img");
+    HD_PRINT("fwd_img", 2, st);
+    return GCMI_OK;
+  }
   constexpr size_t shmem = sizeof(unsigned short) * 3 * (kHM * kWP + 2 * kWTC * kFWP);
   static bool attr_done = false;
   if (!attr_done) {
@@ -748,18 +902,20 @@ int head_fwd_wide(const float* d_in, int64_t ldin, int64_t n_rows, int32_t k, co
 }
 
 // GCMI_ERR_UNSUPPORTED: other widths than a 256-column fingerprint; more than 32 task outputs without d_dl_scratch
-// (n_mols x outputs floats) or more than 256
+// (n_mols x outputs floats) and d_img (head_prep's images of d_w), or more than 256
 int head_bwd_fused(int32_t kind, const float* d_logits, const float* d_labels, const float* d_weights, int64_t n_rows,
                    int32_t n_tasks, int32_t n_classes, int64_t n_mols, const float* d_fp, int64_t ldfp,
                    const float* d_w, float* d_dw, float* d_db, float* d_g2, int64_t ldg2, double* d_loss_acc,
                    const int32_t* d_runs, int32_t n_deg, const int32_t* d_arg, const float* d_rawsum,
                    const float* d_mean, const float* d_invstd, double* d_sums, int32_t dense_width, hipStream_t st,
-                   float* d_dl_scratch) {
+                   float* d_dl_scratch, const float* d_img) {
   static const bool on = !(getenv("GCMI_FUSED_HEAD") && atoi(getenv("GCMI_FUSED_HEAD")) == 0);
   const int tc = n_tasks * (kind == 0 ? n_classes : 1);
   if (!on || !fused_bwd_enabled() || 2 * dense_width != kHB || tc < 1 || n_mols <= 0) return GCMI_ERR_UNSUPPORTED;
   const bool wide = tc > kHT;
-  if (wide && (tc > kWTC || d_dl_scratch == nullptr || !head_wide_enabled())) return GCMI_ERR_UNSUPPORTED;
+  if (wide && (tc > kWTC || d_dl_scratch == nullptr || d_img == nullptr || !head_wide_enabled() || ldfp % 4 != 0 ||
+               !aligned16(d_fp)))
+    return GCMI_ERR_UNSUPPORTED;
   if (d_sums != nullptr && (!d_runs || !d_arg || !d_rawsum || !d_mean || !d_invstd)) return GCMI_ERR_UNSUPPORTED;
   HeadArgs a;
   memset(&a, 0, sizeof(a));
@@ -770,11 +926,22 @@ int head_bwd_fused(int32_t kind, const float* d_logits, const float* d_labels, c
   a.runs = d_runs; a.n_deg = n_deg; a.arg = d_arg; a.rawsum = d_rawsum; a.mean = d_mean; a.invstd = d_invstd;
   a.sums = d_sums;
   if (wide) {
-    hipLaunchKernelGGL(head_bwd_wide_kernel, dim3((unsigned)((n_mols + kHM - 1) / kHM)), dim3(kWT), 0, st, a, d_dl_scratch);
+    constexpr size_t shmem = sizeof(unsigned short) * 3 * kHM * kWP + sizeof(float) * (2 * kHM * kHB + kHM * (kHB / 2));
+    static bool attr_done = false;
+    if (!attr_done) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(head_bwd_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)shmem) != hipSuccess) {
+        (void)hipGetLastError();
+        return GCMI_ERR_UNSUPPORTED;
+      }
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(head_bwd_wide_kernel, dim3((unsigned)((n_mols + kHM - 1) / kHM)), dim3(kWT), shmem, st, a, d_dl_scratch,
+                       reinterpret_cast<const u32x4*>(d_img) + kImgEntries);
     GCMI_CHECK_LAUNCH("head_bwd_wide");
     HD_PRINT("bwd_wide", 0, st);
-    // slabs: four workgroups per CU over all blocks of dW (all resident), never below 64 molecules
-    static const int wg_env = getenv("GCMI_HEAD_WGRAD_WGS") ? atoi(getenv("GCMI_HEAD_WGRAD_WGS")) : 1024;
+    // slabs: two workgroups per CU over all blocks of dW (measured at 8 192 x 256: 1 024 workgroups 24.1 us, 512: 18.8, 256: 19.8 -- the atomics of more, shorter slabs against the latency of fewer, longer ones), never below 64 molecules
+    static const int wg_env = getenv("GCMI_HEAD_WGRAD_WGS") ? atoi(getenv("GCMI_HEAD_WGRAD_WGS")) : 512;
     const int blocks = ((tc + 63) / 64) * 4;
     int64_t slabs = std::max<int64_t>(1, wg_env / blocks);
     slabs = std::min<int64_t>(slabs, (n_mols + 63) / 64);

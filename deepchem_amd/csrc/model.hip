@@ -50,6 +50,7 @@ struct Ws {
   int64_t dense, arg_r, rsum, dfp, tA, tB, tC, tD, tE, total;
   int64_t xb;    // storage == 1: bf16 copy of the atom features (ld = ldS[0])
   int64_t wimg;  // scratch of the forward products (split weight fragments in lane order, rebuilt by every launch)
+  int64_t himg;  // more than 32 task outputs: the head matrix's two fragment images (head_bwd.hip: head_prep), forward -> backward
   // one region the backward zeroes with a single memset: [dlogits | dbsum per layer | lacc | acc]
   int64_t dlogits, dbsum[kMaxL], lacc, acc, acc2, z_end;
 };
@@ -93,6 +94,7 @@ static Ws carve(const gcmi_model_desc* m, int64_t N, int64_t B, int64_t ld_featu
   const int64_t D = m->dense_width;
   const int64_t TC = (int64_t)m->n_tasks * m->n_classes;
   w.bnv[L] = take(4 * D);
+  w.himg = (TC > 32 && TC <= 256 && 2 * D == 256) ? take(kHeadImgFloats) : -1;
   w.dense = take_act(N, D);
   w.arg_r = take(B * D);
   w.rsum = take(2 * B * D);  // per-molecule [row sums | arg-max row value] of the dense output (BatchNorm backward)
@@ -110,6 +112,26 @@ static Ws carve(const gcmi_model_desc* m, int64_t N, int64_t B, int64_t ld_featu
   w.z_end = off;
   w.total = off;
   return w;
+}
+
+// The task head's forward product: with more than 32 outputs on the prepared images (head_bwd.hip), which stay in the
+// workspace for the backward; otherwise (and in the exact product mode) the segmented product.
+static int head_forward(const gcmi_model_desc* m, const Ws& w, float* ws, const float* d_params, const gcmi_model_io* io,
+                        int64_t B, void* stream) {
+  const int D = m->dense_width;
+  const int TC = m->n_tasks * m->n_classes;
+  const int32_t zero32 = 0, nB = (int32_t)B;
+  const int64_t zero64 = 0;
+  if (w.himg >= 0 && B > 0) {
+    hipStream_t st = (hipStream_t)stream;
+    int rc = head_prep(d_params + m->off_head_w, TC, ws + w.himg, st);
+    if (rc == GCMI_OK)
+      rc = head_fwd_wide(io->d_fingerprint, 2 * D, B, 2 * D, d_params + m->off_head_w, d_params + m->off_head_b, TC, 0,
+                         io->d_logits, TC, st, ws + w.himg);
+    if (rc != GCMI_ERR_UNSUPPORTED) return rc;
+  }
+  return gcmi_seg_gemm(1, &zero32, &nB, io->d_fingerprint, 2 * D, 2 * D, d_params + m->off_head_w, &zero64, nullptr, 0, 0,
+                       nullptr, nullptr, d_params + m->off_head_b, &zero64, TC, 1, 0, io->d_logits, TC, stream);
 }
 
 static int check_desc(const gcmi_model_desc* m) {
@@ -306,8 +328,7 @@ static int model_forward_h(const gcmi_model_desc* m, const gcmi_graph* g, const 
                        training ? ws + w.rsum : nullptr, stream, 1));
   const int TC = m->n_tasks * m->n_classes;
   const int32_t nB = (int32_t)B;
-  RUN(gcmi_seg_gemm(1, &zero32, &nB, io->d_fingerprint, 2 * D, 2 * D, d_params + m->off_head_w, &zero64, nullptr, 0, 0,
-                    nullptr, nullptr, d_params + m->off_head_b, &zero64, TC, 1, 0, io->d_logits, TC, stream));
+  RUN(head_forward(m, w, ws, d_params, io, B, stream));
   if (m->mode == 0 && io->d_probs) RUN(gcmi_softmax(io->d_logits, B * m->n_tasks, m->n_classes, io->d_probs, stream));
   if (training) {
     CounterPtrs c;
@@ -360,7 +381,7 @@ static int model_loss_backward_h(const gcmi_model_desc* m, const gcmi_graph* g, 
                                   d_grads + m->off_head_b, ws + w.dfp, 2 * D, reinterpret_cast<double*>(ws + w.lacc),
                                   g->d_mol_runs, g->max_deg + 1, reinterpret_cast<const int32_t*>(ws + w.arg_r), ws + w.rsum,
                                   bnvL, bnvL + D, (N > 0 && g->d_mol_runs) ? reinterpret_cast<double*>(ws + w.acc) : nullptr,
-                                  D, st, ws + w.dlogits);
+                                  D, st, ws + w.dlogits, w.himg >= 0 ? ws + w.himg : nullptr);
     if (rc == GCMI_OK) {
       head_sums = N > 0 && g->d_mol_runs != nullptr;
       RUN(loss_finalize_impl(reinterpret_cast<double*>(ws + w.lacc), 1.f / (float)(n_rows * m->n_tasks), io->d_loss, stream, kLossRep));
@@ -591,9 +612,7 @@ int gcmi_model_forward(const gcmi_model_desc* m, const gcmi_graph* g, const floa
                        stream));
   const int TC = m->n_tasks * m->n_classes;
   const int32_t nB = (int32_t)B;
-  RUN(gcmi_seg_gemm(1, &zero32, &nB, io->d_fingerprint, 2 * D, 2 * D, d_params + m->off_head_w, &zero64,
-                    nullptr, 0, 0, nullptr, nullptr, d_params + m->off_head_b, &zero64, TC, 1, 0,
-                    io->d_logits, TC, stream));
+  RUN(head_forward(m, w, ws, d_params, io, B, stream));
   if (m->mode == 0 && io->d_probs)
     RUN(gcmi_softmax(io->d_logits, B * m->n_tasks, m->n_classes, io->d_probs, stream));
   if (training && m->batch_norm) {
@@ -665,7 +684,7 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
                                   reinterpret_cast<double*>(ws + w.lacc), g->d_mol_runs, g->max_deg + 1,
                                   reinterpret_cast<const int32_t*>(ws + w.arg_r), ws + w.rsum, bnvL, bnvL + D,
                                   (dense_fused_next && g->d_mol_runs) ? reinterpret_cast<double*>(ws + w.acc) : nullptr, D,
-                                  st, ws + w.dlogits);
+                                  st, ws + w.dlogits, w.himg >= 0 ? ws + w.himg : nullptr);
     if (rc == GCMI_OK) {
       head_done = true;
       head_sums = dense_fused_next && g->d_mol_runs != nullptr;
