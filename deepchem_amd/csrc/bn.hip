@@ -188,7 +188,9 @@ __global__ void bn_finalize_kernel(double* __restrict__ sums, int64_t n_rows, in
                                    float eps, float momentum, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, float* __restrict__ mean,
                                    float* __restrict__ invstd, float* __restrict__ scale,
-                                   float* __restrict__ shift) {
+                                   float* __restrict__ shift, int64_t* __restrict__ batches_tracked) {
+  // (nn.BatchNorm1d.num_batches_tracked of this layer: the step's counter launch, folded in)
+  if (batches_tracked != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *batches_tracked += 1;
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_feat; c += gridDim.x * blockDim.x) {
     const double n = (double)n_rows;
     double t1, t2;
@@ -256,7 +258,18 @@ bn_apply_kernel(const float* __restrict__ x, int64_t ldx, int64_t slots, int lpr
 __global__ void bn_bwd_params_kernel(double* __restrict__ sums, int64_t n_rows, int n_feat,
                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                      const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta, float* __restrict__ coef) {
+                                     float* __restrict__ dbeta, float* __restrict__ coef, double* __restrict__ loss_acc,
+                                     int loss_rep, float loss_inv_count, float* __restrict__ loss) {
+  // (the loss of the step: sum of the accumulator replicas the head kernel added into, left clean -- loss.hip's
+  // loss_finalize_kernel, folded into the launch that follows the head kernel anyway)
+  if (loss_acc != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < loss_rep; ++i) {
+      t += loss_acc[i];
+      loss_acc[i] = 0.0;
+    }
+    *loss = (float)(t * (double)loss_inv_count);
+  }
   const double inv_n = 1.0 / (double)n_rows;
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n_feat; c += gridDim.x * blockDim.x) {
     double db, dg;
@@ -395,7 +408,8 @@ static int launch_col_sums(int mode, const float* a, int64_t lda, const float* x
 int bn_stats_impl(const float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat,
                   const float* d_gamma, const float* d_beta, float eps, float momentum,
                   float* d_running_mean, float* d_running_var, float* d_mean, float* d_invstd,
-                  float* d_scale, float* d_shift, double* d_acc, bool acc_clean, void* stream) {
+                  float* d_scale, float* d_shift, double* d_acc, bool acc_clean, void* stream,
+                  int64_t* d_batches_tracked) {
   GCMI_CHECK_ARG(n_feat > 0 && n_rows > 0 && ldx >= n_feat, "bn_stats: bad shape (n_rows=%lld)",
                  (long long)n_rows);
   GCMI_CHECK_ARG(d_x && d_scale && d_shift && d_acc, "bn_stats: NULL buffer");
@@ -405,20 +419,20 @@ int bn_stats_impl(const float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat,
   if (rc) return rc;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((n_feat + 255) / 256), dim3(256), 0, st, d_acc, n_rows,
                      n_feat, d_gamma, d_beta, eps, momentum, d_running_mean, d_running_var, d_mean,
-                     d_invstd, d_scale, d_shift);
+                     d_invstd, d_scale, d_shift, d_batches_tracked);
   GCMI_CHECK_LAUNCH("bn_finalize");
   return GCMI_OK;
 }
 
 int bn_finalize_impl(int64_t n_rows, int32_t n_feat, const float* d_gamma, const float* d_beta, float eps,
                      float momentum, float* d_running_mean, float* d_running_var, float* d_mean, float* d_invstd,
-                     float* d_scale, float* d_shift, double* d_acc, void* stream) {
+                     float* d_scale, float* d_shift, double* d_acc, void* stream, int64_t* d_batches_tracked) {
   GCMI_CHECK_ARG(n_feat > 0 && n_rows > 0 && d_scale && d_shift && d_acc, "bn_finalize: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   TimedScope ts(GCMI_K_BATCHNORM, st);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((n_feat + 255) / 256), dim3(256), 0, st, d_acc, n_rows,
                      n_feat, d_gamma, d_beta, eps, momentum, d_running_mean, d_running_var, d_mean,
-                     d_invstd, d_scale, d_shift);
+                     d_invstd, d_scale, d_shift, d_batches_tracked);
   GCMI_CHECK_LAUNCH("bn_finalize");
   return GCMI_OK;
 }
@@ -633,12 +647,14 @@ int bn_bwd_pool_impl(const float* d_dy, int64_t lddy, const float* d_x, int64_t 
 }
 
 int bn_bwd_params_impl(int64_t n_rows, int32_t n_feat, const float* d_gamma, const float* d_mean,
-                       const float* d_invstd, float* d_dgamma, float* d_dbeta, double* d_acc, void* stream) {
+                       const float* d_invstd, float* d_dgamma, float* d_dbeta, double* d_acc, void* stream,
+                       double* d_loss_acc, int loss_rep, float loss_inv_count, float* d_loss) {
   GCMI_CHECK_ARG(n_feat > 0 && n_rows > 0 && d_mean && d_invstd && d_acc, "bn_bwd_params: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   TimedScope ts(GCMI_K_BATCHNORM, st);
   hipLaunchKernelGGL(bn_bwd_params_kernel, dim3((n_feat + 255) / 256), dim3(256), 0, st, d_acc, n_rows, n_feat,
-                     d_gamma, d_mean, d_invstd, d_dgamma, d_dbeta, reinterpret_cast<float*>(d_acc));
+                     d_gamma, d_mean, d_invstd, d_dgamma, d_dbeta, reinterpret_cast<float*>(d_acc), d_loss_acc, loss_rep,
+                     loss_inv_count, d_loss);
   GCMI_CHECK_LAUNCH("bn_bwd_params");
   return GCMI_OK;
 }
@@ -675,7 +691,7 @@ static int bn_bwd_any(const ReadoutGrad* rgp, const float* d_dy, int64_t lddy, c
   // coefficient vectors (3F floats) live in the first 2F doubles of the scratch
   float* coef = reinterpret_cast<float*>(d_acc);
   hipLaunchKernelGGL(bn_bwd_params_kernel, dim3((n_feat + 255) / 256), dim3(256), 0, st, d_acc, n_rows,
-                     n_feat, d_gamma, d_mean, d_invstd, d_dgamma, d_dbeta, coef);
+                     n_feat, d_gamma, d_mean, d_invstd, d_dgamma, d_dbeta, coef, nullptr, 0, 0.f, nullptr);
   GCMI_CHECK_LAUNCH("bn_bwd_params");
   if (d_dx) {
     ReadoutGrad rg{nullptr, nullptr, 0, nullptr};

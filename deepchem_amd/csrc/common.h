@@ -94,8 +94,10 @@ int bn_bwd_pool_impl(const float* d_dy, int64_t lddy, const float* d_x, int64_t 
 int win_gather_max_bwd_if_ill(const gcmi_graph* g, const float* d_dout, int64_t lddo, int n_feat, const uint8_t* d_arg,
                               float* d_dx, int64_t lddx, const float* d_gamma, const float* d_beta, hipStream_t st);
 // the part of the BatchNorm backward after its column sums (dgamma, dbeta, coefficient vectors at the head of d_acc)
+// (d_loss_acc: also *d_loss = inv_count * sum of the loss_rep accumulator replicas, cleared -- loss_finalize_impl folded in)
 int bn_bwd_params_impl(int64_t n_rows, int32_t n_feat, const float* d_gamma, const float* d_mean,
-                       const float* d_invstd, float* d_dgamma, float* d_dbeta, double* d_acc, void* stream);
+                       const float* d_invstd, float* d_dgamma, float* d_dbeta, double* d_acc, void* stream,
+                       double* d_loss_acc = nullptr, int loss_rep = 0, float loss_inv_count = 0.f, float* d_loss = nullptr);
 
 // ---- bf16 activation storage (gcmi_model_desc.storage == 1): raw 16-bit patterns, leading dimensions in elements
 bool win_usable_h(const gcmi_graph* g, int n_feat);
@@ -221,14 +223,14 @@ int readout_fwd_impl(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t
 // the part of bn_stats_impl after the column sums
 int bn_finalize_impl(int64_t n_rows, int32_t n_feat, const float* d_gamma, const float* d_beta, float eps,
                      float momentum, float* d_running_mean, float* d_running_var, float* d_mean, float* d_invstd,
-                     float* d_scale, float* d_shift, double* d_acc, void* stream);
+                     float* d_scale, float* d_shift, double* d_acc, void* stream, int64_t* d_batches_tracked = nullptr);
 
 // BatchNorm / loss with a caller-guaranteed clean accumulator scratch (bn.hip, loss.hip): the
 // whole-model path zeroes its scratch once per pass instead of once per call.
 int bn_stats_impl(const float* d_x, int64_t ldx, int64_t n_rows, int32_t n_feat, const float* d_gamma,
                   const float* d_beta, float eps, float momentum, float* d_running_mean,
                   float* d_running_var, float* d_mean, float* d_invstd, float* d_scale, float* d_shift,
-                  double* d_acc, bool acc_clean, void* stream);
+                  double* d_acc, bool acc_clean, void* stream, int64_t* d_batches_tracked = nullptr);
 int bn_bwd_impl(const float* d_dy, int64_t lddy, const float* d_x, int64_t ldx, int64_t n_rows,
                 int32_t n_feat, const float* d_gamma, const float* d_mean, const float* d_invstd,
                 float* d_dgamma, float* d_dbeta, float* d_dx, int64_t lddx, int32_t relu_mask,

@@ -10,9 +10,19 @@ namespace gcmi {
 
 constexpr int kMaxL = GCMI_MAX_CONV_LAYERS;
 
-__global__ void bias_pack_kernel(const float* __restrict__ b_list, int max_deg, int width,
-                                 float* __restrict__ bsum) {
+struct BiasLayers {  // the GraphConv layers' bias blocks: one launch packs (or unpacks) all of them (blockIdx.y = layer)
+  const float* src[kMaxL];
+  float* dst[kMaxL];
+  int width[kMaxL];
+};
+
+__global__ void bias_pack_kernel(BiasLayers bl, int max_deg) {
   // b_list: (2*max_deg+1, width) in reference order; bsum[d] = b_rel_d + b_self_d, bsum[0] = b_self_0
+  const int l = blockIdx.y;
+  const float* __restrict__ b_list = pick_n(bl.src, l);
+  float* __restrict__ bsum = pick_n(bl.dst, l);
+  const int width = pick_n(bl.width, l);
+  if (b_list == nullptr) return;
   const int n = (max_deg + 1) * width;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int d = i / width, c = i - d * width;
@@ -21,8 +31,12 @@ __global__ void bias_pack_kernel(const float* __restrict__ b_list, int max_deg, 
   }
 }
 
-__global__ void bias_unpack_kernel(const float* __restrict__ dbsum, int max_deg, int width,
-                                   float* __restrict__ db_list) {
+__global__ void bias_unpack_kernel(BiasLayers bl, int max_deg) {
+  const int l = blockIdx.y;
+  const float* __restrict__ dbsum = pick_n(bl.src, l);
+  float* __restrict__ db_list = pick_n(bl.dst, l);
+  const int width = pick_n(bl.width, l);
+  if (dbsum == nullptr) return;
   const int n = (2 * max_deg + 1) * width;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int k = i / width, c = i - k * width;
@@ -112,6 +126,30 @@ static Ws carve(const gcmi_model_desc* m, int64_t N, int64_t B, int64_t ld_featu
   w.z_end = off;
   w.total = off;
   return w;
+}
+
+// b_rel_d + b_self_d of every GraphConv layer (the products add ONE bias row per degree): one launch for all layers
+static int pack_biases(const gcmi_model_desc* m, const Ws& w, float* ws, const float* d_params, hipStream_t st) {
+  BiasLayers bl;
+  memset(&bl, 0, sizeof(bl));
+  for (int l = 0; l < m->n_layers; ++l) {
+    bl.src[l] = d_params + m->off_conv_b[l];
+    bl.dst[l] = ws + w.bsum[l];
+    bl.width[l] = m->conv_width[l];
+  }
+  hipLaunchKernelGGL(bias_pack_kernel, dim3(4, m->n_layers), dim3(256), 0, st, bl, m->max_deg);
+  GCMI_CHECK_LAUNCH("bias_pack");
+  return GCMI_OK;
+}
+
+// ... and the per-degree bias gradients back into the reference's (2 max_deg + 1) rows, for the layers whose block ran
+static int unpack_bias_grads(const gcmi_model_desc* m, const BiasLayers& bl, int n_layers, hipStream_t st) {
+  bool any = false;
+  for (int l = 0; l < n_layers; ++l) any = any || bl.src[l] != nullptr;
+  if (!any) return GCMI_OK;
+  hipLaunchKernelGGL(bias_unpack_kernel, dim3(4, n_layers), dim3(256), 0, st, bl, m->max_deg);
+  GCMI_CHECK_LAUNCH("bias_unpack");
+  return GCMI_OK;
 }
 
 // The task head's forward product: with more than 32 outputs on the prepared images (head_bwd.hip), which stay in the
@@ -243,13 +281,11 @@ static int model_forward_h(const gcmi_model_desc* m, const gcmi_graph* g, const 
   const bf16_t* xin = nullptr;
   int64_t ldin = 0;
   bool sum_done = false;  // S[l] was written by the fused pass of block l - 1
+  RUN(pack_biases(m, w, ws, d_params, st));
   for (int l = 0; l < L; ++l) {
     const int K = l == 0 ? m->n_feat_in : m->conv_width[l - 1];
     const int W = m->conv_width[l];
     const Segs sg = make_segs(g, K, W);
-    hipLaunchKernelGGL(bias_pack_kernel, dim3(4), dim3(256), 0, st, d_params + m->off_conv_b[l], m->max_deg, W,
-                       ws + w.bsum[l]);
-    GCMI_CHECK_LAUNCH("bias_pack");
     float* bnv = ws + w.bnv[l];
     float* scale = bnv + 2 * W;
     float* shift = bnv + 3 * W;
@@ -276,7 +312,7 @@ static int model_forward_h(const gcmi_model_desc* m, const gcmi_graph* g, const 
       if (training) {
         RUN(bn_finalize_impl(N, W, d_params + m->off_bn_gamma[l], d_params + m->off_bn_beta[l], m->bn_eps, m->bn_momentum,
                              io->d_bn_running_mean[l], io->d_bn_running_var[l], bnv, bnv + W, scale, shift,
-                             reinterpret_cast<double*>(ws + w.acc), stream));
+                             reinterpret_cast<double*>(ws + w.acc), stream, io->d_bn_batches_tracked[l]));
       } else {
         RUN(gcmi_bn_fold_eval(d_params + m->off_bn_gamma[l], d_params + m->off_bn_beta[l], io->d_bn_running_mean[l],
                               io->d_bn_running_var[l], m->bn_eps, W, scale, shift, stream));
@@ -317,7 +353,7 @@ static int model_forward_h(const gcmi_model_desc* m, const gcmi_graph* g, const 
     if (training) {
       RUN(bn_finalize_impl(N, D, d_params + m->off_bn_gamma[L], d_params + m->off_bn_beta[L], m->bn_eps, m->bn_momentum,
                            io->d_bn_running_mean[L], io->d_bn_running_var[L], bnvD, bnvD + D, scale, shift,
-                           reinterpret_cast<double*>(ws + w.acc), stream));
+                           reinterpret_cast<double*>(ws + w.acc), stream, io->d_bn_batches_tracked[L]));
     } else {
       RUN(gcmi_bn_fold_eval(d_params + m->off_bn_gamma[L], d_params + m->off_bn_beta[L], io->d_bn_running_mean[L],
                             io->d_bn_running_var[L], m->bn_eps, D, scale, shift, stream));
@@ -330,7 +366,7 @@ static int model_forward_h(const gcmi_model_desc* m, const gcmi_graph* g, const 
   const int32_t nB = (int32_t)B;
   RUN(head_forward(m, w, ws, d_params, io, B, stream));
   if (m->mode == 0 && io->d_probs) RUN(gcmi_softmax(io->d_logits, B * m->n_tasks, m->n_classes, io->d_probs, stream));
-  if (training) {
+  if (training && N == 0) {  // (with atoms, every layer's statistics launch bumps its own counter)
     CounterPtrs c;
     c.n = L + 1;
     bool any = false;
@@ -384,7 +420,9 @@ static int model_loss_backward_h(const gcmi_model_desc* m, const gcmi_graph* g, 
                                   D, st, ws + w.dlogits, w.himg >= 0 ? ws + w.himg : nullptr);
     if (rc == GCMI_OK) {
       head_sums = N > 0 && g->d_mol_runs != nullptr;
-      RUN(loss_finalize_impl(reinterpret_cast<double*>(ws + w.lacc), 1.f / (float)(n_rows * m->n_tasks), io->d_loss, stream, kLossRep));
+      // (with head_sums the loss is finalised by the BatchNorm parameter launch that follows)
+      if (!head_sums)
+        RUN(loss_finalize_impl(reinterpret_cast<double*>(ws + w.lacc), 1.f / (float)(n_rows * m->n_tasks), io->d_loss, stream, kLossRep));
     } else if (rc != GCMI_ERR_UNSUPPORTED) {
       return rc;
     } else {
@@ -407,7 +445,8 @@ static int model_loss_backward_h(const gcmi_model_desc* m, const gcmi_graph* g, 
   // ---- dense block: BatchNorm sums from per-molecule data, then one pass (dense and pool rows arrive as bf16)
   if (head_sums) {
     RUN(bn_bwd_params_impl(N, D, d_params + m->off_bn_gamma[L], bnvL, bnvL + D, d_grads + m->off_bn_gamma[L],
-                           d_grads + m->off_bn_beta[L], reinterpret_cast<double*>(ws + w.acc), stream));
+                           d_grads + m->off_bn_beta[L], reinterpret_cast<double*>(ws + w.acc), stream,
+                           reinterpret_cast<double*>(ws + w.lacc), kLossRep, 1.f / (float)(n_rows * m->n_tasks), io->d_loss));
   } else {
     // (the per-molecule sums kernel reads rawsum, never the atom rows: the bf16 matrix is only passed through)
     RUN(bn_bwd_readout_impl(g->d_membership, ws + w.dfp, 2 * D, reinterpret_cast<const int32_t*>(ws + w.arg_r),
@@ -427,6 +466,8 @@ static int model_loss_backward_h(const gcmi_model_desc* m, const gcmi_graph* g, 
   }
   // ---- GraphConv / BatchNorm / GraphPool blocks, last to first (gradient streams fp32: the window kernels as they are)
   bool dy_ready = false;
+  BiasLayers ub;
+  memset(&ub, 0, sizeof(ub));
   for (int l = L - 1; l >= 0; --l) {
     const int W = m->conv_width[l];
     const int K = l == 0 ? m->n_feat_in : m->conv_width[l - 1];
@@ -468,9 +509,9 @@ static int model_loss_backward_h(const gcmi_model_desc* m, const gcmi_graph* g, 
       if (rc == GCMI_ERR_UNSUPPORTED) set_error("bf16 activation storage: GraphConv %d has no one-pass backward", l);
       RUN(rc);
     }
-    hipLaunchKernelGGL(bias_unpack_kernel, dim3(4), dim3(256), 0, st, ws + w.dbsum[l], m->max_deg, W,
-                       d_grads + m->off_conv_b[l]);
-    GCMI_CHECK_LAUNCH("bias_unpack");
+    ub.src[l] = ws + w.dbsum[l];  // (unpacked into the reference's bias rows in one launch after the loop)
+    ub.dst[l] = d_grads + m->off_conv_b[l];
+    ub.width[l] = W;
     if (l == 0) break;  // the atom features need no gradient
     // dX holds the self part; the neighbour part is added onto it, and where the window kernels can hold a third tile
     // the GraphPool backward of the block below runs in the same pass
@@ -492,6 +533,7 @@ static int model_loss_backward_h(const gcmi_model_desc* m, const gcmi_graph* g, 
     }
     dpool = dX;
   }
+  RUN(unpack_bias_grads(m, ub, L, st));
   return GCMI_OK;
 }
 
@@ -531,14 +573,12 @@ int gcmi_model_forward(const gcmi_model_desc* m, const gcmi_graph* g, const floa
     return GCMI_ERR_LAUNCH;
   }
   bool stats_fused = false;
+  RUN(pack_biases(m, w, ws, d_params, st));
   for (int l = 0; l < L; ++l) {
     const int K = l == 0 ? m->n_feat_in : m->conv_width[l - 1];
     const int W = m->conv_width[l];
     const Segs sg = make_segs(g, K, W);
     stats_fused = false;
-    hipLaunchKernelGGL(bias_pack_kernel, dim3(4), dim3(256), 0, st, d_params + m->off_conv_b[l],
-                       m->max_deg, W, ws + w.bsum[l]);
-    GCMI_CHECK_LAUNCH("bias_pack");
     if (N > 0) {
       RUN(gcmi_gather_sum_fwd(g, x, ldx, (int32_t)w.ngather[l], ws + w.S[l], w.ldS[l], 0, stream));
       // training with BatchNorm: the product's epilogue also adds the column sums of its output into the
@@ -558,12 +598,12 @@ int gcmi_model_forward(const gcmi_model_desc* m, const gcmi_graph* g, const floa
       if (training && stats_fused) {
         RUN(bn_finalize_impl(N, W, d_params + m->off_bn_gamma[l], d_params + m->off_bn_beta[l], m->bn_eps,
                              m->bn_momentum, io->d_bn_running_mean[l], io->d_bn_running_var[l], bnv, bnv + W,
-                             scale, shift, reinterpret_cast<double*>(ws + w.acc), stream));
+                             scale, shift, reinterpret_cast<double*>(ws + w.acc), stream, io->d_bn_batches_tracked[l]));
       } else if (training) {
         RUN(bn_stats_impl(ws + w.gc[l], W, N, W, d_params + m->off_bn_gamma[l],
                           d_params + m->off_bn_beta[l], m->bn_eps, m->bn_momentum,
                           io->d_bn_running_mean[l], io->d_bn_running_var[l], bnv, bnv + W, scale, shift,
-                          reinterpret_cast<double*>(ws + w.acc), true, stream));
+                          reinterpret_cast<double*>(ws + w.acc), true, stream, io->d_bn_batches_tracked[l]));
       } else {
         RUN(gcmi_bn_fold_eval(d_params + m->off_bn_gamma[l], d_params + m->off_bn_beta[l],
                               io->d_bn_running_mean[l], io->d_bn_running_var[l], m->bn_eps, W, scale,
@@ -596,11 +636,12 @@ int gcmi_model_forward(const gcmi_model_desc* m, const gcmi_graph* g, const floa
     if (training && stats_fused) {
       RUN(bn_finalize_impl(N, D, d_params + m->off_bn_gamma[L], d_params + m->off_bn_beta[L], m->bn_eps,
                            m->bn_momentum, io->d_bn_running_mean[L], io->d_bn_running_var[L], bnv, bnv + D, scale,
-                           shift, reinterpret_cast<double*>(ws + w.acc), stream));
+                           shift, reinterpret_cast<double*>(ws + w.acc), stream, io->d_bn_batches_tracked[L]));
     } else if (training) {
       RUN(bn_stats_impl(ws + w.dense, D, N, D, d_params + m->off_bn_gamma[L], d_params + m->off_bn_beta[L],
                         m->bn_eps, m->bn_momentum, io->d_bn_running_mean[L], io->d_bn_running_var[L], bnv,
-                        bnv + D, scale, shift, reinterpret_cast<double*>(ws + w.acc), true, stream));
+                        bnv + D, scale, shift, reinterpret_cast<double*>(ws + w.acc), true, stream,
+                        io->d_bn_batches_tracked[L]));
     } else {
       RUN(gcmi_bn_fold_eval(d_params + m->off_bn_gamma[L], d_params + m->off_bn_beta[L],
                             io->d_bn_running_mean[L], io->d_bn_running_var[L], m->bn_eps, D, scale, shift,
@@ -615,7 +656,7 @@ int gcmi_model_forward(const gcmi_model_desc* m, const gcmi_graph* g, const floa
   RUN(head_forward(m, w, ws, d_params, io, B, stream));
   if (m->mode == 0 && io->d_probs)
     RUN(gcmi_softmax(io->d_logits, B * m->n_tasks, m->n_classes, io->d_probs, stream));
-  if (training && m->batch_norm) {
+  if (training && m->batch_norm && N == 0) {  // (with atoms, every layer's statistics launch bumps its own counter)
     CounterPtrs c;
     c.n = L + 1;
     bool any = false;
@@ -688,8 +729,10 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
     if (rc == GCMI_OK) {
       head_done = true;
       head_sums = dense_fused_next && g->d_mol_runs != nullptr;
-      RUN(loss_finalize_impl(reinterpret_cast<double*>(ws + w.lacc), 1.f / (float)(n_rows * m->n_tasks), io->d_loss,
-                             stream, kLossRep));
+      // (with head_sums the loss is finalised by the BatchNorm parameter launch that follows)
+      if (!head_sums)
+        RUN(loss_finalize_impl(reinterpret_cast<double*>(ws + w.lacc), 1.f / (float)(n_rows * m->n_tasks), io->d_loss,
+                               stream, kLossRep));
     } else if (rc != GCMI_ERR_UNSUPPORTED) {
       return rc;
     }
@@ -723,10 +766,15 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
     if (!head_done) RUN(readout_grad_prep(ws + w.dfp, 2 * D, io->d_fingerprint, 2 * D, B, D, st));
     const float* bnv = ws + w.bnv[L];
     const bool try_fused = fused_bwd_enabled() && D == 128 && Wl > 32 && Wl <= 64;
+    if (head_sums && !try_fused)  // (cannot happen: head_sums is computed from the same conditions)
+      RUN(loss_finalize_impl(reinterpret_cast<double*>(ws + w.lacc), 1.f / (float)(n_rows * m->n_tasks), io->d_loss,
+                             stream, kLossRep));
     if (head_sums && try_fused) {
       // the sums are in place (head_bwd.hip): dgamma, dbeta and the coefficient vectors
       RUN(bn_bwd_params_impl(N, D, d_params + m->off_bn_gamma[L], bnv, bnv + D, d_grads + m->off_bn_gamma[L],
-                             d_grads + m->off_bn_beta[L], reinterpret_cast<double*>(ws + w.acc), stream));
+                             d_grads + m->off_bn_beta[L], reinterpret_cast<double*>(ws + w.acc), stream,
+                             reinterpret_cast<double*>(ws + w.lacc), kLossRep, 1.f / (float)(n_rows * m->n_tasks),
+                             io->d_loss));
     } else {
       RUN(bn_bwd_readout_impl(g->d_membership, ws + w.dfp, 2 * D, reinterpret_cast<const int32_t*>(ws + w.arg_r),
                               ws + w.dense, D, N, D, d_params + m->off_bn_gamma[L], bnv, bnv + D,
@@ -768,6 +816,8 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
                       nullptr, nullptr, nullptr, Wl, 0, 0, dpool, Wl, stream));
   }
   // ---- GraphConv / BatchNorm / GraphPool blocks, last to first
+  BiasLayers ub;
+  memset(&ub, 0, sizeof(ub));
   for (int l = L - 1; l >= 0; --l) {
     if (!full && !m->batch_norm) break;  // nothing trainable in front of the dense layer
     const int W = m->conv_width[l];
@@ -864,9 +914,9 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
       RUN(gcmi_seg_gemm_wgrad(sg.n, sg.begin, sg.end, xin, ldx, K, dgc, W, W, d_grads + m->off_conv_w[l],
                               sg.w_self, ws + w.dbsum[l], sg.b_off, 0, stream));
     }
-    hipLaunchKernelGGL(bias_unpack_kernel, dim3(4), dim3(256), 0, st, ws + w.dbsum[l], m->max_deg, W,
-                       d_grads + m->off_conv_b[l]);
-    GCMI_CHECK_LAUNCH("bias_unpack");
+    ub.src[l] = ws + w.dbsum[l];  // (unpacked into the reference's bias rows in one launch after the loop)
+    ub.dst[l] = d_grads + m->off_conv_b[l];
+    ub.width[l] = W;
     if (l == 0) break;  // the atom features need no gradient
     // dS = dgc . W_rel^T ; dX = dgc . W_self^T + (transposed gather of dS)
     if (fused_done) {
@@ -895,6 +945,7 @@ int gcmi_model_loss_backward(const gcmi_model_desc* m, const gcmi_graph* g, cons
     }
     dpool = dX;
   }
+  RUN(unpack_bias_grads(m, ub, L, st));
   return GCMI_OK;
 }
 
