@@ -855,6 +855,13 @@ static void head_diag_print(const char* what, int kern, hipStream_t st) {
 #define HD_PRINT(what, kern, st) do { } while (0)
 #endif
 
+// fewest outputs that take the matrix-core head kernels (GCMI_HEAD_WIDE_MIN; default 33: up to 32 outputs head_bwd_kernel
+// keeps a thread's column of the head matrix in registers)
+static int head_wide_min() {
+  static const int v = getenv("GCMI_HEAD_WIDE_MIN") ? atoi(getenv("GCMI_HEAD_WIDE_MIN")) : kHT + 1;
+  return v < 1 ? 1 : v;
+}
+
 static bool head_wide_enabled() {
   static const bool on = !(getenv("GCMI_HEAD_WIDE") && atoi(getenv("GCMI_HEAD_WIDE")) == 0);
   return on && !gemm_exact_mode();
@@ -862,7 +869,7 @@ static bool head_wide_enabled() {
 
 // the two fragment images of the head matrix (kHeadImgFloats floats at d_img); GCMI_ERR_UNSUPPORTED: outside 33..256 outputs
 int head_prep(const float* d_w, int32_t n_out, float* d_img, hipStream_t st) {
-  if (!head_wide_enabled() || n_out <= kHT || n_out > kWTC || d_img == nullptr || !aligned16(d_w) || !aligned16(d_img))
+  if (!head_wide_enabled() || n_out < head_wide_min() || n_out > kWTC || d_img == nullptr || !aligned16(d_w) || !aligned16(d_img))
     return GCMI_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(head_prep_kernel, dim3(2 * kImgTiles * kImgKs * 64 / 256), dim3(256), 0, st, d_w, n_out,
                      reinterpret_cast<u32x4*>(d_img));
@@ -874,7 +881,7 @@ int head_prep(const float* d_w, int32_t n_out, float* d_img, hipStream_t st) {
 // d_img: the images head_prep made of THIS d_w (the forward one is read), or nullptr: the weights are split per workgroup
 int head_fwd_wide(const float* d_in, int64_t ldin, int64_t n_rows, int32_t k, const float* d_w, const float* d_bias,
                   int32_t n_out, int32_t act, float* d_out, int64_t ldo, hipStream_t st, const float* d_img) {
-  if (!head_wide_enabled() || k != kHB || n_out <= kHT || n_out > kWTC || act != 0 || ldin % 4 != 0 || !aligned16(d_in) ||
+  if (!head_wide_enabled() || k != kHB || n_out < head_wide_min() || n_out > kWTC || act != 0 || ldin % 4 != 0 || !aligned16(d_in) ||
       !aligned16(d_w) || n_rows <= 0)
     return GCMI_ERR_UNSUPPORTED;
   if (d_img != nullptr) {
@@ -912,7 +919,7 @@ int head_bwd_fused(int32_t kind, const float* d_logits, const float* d_labels, c
   static const bool on = !(getenv("GCMI_FUSED_HEAD") && atoi(getenv("GCMI_FUSED_HEAD")) == 0);
   const int tc = n_tasks * (kind == 0 ? n_classes : 1);
   if (!on || !fused_bwd_enabled() || 2 * dense_width != kHB || tc < 1 || n_mols <= 0) return GCMI_ERR_UNSUPPORTED;
-  const bool wide = tc > kHT;
+  const bool wide = tc > kHT || (tc >= head_wide_min() && d_dl_scratch != nullptr && d_img != nullptr && head_wide_enabled());
   if (wide && (tc > kWTC || d_dl_scratch == nullptr || d_img == nullptr || !head_wide_enabled() || ldfp % 4 != 0 ||
                !aligned16(d_fp)))
     return GCMI_ERR_UNSUPPORTED;

@@ -108,7 +108,7 @@ static Ws carve(const gcmi_model_desc* m, int64_t N, int64_t B, int64_t ld_featu
   const int64_t D = m->dense_width;
   const int64_t TC = (int64_t)m->n_tasks * m->n_classes;
   w.bnv[L] = take(4 * D);
-  w.himg = (TC > 32 && TC <= 256 && 2 * D == 256) ? take(kHeadImgFloats) : -1;
+  w.himg = (TC <= 256 && 2 * D == 256) ? take(kHeadImgFloats) : -1;  // (786 KB; used from head_wide_min() outputs on)
   w.dense = take_act(N, D);
   w.arg_r = take(B * D);
   w.rsum = take(2 * B * D);  // per-molecule [row sums | arg-max row value] of the dense output (BatchNorm backward)
