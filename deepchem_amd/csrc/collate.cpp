@@ -53,6 +53,7 @@ struct BatchPlan {
   int64_t n_atoms = 0, n_edges = 0, win_entries = 0;
   bool want_win = false;
   int32_t n_win_big = 0, win_alloc = 0, win_ecap = 0, win_alloc_big = 0, win_ecap_big = 0;
+  int32_t n_mols_with_atoms = 0;  // -> gcmi_graph.win_reserved[0]: every molecule of a window pass is one of these
 };
 
 // hist: n_sel x ND degree histograms in batch order.  out_win_meta (n_win descriptors) is written when windows are
@@ -107,10 +108,12 @@ int plan_serial(const int32_t* hist_p, int64_t n_sel, int n_deg, int32_t win_cap
     int64_t cursor[ND];
     for (int d = 0; d < ND; ++d) cursor[d] = deg_start[d];
     int64_t in_win = 0;
+    int32_t with_atoms = 0;
     for (int64_t p = 0; p < n_sel; ++p) {
       const int32_t* hp = hist_p + (size_t)p * ND;
       int64_t sz = 0;
       for (int d = 0; d < ND; ++d) sz += hp[d];
+      with_atoms += sz > 0 ? 1 : 0;
       if (want_win) {
         if (p == 0 || in_win + sz > win_cap) {  // open a new window at molecule p
           Win w;
@@ -134,6 +137,7 @@ int plan_serial(const int32_t* hist_p, int64_t n_sel, int n_deg, int32_t win_cap
       }
       for (int d = n_deg; d < ND; ++d) bp[d] = 0;
     }
+    P.n_mols_with_atoms = with_atoms;
     // close the windows: counts -> prefixes, edge offsets (every window padded to 8 entries = 16 B).
     // Descriptors are emitted with the ordinary windows first and the oversized ones (a single
     // molecule above win_cap) last, so the kernels can give the two classes different LDS shapes.
@@ -180,6 +184,7 @@ int plan_serial(const int32_t* hist_p, int64_t n_sel, int n_deg, int32_t win_cap
   P.n_edges = n_edges;
   P.want_win = want_win;
   P.n_win_big = n_win_big;
+  P.n_mols_with_atoms = P.wins.empty() ? 0 : P.n_mols_with_atoms;
   P.win_alloc = win_alloc;
   P.win_ecap = win_ecap;
   P.win_alloc_big = win_alloc_big;
@@ -372,7 +377,8 @@ int gcmi_collate_plans(const float* atom_features, int64_t n_feat, const int64_t
   graph->win_ecap = want_win ? win_ecap : 0;
   graph->win_alloc_big = want_win ? win_alloc_big : 0;
   graph->win_ecap_big = want_win ? win_ecap_big : 0;
-  graph->win_reserved[0] = graph->win_reserved[1] = 0;
+  graph->win_reserved[0] = want_win ? P.n_mols_with_atoms : 0;  // molecules the windows cover (readout over windows)
+  graph->win_reserved[1] = 0;
   graph->d_win_meta = nullptr;
   graph->d_win_edges = nullptr;
   return GCMI_OK;
@@ -749,7 +755,8 @@ int gcmi_collate_plan(const int32_t* mol_hist, const int64_t* atom_ptr, const in
   graph->win_ecap = P.want_win ? P.win_ecap : 0;
   graph->win_alloc_big = P.want_win ? P.win_alloc_big : 0;
   graph->win_ecap_big = P.want_win ? P.win_ecap_big : 0;
-  graph->win_reserved[0] = graph->win_reserved[1] = 0;
+  graph->win_reserved[0] = P.want_win ? P.n_mols_with_atoms : 0;  // molecules the windows cover (readout over windows)
+  graph->win_reserved[1] = 0;
   graph->d_win_meta = nullptr;
   graph->d_win_edges = nullptr;
   return GCMI_OK;

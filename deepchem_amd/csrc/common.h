@@ -217,6 +217,9 @@ int seg_gemm_stats(int32_t n_seg, const int32_t* seg_begin, const int32_t* seg_e
                    int32_t n_out, int32_t trans_w, int32_t act, float* d_out, int64_t ldo, double* d_stats,
                    bool* fused, void* stream, float* d_wimg_scratch = nullptr);
 // gcmi_readout_fwd that also leaves the per-molecule sums of the rows before the folded BatchNorm in d_rawsum
+// GraphGather forward over the LDS molecule windows (gather_lds.hip: ReadoutOp); GCMI_ERR_UNSUPPORTED: not applicable
+int win_readout(const gcmi_graph* g, const float* d_x, int64_t ldx, int n_feat, const float* d_scale, const float* d_shift,
+                int act, float* d_out, int64_t ldo, int32_t* d_arg, float* d_rawsum, int x_bf16, hipStream_t st);
 int readout_fwd_impl(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t n_feat, const float* d_scale,
                      const float* d_shift, int32_t act, float* d_out, int64_t ldo, int32_t* d_arg, float* d_rawsum,
                      void* stream, int32_t x_bf16 = 0);

@@ -964,6 +964,119 @@ struct SumAccMaxBwdOpH {
 // ---------------------------------------------------------------- the persistent window walker
 // Workgroups [0, g_norm) walk the ordinary windows double-buffered; workgroups [g_norm, gridDim)
 // walk the oversized windows (one big molecule each) using both buffers as one.
+// GraphGather over the windows: out[b] = act([sum over the atoms of molecule b | max over them]) of the (folded-BatchNorm)
+// rows (layers.py:6450-6479), with the arg-max rows and the raw sums the BatchNorm backward wants -- what
+// readout_fwd_kernel (readout.hip) computes walking a molecule's <= 11 row runs in HBM, at 3.3 TB/s.  A window holds
+// WHOLE molecules, so once its rows are in LDS every molecule of it is reduced from LDS: a thread = (molecule, 16-byte
+// column piece), the molecule's rows in ascending row order (degree block by degree block: the order of
+// readout_fwd_kernel, so sums are bit-identical and the first maximum wins as there).  The molecules of a window are
+// the membership of its first and last rows; their row runs come from d_mol_runs.  (Those few global loads sit in the
+// compute phase and wait behind the next window's DMA like the kPre loads of the accumulating ops.)
+// F = the row width the outputs are laid out for; the tile holds the columns [col0, col0 + LPR * kEPP) of the rows (fp32
+// rows of 128 columns do not fit two window buffers: two passes of 64).
+template <bool BN, bool HB>
+struct ReadoutOp {
+  const float* __restrict__ scale;
+  const float* __restrict__ shift;
+  const int32_t* __restrict__ runs;
+  const int32_t* __restrict__ membership;
+  int n_deg, act, F, col0;
+  float* __restrict__ out;
+  int64_t ldo;
+  int32_t* __restrict__ arg;
+  float* __restrict__ rawsum;
+  static constexpr bool kExtraTile = false;
+  static constexpr int kEPP = HB ? 8 : 4;
+  using State = NoState;
+  __device__ __forceinline__ bool skip(int) const { return false; }
+  template <int WT>
+  __device__ __forceinline__ void init(float* sh_lds, int n_cols, State&) const {
+    if (BN)
+      for (int i = threadIdx.x; i < n_cols; i += WT) {
+        sh_lds[i] = scale[col0 + i];
+        sh_lds[256 + i] = shift[col0 + i];
+      }
+  }
+  template <int WT>
+  __device__ __forceinline__ void finish(char*, int, State&) const {}
+  template <int WT, int LPR>
+  __device__ __forceinline__ void run(const char* buf, const Layout& L, const WinMeta& m, const float* sh_lds, State&) const {
+    constexpr int V = kEPP;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    // the window's molecules
+    int m0 = INT_MAX, m1 = -1;
+#pragma unroll
+    for (int d = 0; d < kND; ++d) {
+      if (d <= L.maxd && m.sb[d + 1] > m.sb[d]) {
+        const int a = membership[m.rb[d] + m.sb[d]], b = membership[m.rb[d] + m.sb[d + 1] - 1];
+        m0 = a < m0 ? a : m0;
+        m1 = b > m1 ? b : m1;
+      }
+    }
+    const int n_items = (m1 - m0 + 1) * LPR;
+    for (int e = threadIdx.x; e < n_items; e += WT) {
+      const int mi = e / LPR;
+      const int c = e - mi * LPR;
+      const int b = m0 + mi;
+      const int2* rb = reinterpret_cast<const int2*>(runs + (int64_t)b * n_deg * 2);
+      int2 run[kND];
+#pragma unroll
+      for (int d = 0; d < kND; ++d) run[d] = d < n_deg ? rb[d] : make_int2(0, 0);
+      float sc[V], sh[V], sum[V], mx[V], raw[V], rawmx[V];
+      int am[V];
+#pragma unroll
+      for (int q = 0; q < V; ++q) {
+        sc[q] = BN ? sh_lds[c * V + q] : 1.f;
+        sh[q] = BN ? sh_lds[256 + c * V + q] : 0.f;
+        raw[q] = 0.f; rawmx[q] = 0.f; sum[q] = 0.f;
+        mx[q] = -INFINITY;
+        am[q] = -1;
+      }
+#pragma unroll
+      for (int d = 0; d < kND; ++d) {
+        for (int r = run[d].x; r < run[d].y; ++r) {
+          const int slot = r - m.rb[d];
+          float v[V];
+          if constexpr (HB) {
+            widen8(reinterpret_cast<const uint4*>(buf)[slot * LPR + c], v);
+          } else {
+            const float4 t = reinterpret_cast<const float4*>(buf)[slot * LPR + c];
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+          }
+#pragma unroll
+          for (int q = 0; q < V; ++q) {
+            const float a = BN ? fmaf(v[q], sc[q], sh[q]) : v[q];
+            raw[q] += v[q];
+            sum[q] += a;
+            if (a > mx[q]) { mx[q] = a; am[q] = r; rawmx[q] = v[q]; }
+          }
+        }
+      }
+      float* o = out + (int64_t)b * ldo + col0 + c * V;
+#pragma unroll
+      for (int h = 0; h < V / 4; ++h) {
+        f32x4 so, mo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          so[q] = act == 1 ? tanhf(sum[4 * h + q]) : sum[4 * h + q];
+          mo[q] = act == 1 ? tanhf(mx[4 * h + q]) : mx[4 * h + q];
+        }
+        *reinterpret_cast<f32x4*>(o + 4 * h) = so;
+        *reinterpret_cast<f32x4*>(o + F + 4 * h) = mo;
+        if (arg)
+          *reinterpret_cast<i32x4*>(arg + (int64_t)b * F + col0 + c * V + 4 * h) =
+              i32x4{am[4 * h], am[4 * h + 1], am[4 * h + 2], am[4 * h + 3]};
+        if (rawsum) {  // [sum of the rows | value of the arg-max row], both BEFORE the folded BatchNorm
+          float* rs = rawsum + (int64_t)b * 2 * F + col0 + c * V + 4 * h;
+          *reinterpret_cast<f32x4*>(rs) = f32x4{raw[4 * h], raw[4 * h + 1], raw[4 * h + 2], raw[4 * h + 3]};
+          *reinterpret_cast<f32x4*>(rs + F) = f32x4{rawmx[4 * h], rawmx[4 * h + 1], rawmx[4 * h + 2], rawmx[4 * h + 3]};
+        }
+      }
+    }
+  }
+};
+
 template <int WT, int LPR, bool AUX, class Op>
 __global__ void __launch_bounds__(WT)
 win_kernel(const int32_t* __restrict__ meta, const uint16_t* __restrict__ edges, int n_norm, int n_win,
@@ -1173,6 +1286,47 @@ static int launch_h(const gcmi_graph* g, int n_feat, const bf16_t* x, int64_t ld
   }
   set_error("%s: no bf16 window kernel for %d features", what, n_feat);
   return GCMI_ERR_UNSUPPORTED;
+}
+
+// GraphGather forward over the windows (ReadoutOp): GCMI_ERR_UNSUPPORTED where the window form does not apply -- no
+// window plan, molecules without atoms (the plan says how many molecules its windows cover: gcmi_graph.win_reserved[0]),
+// other widths than 128 columns -- and the caller walks the row runs instead (readout.hip).
+int win_readout(const gcmi_graph* g, const float* d_x, int64_t ldx, int n_feat, const float* d_scale, const float* d_shift,
+                int act, float* d_out, int64_t ldo, int32_t* d_arg, float* d_rawsum, int x_bf16, hipStream_t st) {
+  // Kept, OFF (GCMI_READOUT_WINDOWS=1 turns it on; results identical, tests pass with it): measured 311 + 297 us for the
+  // two fp32 passes against readout_fwd_kernel's 187, and 737 us against 130 on bf16 rows.  A window is ~25 molecules, so
+  // the compute phase has 25 x 16 serial chains of ~18 rows for 512 threads at ONE workgroup per CU (LDS), and its
+  // run-bound loads wait behind the next window's DMA; the row-run walk keeps thousands of molecules in flight per CU.
+  static const bool on = getenv("GCMI_READOUT_WINDOWS") && atoi(getenv("GCMI_READOUT_WINDOWS")) == 1;
+  if (!on || n_feat != 128 || g->win_reserved[0] != g->n_mols || g->n_mols <= 0 || g->d_membership == nullptr ||
+      g->d_mol_runs == nullptr || (reinterpret_cast<uintptr_t>(g->d_mol_runs) & 7u) || ldo % 4 || !aligned16(d_out) ||
+      (d_arg && !aligned16(d_arg)) || (d_rawsum && !aligned16(d_rawsum)))
+    return GCMI_ERR_UNSUPPORTED;
+  const bool bn = d_scale != nullptr;
+  if (x_bf16) {
+    if (!win_usable_h(g, 128) || (reinterpret_cast<uintptr_t>(d_x) & 15u) || ldx % 8) return GCMI_ERR_UNSUPPORTED;
+    const bf16_t* xh = reinterpret_cast<const bf16_t*>(d_x);
+    if (bn) {
+      ReadoutOp<true, true> op{d_scale, d_shift, g->d_mol_runs, g->d_membership, g->max_deg + 1, act, 128, 0, d_out, ldo, d_arg, d_rawsum};
+      return launch_h<ReadoutOp<true, true>>(g, 128, xh, ldx, op, st, "win_readout");
+    }
+    ReadoutOp<false, true> op{nullptr, nullptr, g->d_mol_runs, g->d_membership, g->max_deg + 1, act, 128, 0, d_out, ldo, d_arg, d_rawsum};
+    return launch_h<ReadoutOp<false, true>>(g, 128, xh, ldx, op, st, "win_readout");
+  }
+  // fp32 rows: two passes of 64 columns (512-byte rows do not fit two window buffers)
+  if (!win_usable(g, 64, false) || !aligned16(d_x) || ldx % 4) return GCMI_ERR_UNSUPPORTED;
+  for (int col0 = 0; col0 < 128; col0 += 64) {
+    int rc;
+    if (bn) {
+      ReadoutOp<true, false> op{d_scale, d_shift, g->d_mol_runs, g->d_membership, g->max_deg + 1, act, 128, col0, d_out, ldo, d_arg, d_rawsum};
+      rc = launch<false, ReadoutOp<true, false>>(g, 64, d_x + col0, ldx, nullptr, op, st, "win_readout");
+    } else {
+      ReadoutOp<false, false> op{nullptr, nullptr, g->d_mol_runs, g->d_membership, g->max_deg + 1, act, 128, col0, d_out, ldo, d_arg, d_rawsum};
+      rc = launch<false, ReadoutOp<false, false>>(g, 64, d_x + col0, ldx, nullptr, op, st, "win_readout");
+    }
+    if (rc) return rc;
+  }
+  return GCMI_OK;
 }
 
 bool win_has_width(int n_feat) { return n_feat == 64 || n_feat == 76 || n_feat == 128; }

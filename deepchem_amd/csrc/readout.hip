@@ -400,6 +400,10 @@ int readout_fwd_impl(const gcmi_graph* g, const float* d_x, int64_t ldx, int32_t
                           ? 1
                           : 0;
   TimedScope ts(GCMI_K_READOUT, st);
+  if (g->n_atoms > 0) {  // the window form where it applies (rows staged once through LDS, molecules reduced there)
+    const int wrc = win_readout(g, d_x, ldx, n_feat, d_scale, d_shift, act, d_out, ldo, d_arg, d_rawsum, x_bf16, st);
+    if (wrc != GCMI_ERR_UNSUPPORTED) return wrc;
+  }
   // run bounds in registers + two rounds in flight: lane groups of whole power-of-two size inside one wave that
   // can hold one run per lane (GCMI_OPT_READOUT_PIPELINED / GCMI_READOUT_PRE=0: the plain walk)
   const bool pre = get_readout_pipelined() != 0 && V == 4 && g->n_atoms > 0 && gl == lpr && gl >= n_deg && gl <= 64 && (gl & (gl - 1)) == 0 &&

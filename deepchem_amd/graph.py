@@ -140,6 +140,7 @@ class BatchGraph:
         self.win_meta, self.win_edges = win_meta, win_edges
         for f in ("n_win", "n_win_big", "win_alloc", "win_ecap", "win_alloc_big", "win_ecap_big"):
             setattr(self.c, f, int(getattr(plan, f)))
+        self.c.win_reserved[0] = int(plan.win_reserved[0])  # molecules the windows cover (GraphGather over the windows)
         self.c.d_win_meta = win_meta.data_ptr()
         self.c.d_win_edges = win_edges.data_ptr()
 
