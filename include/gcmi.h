@@ -97,7 +97,9 @@ typedef struct gcmi_graph {
   int32_t win_ecap;                     /* its padded edge entries (largest)          */
   int32_t win_alloc_big;                /* the same for the oversized windows         */
   int32_t win_ecap_big;
-  int32_t win_reserved[2];
+  int32_t win_reserved[2];              /* [0]: molecules with at least one atom among the collated ones (filled by
+                                           gcmi_collate / gcmi_collate_plans with the windows; 0 = unknown): when it
+                                           equals n_mols every molecule lies in some window; [1]: 0 */
   const int32_t* d_win_meta;            /* n_win * GCMI_WIN_META_INTS                */
   const uint16_t* d_win_edges;          /* <= E + 8 * n_win                          */
 } gcmi_graph;
