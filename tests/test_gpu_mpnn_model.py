@@ -204,3 +204,33 @@ def test_mpnn_regression_uncertainty():
         MPNNModel(1, uncertainty=True)
     with pytest.raises(ValueError, match="only supported in regression"):
         MPNNModel(1, mode="classification", uncertainty=True, dropout=0.1)
+
+
+def test_flat_step_equals_the_per_tensor_step():
+    """The flat step (parameters / gradients / Adam moments in three flat buffers, weight gradients accumulated in place
+    by the kernels, one Adam launch: TorchModel._ensure_built, ops.direct_param_grads) against the per-tensor path
+    (autograd accumulates, one Adam launch per tensor): same losses and parameters after three steps, up to the order
+    in which a shared weight's T per-round gradients are added."""
+    import deepchem_amd as dc
+    B, d, T, M, n_tasks = 5, 32, 3, 3, 2
+    mols = qm9_like(15, 20, 6, seed=8)
+    rng = np.random.RandomState(9)
+    ds = dc.data.NumpyDataset(mols, rng.randn(15, n_tasks), np.ones((15, n_tasks)))
+    out = []
+    for flat in (True, False):
+        model = build("regression", T, M, d, B, n_tasks, seed=7)
+        model._flat_step = flat
+        losses = []
+        model.fit(ds, nb_epoch=1, deterministic=True, checkpoint_interval=0,
+                  callbacks=[lambda m, s, iteration_loss=None: losses.append(float(iteration_loss))])
+        assert (getattr(model, "_grad_arena", None) is not None) == flat
+        if flat:
+            assert model._grad_arena.params_homed() and model._pytorch_optimizer._flat is not None
+            steps = {float(st["step"]) for st in model._pytorch_optimizer.state.values() if "step" in st}
+            assert steps == {3.0}
+        out.append((losses, {k: v.detach().cpu().clone() for k, v in model.model.state_dict().items()}))
+    assert np.allclose(out[0][0], out[1][0], rtol=1e-5), (out[0][0], out[1][0])
+    for k in out[0][1]:
+        a, b = out[0][1][k].double(), out[1][1][k].double()
+        # (three Adam steps of lr 1e-3: an entry whose gradient is at rounding level may step the other way)
+        assert float((a - b).abs().max()) <= 2.2e-3 * 3 and float((a - b).abs().median()) <= 1e-5 * max(1.0, float(b.abs().max())), k
