@@ -227,13 +227,9 @@ def head_gemm_utilisation(device, args, iters: int = 50):
     peak = MFMA_BF16_PEAK_TFLOPS / 6.0 if args.gemm_mode == "fast" else MFMA_F32_PEAK_TFLOPS
     res = {"gemm_mode": args.gemm_mode, "mfma_peak_tflops_this_arithmetic": round(peak, 1)}
     gen = torch.Generator(device="cpu").manual_seed(11)
-    for name, rows, n_out in (("tox21", args.batch, args.tasks * 2), ("pcba", 8192, 256)):
-        a = torch.randn((rows, 256), generator=gen).to(device)
-        w = (torch.randn(256 * n_out, generator=gen) * 0.05).to(device)
-        b = torch.zeros(n_out, device=device)
-        o = torch.empty((rows, n_out), device=device)
-        run = lambda: ops.seg_gemm([0], [rows], a, w, [0], None, None, None, b, [0], n_out, False, False, rows,  # noqa: E731
-                                   k1=256, out=o)
+    scratch = torch.empty(ops.task_head_scratch_floats(), dtype=torch.float32, device=device)
+
+    def timed(run):
         for _ in range(5):
             run()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -242,10 +238,21 @@ def head_gemm_utilisation(device, args, iters: int = 50):
             run()
         e1.record()
         torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / iters
+        return e0.elapsed_time(e1) * 1e3 / iters
+    for name, rows, n_out in (("tox21", args.batch, args.tasks * 2), ("pcba", 8192, 256)):
+        a = torch.randn((rows, 256), generator=gen).to(device)
+        w = (torch.randn((n_out, 256), generator=gen) * 0.05).to(device)  # nn.Linear layout, as the model holds it
+        b = torch.zeros(n_out, device=device)
+        o = torch.empty((rows, n_out), device=device)
+        # the head as the whole-model step runs it (gcmi_task_head_forward): with more than 32 outputs the head matrix
+        # is split into fragment images first (one small launch, counted) and the product runs from them
+        us = timed(lambda: ops.task_head_forward(a, w, b, scratch, o))
+        # ... and the plain segmented product on the same operands (no scratch: weights split per workgroup)
+        us_plain = timed(lambda: ops.seg_gemm([0], [rows], a, w.reshape(-1), [0], None, None, None, b, [0], n_out, True, False,
+                                              rows, k1=256, out=o))
         flops = 2.0 * rows * 256 * n_out
         nbytes = 4.0 * (rows * (256 + n_out) + 256 * n_out + n_out)
-        res[name] = {"rows": rows, "k": 256, "n_out": n_out, "us": round(us, 2),
+        res[name] = {"rows": rows, "k": 256, "n_out": n_out, "us": round(us, 2), "us_seg_gemm": round(us_plain, 2),
                      "tflops": round(flops / (us * 1e-6) / 1e12, 2),
                      "mfma_frac": round(flops / (us * 1e-6) / 1e12 / peak, 4),
                      "GBps": round(nbytes / (us * 1e-6) / 1e9, 1),

@@ -153,6 +153,7 @@ _SIGNATURES = {
                       _P, _I64P, _P, _I64P, c_int32, c_int32, c_int32, _P, c_int64, _P],
     "gcmi_seg_gemm_wgrad": [c_int32, _I32P, _I32P, _P, c_int64, c_int32, _P, c_int64, c_int32, _P,
                             _I64P, _P, _I64P, c_int32, _P],
+    "gcmi_task_head_forward": [_P, c_int64, c_int64, c_int32, _P, _P, c_int32, _P, _P, c_int64, _P],
     "gcmi_relu_bwd": [_P, c_int64, _P, c_int64, c_int64, c_int32, _P],
     "gcmi_loss_fwd_bwd": [c_int32, _P, _P, _P, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P],
     "gcmi_softmax": [_P, c_int64, c_int32, _P, _P],
@@ -196,6 +197,7 @@ _SIGNATURES = {
 }
 
 EXPORTS = ["gcmi_version", "gcmi_last_error", "gcmi_model_workspace_floats", "gcmi_small_workspace_floats",
+           "gcmi_task_head_scratch_floats",
            "gcmi_smiles_check", "gcmi_collate_plan_words", "gcmi_collate_batches_layout"] + sorted(_SIGNATURES)
 
 _lib = None
@@ -238,6 +240,7 @@ def load():
         "gcmi_small_workspace_floats": (c_int64, [_MD, c_int64, c_int64]),
         "gcmi_smiles_check": (c_char_p, [c_char_p]),
         "gcmi_collate_plan_words": (c_int64, [c_int64]),
+        "gcmi_task_head_scratch_floats": (c_int64, []),
     }
     for name, (restype, argtypes) in special.items():
         if host_only and not hasattr(lib, name):

@@ -798,6 +798,26 @@ int gcmi_seg_gemm_wgrad(int32_t n_seg, const int32_t* seg_begin, const int32_t* 
   return GCMI_OK;
 }
 
+int64_t gcmi_task_head_scratch_floats(void) { return kHeadImgFloats; }
+
+int gcmi_task_head_forward(const float* d_fingerprint, int64_t ld, int64_t n_rows, int32_t k, const float* d_w,
+                           const float* d_bias, int32_t n_out, float* d_img_scratch, float* d_out, int64_t ldo,
+                           void* stream) {
+  GCMI_CHECK_ARG(d_fingerprint && d_w && d_out && n_rows >= 0 && k > 0 && n_out > 0 && ld >= k && ldo >= n_out,
+                 "task_head_forward: bad arguments");
+  if (n_rows == 0) return GCMI_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (d_img_scratch != nullptr && !gemm_exact_mode()) {
+    int rc = head_prep(d_w, n_out, d_img_scratch, st);
+    if (rc == GCMI_OK) rc = head_fwd_wide(d_fingerprint, ld, n_rows, k, d_w, d_bias, n_out, 0, d_out, ldo, st, d_img_scratch);
+    if (rc != GCMI_ERR_UNSUPPORTED) return rc;
+  }
+  const int32_t zero32 = 0, nr = (int32_t)n_rows;
+  const int64_t zero64 = 0;
+  return gcmi_seg_gemm(1, &zero32, &nr, d_fingerprint, ld, k, d_w, &zero64, nullptr, 0, 0, nullptr, nullptr, d_bias,
+                       d_bias ? &zero64 : nullptr, n_out, 1, 0, d_out, ldo, stream);
+}
+
 int gcmi_relu_bwd(float* d_g, int64_t ldg, const float* d_y, int64_t ldy, int64_t n_rows,
                   int32_t n_feat, void* stream) {
   GCMI_CHECK_ARG(n_feat > 0 && n_rows >= 0 && ldg >= n_feat && ldy >= n_feat, "relu_bwd: bad shape");

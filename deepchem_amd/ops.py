@@ -232,6 +232,28 @@ def seg_gemm(seg_begin, seg_end, a1, w1, w1_off, a2, w2, w2_off, bias, bias_off,
     return out
 
 
+def task_head_forward(fingerprint: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                      scratch: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """logits = fingerprint . weight^T + bias with nn.Linear's (n_out, k) weight, as the whole-model path runs the task
+    head (gcmi_task_head_forward): with 33..256 outputs and a ``scratch`` of ``task_head_scratch_floats()`` floats, from
+    fragment images of the weight prepared in it."""
+    _mat(fingerprint, "fingerprint")
+    n, k = fingerprint.shape
+    n_out = weight.shape[0]
+    if weight.shape != (n_out, k) or weight.dtype != torch.float32 or not weight.is_cuda or not weight.is_contiguous():
+        raise ValueError("weight must be a contiguous float32 CUDA tensor of shape (n_out, %d)" % k)
+    if out is None:
+        out = torch.empty((n, n_out), dtype=torch.float32, device=fingerprint.device)
+    _lib.call("gcmi_task_head_forward", _ptr(fingerprint), _ld(fingerprint), n, k, _ptr(weight),
+              _ptr(bias) if bias is not None else None, n_out, _ptr(scratch) if scratch is not None else None, _ptr(out),
+              _ld(out), _stream())
+    return out
+
+
+def task_head_scratch_floats() -> int:
+    return int(_lib.load().gcmi_task_head_scratch_floats())
+
+
 def seg_gemm_wgrad(seg_begin, seg_end, a, g, dw, dw_off, dbias, dbias_off, trans_w: bool):
     """dw (+)= a^T g per segment; dw / dbias are flat, pre-zeroed, accumulated in place."""
     n_seg = len(seg_begin)

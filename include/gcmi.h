@@ -317,6 +317,15 @@ int gcmi_seg_gemm_wgrad(int32_t n_seg, const int32_t* seg_begin, const int32_t* 
                         const float* d_a, int64_t lda, int32_t k, const float* d_g, int64_t ldg,
                         int32_t n, float* d_dw, const int64_t* dw_off, float* d_dbias,
                         const int64_t* dbias_off, int32_t trans_w, void* stream);
+/* The task head's forward product as the whole-model path runs it (graphconvmodel.py:177-179, :230-236:
+ * logits = fingerprint . W^T + b with nn.Linear's (n_out x 256) weight).  With 33..256 outputs -- PCBA: 128 tasks x 2 --
+ * the head matrix is first split once into fragment images in d_img_scratch (gcmi_task_head_scratch_floats() floats; the
+ * model keeps them in its workspace for the backward) and the product runs from those; other shapes, or
+ * d_img_scratch == NULL, are gcmi_seg_gemm with trans_w = 1.                                                    */
+int64_t gcmi_task_head_scratch_floats(void);
+int gcmi_task_head_forward(const float* d_fingerprint, int64_t ld, int64_t n_rows, int32_t k, const float* d_w,
+                           const float* d_bias, int32_t n_out, float* d_img_scratch, float* d_out, int64_t ldo,
+                           void* stream);
 /* elementwise g *= (y > 0): ReLU derivative, in place on g. */
 int gcmi_relu_bwd(float* d_g, int64_t ldg, const float* d_y, int64_t ldy, int64_t n_rows,
                   int32_t n_feat, void* stream);

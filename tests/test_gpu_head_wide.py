@@ -46,3 +46,21 @@ def test_wide_head_meets_the_oracle(mode, tasks, classes, n):
     checked, report = _check(native, outs(_oracle_step(packed, y, w, tasks, "full", state, **kw)),
                              outs(_oracle_step(packed, y, w, tasks, "full", state, double=True, **kw)))
     assert checked > 40
+
+
+@pytest.mark.parametrize("rows,n_out,with_scratch", [(100, 24, True), (75, 40, True), (8192, 256, True), (333, 256, False),
+                                                     (64, 200, True)])
+def test_task_head_forward_op(rows, n_out, with_scratch):
+    """gcmi_task_head_forward (prepared images with a scratch, the segmented product without, or up to 32 outputs)
+    against the float64 product: 1e-5 of the output's scale (fp32-accurate split products)."""
+    from deepchem_amd import ops
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(rows + n_out)
+    a = torch.randn((rows, 256), generator=gen)
+    w = torch.randn((n_out, 256), generator=gen) * 0.1
+    b = torch.randn(n_out, generator=gen)
+    scratch = torch.empty(ops.task_head_scratch_floats(), dtype=torch.float32, device=dev) if with_scratch else None
+    out = ops.task_head_forward(a.to(dev), w.to(dev), b.to(dev), scratch)
+    ref = a.double() @ w.double().T + b.double()
+    err = float((out.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+    assert out.shape == (rows, n_out) and err <= 1e-5, err
