@@ -166,6 +166,8 @@ _SIGNATURES = {
     "gcmi_tanh_": [_P, c_int64, c_int64, c_int32, _P],
     "gcmi_edge_network_sum": [_P, c_int64, c_int32, c_int32, _P, c_int64, _P, _P, c_int32, _P, c_int64, _P],
     "gcmi_edge_network_moments": [_P, c_int64, c_int32, c_int32, _P, c_int64, _P, _P, c_int32, _P, c_int64, _P],
+    "gcmi_edge_network_moments_mol": [_P, c_int64, c_int32, c_int32, _P, c_int64, _P, _P, c_int32, _P, c_int32, c_int32, _P,
+                                      c_int64, _P],
     "gcmi_gru_gates": [_P, _P, _P, _P, c_int64, _P],
     "gcmi_gru_out": [_P, _P, _P, _P, c_int64, _P],
     "gcmi_gru_gates_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P],

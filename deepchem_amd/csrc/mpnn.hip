@@ -126,6 +126,94 @@ edge_moments_kernel(const float* __restrict__ h, int64_t ldh, int d, int K, cons
   }
 }
 
+// The same moments with the molecule as the unit of work.  In the MPNN batch every pair joins two atoms of ONE
+// molecule (all n x n ordered pairs, graph_models.py:1197-1247), so the n state rows of a molecule are gathered n times
+// over: a workgroup takes one molecule, stages its state rows in LDS once (16-byte loads), and its waves -- one
+// destination atom at a time -- read the states from there; the pair-feature rows of a destination atom are
+// contiguous and come 64 / KP pairs per coalesced load, the source indices with them.  A pair whose source lies
+// outside the molecule (the kernel does not assume there is none) and molecules too large for the LDS budget read the
+// state row from global memory as edge_moments_kernel does.  (edge_moments_kernel: a dependent src -> row gather per
+// pair round, 540 MB of L2 reads per launch at 4 096 molecules; 225 us.)
+constexpr int kMolLdsFloats = 12 * 1024;  // 48 KB of state rows per workgroup
+
+template <int KP, int NC>
+__global__ void __launch_bounds__(kMpBlock)
+edge_moments_mol_kernel(const float* __restrict__ h, int64_t ldh, int d, int K, const float* __restrict__ pf, int64_t ldp,
+                        const int32_t* __restrict__ dst_ptr, const int32_t* __restrict__ src,
+                        const int32_t* __restrict__ mol_ptr, int n_mols, float* __restrict__ t, int64_t ldt,
+                        int lds_floats) {
+  // (sized by the host for the largest molecule when it knows it: a fixed 48 KB leaves three workgroups per CU)
+  extern __shared__ __attribute__((aligned(16))) float hs[];
+  constexpr int PPR = 64 / KP;  // pairs per round
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int dq = d / 4;
+  for (int m = blockIdx.x; m < n_mols; m += gridDim.x) {
+    const int a0 = mol_ptr[m], a1 = mol_ptr[m + 1];
+    const int n = a1 - a0;
+    const bool staged = n * d <= lds_floats && (d & 3) == 0 && (ldh & 3) == 0;
+    __syncthreads();  // (the previous molecule's rows are no longer read)
+    if (staged) {
+      for (int e = threadIdx.x; e < n * dq; e += kMpBlock) {
+        const int r = e / dq, q = e - r * dq;
+        *reinterpret_cast<float4*>(hs + r * d + 4 * q) = *reinterpret_cast<const float4*>(h + (int64_t)(a0 + r) * ldh + 4 * q);
+      }
+    }
+    __syncthreads();
+    for (int i = a0 + wave; i < a1; i += kMpBlock / 64) {
+      const int p0 = dst_ptr[i], p1 = dst_ptr[i + 1];
+      float acc[KP + 1][NC];
+#pragma unroll
+      for (int k = 0; k <= KP; ++k)
+#pragma unroll
+        for (int q = 0; q < NC; ++q) acc[k][q] = 0.f;
+      for (int p = p0; p < p1; p += PPR) {
+        // lane l: feature l % KP of pair p + l / KP; lanes 0 .. PPR - 1 also the pairs' source atoms
+        const int pl = p + lane / KP, kl = lane % KP;
+        const float f = (pl < p1 && kl < K) ? pf[(int64_t)pl * ldp + kl] : 0.f;
+        const int sl = (lane < PPR && p + lane < p1) ? src[p + lane] : -1;
+        const int np = p1 - p < PPR ? p1 - p : PPR;
+        for (int u = 0; u < np; ++u) {
+          const int sj = __builtin_amdgcn_readlane(sl, u);
+          const bool in_lds = staged && sj >= a0 && sj < a1;
+          float v[NC];
+#pragma unroll
+          for (int q = 0; q < NC; ++q) {
+            const int c = lane + 64 * q;
+            v[q] = c < d ? (in_lds ? hs[(sj - a0) * d + c] : h[(int64_t)sj * ldh + c]) : 0.f;
+          }
+#pragma unroll
+          for (int k = 0; k < KP; ++k) {
+            if (k < K) {
+              const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, f), u * KP + k));
+#pragma unroll
+              for (int q = 0; q < NC; ++q) acc[k][q] = fmaf(w, v[q], acc[k][q]);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < NC; ++q) acc[KP][q] += v[q];
+        }
+      }
+      float* row = t + (int64_t)i * ldt;
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        if (k < K) {
+#pragma unroll
+          for (int q = 0; q < NC; ++q) {
+            const int c = lane + 64 * q;
+            if (c < d) row[(int64_t)k * d + c] = acc[k][q];
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        const int c = lane + 64 * q;
+        if (c < d) row[(int64_t)K * d + c] = acc[KP][q];
+      }
+    }
+  }
+}
+
 // z <- sigmoid(z), r <- sigmoid(r), hr = h * r
 __global__ void gru_gates_kernel(float* __restrict__ z, float* __restrict__ r, const float* __restrict__ h,
                                  float* __restrict__ hr, int64_t n) {
@@ -389,6 +477,42 @@ int gcmi_edge_network_moments(const float* d_h, int64_t ldh, int32_t n_hidden, i
     hipLaunchKernelGGL((edge_moments_kernel<16, 2>), grid, dim3(kMpBlock), 0, st, d_h, ldh, n_hidden, n_pair_feat,
                        d_pair_feat, ldp, d_dst_ptr, d_src, n_dst, d_t, ldt);
   GCMI_CHECK_LAUNCH("edge_network_moments");
+  return GCMI_OK;
+}
+
+int gcmi_edge_network_moments_mol(const float* d_h, int64_t ldh, int32_t n_hidden, int32_t n_pair_feat,
+                                  const float* d_pair_feat, int64_t ldp, const int32_t* d_dst_ptr, const int32_t* d_src,
+                                  int32_t n_dst, const int32_t* d_mol_ptr, int32_t n_mols, int32_t max_mol_atoms,
+                                  float* d_t, int64_t ldt, void* stream) {
+  // Measured (QM9-like molecules, 18 atoms, all pairs; us per launch, this kernel / the per-atom kernel): 18 k atoms
+  // 93 / 52, 73 k atoms 229 / 227, 147 k atoms 404 / 488 -- both are bound by the moment arithmetic and the 3.6 KB row
+  // every atom writes; the staged rows only pay once the per-atom gathers outgrow L2.  GCMI_EDGE_MOMENTS_MOL=1 / 0
+  // forces it on / off.
+  static const int mode = getenv("GCMI_EDGE_MOMENTS_MOL") ? atoi(getenv("GCMI_EDGE_MOMENTS_MOL")) : -1;
+  const bool on = mode == 1 || (mode != 0 && n_dst >= 96 * 1024);
+  if (!on || d_mol_ptr == nullptr || n_mols <= 0)
+    return gcmi_edge_network_moments(d_h, ldh, n_hidden, n_pair_feat, d_pair_feat, ldp, d_dst_ptr, d_src, n_dst, d_t, ldt, stream);
+  GCMI_CHECK_ARG(n_hidden > 0 && n_hidden <= 128 && n_pair_feat > 0 && n_pair_feat <= 16 && n_dst >= 0 &&
+                     ldh >= n_hidden && ldp >= n_pair_feat && ldt >= (int64_t)(n_pair_feat + 1) * n_hidden,
+                 "edge_network_moments_mol: bad shape (n_hidden <= 128, n_pair_feat <= 16)");
+  if (n_dst == 0) return GCMI_OK;
+  GCMI_CHECK_ARG(d_h && d_pair_feat && d_dst_ptr && d_src && d_t, "edge_network_moments_mol: NULL buffer");
+  GCMI_CHECK_ARG(aligned16(d_h) || (n_hidden & 3) || (ldh & 3), "edge_network_moments_mol: state rows must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)std::min<int64_t>(n_mols, 256 * 32));
+  // LDS for the state rows of one molecule: the largest one if the caller knows it (max_mol_atoms > 0), at most 48 KB
+  int lds_floats = kMolLdsFloats;
+  if (max_mol_atoms > 0) lds_floats = (int)std::min<int64_t>(kMolLdsFloats, ((int64_t)max_mol_atoms * n_hidden + 63) / 64 * 64);
+#define LAUNCH_EMM(KP, NC)                                                                                                 \
+  hipLaunchKernelGGL((edge_moments_mol_kernel<KP, NC>), grid, dim3(kMpBlock), sizeof(float) * (size_t)lds_floats, st, d_h, \
+                     ldh, n_hidden, n_pair_feat, d_pair_feat, ldp, d_dst_ptr, d_src, d_mol_ptr, n_mols, d_t, ldt, lds_floats)
+  if (n_pair_feat <= 8) {
+    if (n_hidden <= 64) LAUNCH_EMM(8, 1); else LAUNCH_EMM(8, 2);
+  } else {
+    if (n_hidden <= 64) LAUNCH_EMM(16, 1); else LAUNCH_EMM(16, 2);
+  }
+#undef LAUNCH_EMM
+  GCMI_CHECK_LAUNCH("edge_network_moments_mol");
   return GCMI_OK;
 }
 

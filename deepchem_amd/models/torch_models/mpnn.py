@@ -181,7 +181,7 @@ class PairPlan:
     backward pass (with the pair features permuted once).  Built with device ops (bincount / cumsum / a stable
     argsort): sorting 3 x 10^5 pairs on the host cost more than the whole optimizer step."""
 
-    def __init__(self, atom_to_pair, pair_features: torch.Tensor, n_atoms: int, device):
+    def __init__(self, atom_to_pair, pair_features: torch.Tensor, n_atoms: int, device, mol_ptr=None, max_mol_atoms: int = 0):
         a2p = torch.as_tensor(np.ascontiguousarray(np.asarray(atom_to_pair), np.int64).reshape(-1, 2)) \
             if not torch.is_tensor(atom_to_pair) else atom_to_pair.reshape(-1, 2).to(torch.int64)
         a2p = a2p.to(device, non_blocking=True)
@@ -194,6 +194,8 @@ class PairPlan:
                 raise ValueError("atom_to_pair must list pairs by ascending first atom, atoms inside [0, %d)" % n_atoms)
         self.n_atoms = n_atoms
         self.pf = pair_features
+        self.mol_ptr = mol_ptr  # int32 CSR of the atoms per molecule, or None: the moments kernel stages molecules in LDS
+        self.max_mol_atoms = int(max_mol_atoms)  # (0: unknown)
 
         def csr(ids):
             ptr = torch.zeros(n_atoms + 1, dtype=torch.int64, device=device)
@@ -246,7 +248,7 @@ class EdgeNetworkFn(torch.autograd.Function):
     def forward(ctx, h, M, plan: PairPlan, acc: EdgeAccum):
         h = ops.rowmajor(h)
         d, K = acc.d, acc.K
-        T = ops.edge_network_moments(h, plan.pf, plan.dst_ptr, plan.src)
+        T = ops.edge_network_moments(h, plan.pf, plan.dst_ptr, plan.src, plan.mol_ptr, plan.max_mol_atoms)
         n = T.shape[0]
         m = ops.seg_gemm([0], [n], T, M.reshape(-1), [0], None, None, None, None, None, d, True, False, n, (K + 1) * d, 0)
         ctx.plan, ctx.acc = plan, acc
@@ -273,7 +275,7 @@ class EdgeNetworkFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if acc.M2 is None:
                 acc.M2 = M.reshape(d, K + 1, d).permute(2, 1, 0).reshape(d, (K + 1) * d).contiguous()
-            Tt = ops.edge_network_moments(dm, plan.pf_t, plan.src_ptr, plan.dst_of_sorted)  # [sum_i pf_ijk dm_i | sum_i dm_i]
+            Tt = ops.edge_network_moments(dm, plan.pf_t, plan.src_ptr, plan.dst_of_sorted, plan.mol_ptr, plan.max_mol_atoms)  # [sum_i pf_ijk dm_i | sum_i dm_i]
             dh = ops.seg_gemm([0], [n], Tt, acc.M2.reshape(-1), [0], None, None, None, None, None, d, True, False, n,
                               (K + 1) * d, 0)
         return dh, dM, None, None
@@ -328,9 +330,10 @@ class _MPNNTorchModel(nn.Module):
         n, d = x.shape[0], self.n_hidden
         if x.shape[1] != self.n_atom_feat or pf.shape[1] != self.n_pair_feat:
             raise ValueError("MPNNModel: feature widths do not match the model")
-        plan = PairPlan(atom_to_pair, pf, n, dev)
         split = atom_split.cpu().numpy() if torch.is_tensor(atom_split) else np.asarray(atom_split)
         mol_ptr = torch.from_numpy(_csr_from_sorted(np.asarray(split, np.int64), self.batch_size, "atom_split")).to(dev)  # int32
+        biggest = int(np.bincount(np.asarray(split, np.int64)).max()) if len(split) else 0
+        plan = PairPlan(atom_to_pair, pf, n, dev, mol_ptr, biggest)
         h = torch.zeros((n, d), dtype=torch.float32, device=dev)
         h[:, :self.n_atom_feat] = x  # zero padding up to n_hidden (MessagePassing.call, :3697-3706)
         edge_M = EdgeMatsFn.apply(self.edge_W, self.edge_b, d)

@@ -429,13 +429,21 @@ def expand_atom_codes(codes: torch.Tensor, ld_out: int = 76) -> torch.Tensor:
     return out
 
 
-def edge_network_moments(h: torch.Tensor, pair_feat: torch.Tensor, dst_ptr: torch.Tensor, src: torch.Tensor):
-    """T[i] = [sum_p pf[p,0] h[src_p] | ... | sum_p pf[p,K-1] h[src_p] | sum_p h[src_p]] per destination atom."""
+def edge_network_moments(h: torch.Tensor, pair_feat: torch.Tensor, dst_ptr: torch.Tensor, src: torch.Tensor,
+                         mol_ptr: Optional[torch.Tensor] = None, max_mol_atoms: int = 0):
+    """T[i] = [sum_p pf[p,0] h[src_p] | ... | sum_p pf[p,K-1] h[src_p] | sum_p h[src_p]] per destination atom.
+    ``mol_ptr`` (int32 CSR of the atoms per molecule): the molecule-staged kernel (same T)."""
     h = _mat(h, "h")
     pf = _mat(pair_feat, "pair_feat")
     d, K = h.shape[1], pf.shape[1]
     n_dst = dst_ptr.numel() - 1
     t = torch.empty((n_dst, (K + 1) * d), dtype=torch.float32, device=h.device)
+    if mol_ptr is not None:
+        mp = _i32vec(mol_ptr, "mol_ptr")
+        _lib.call("gcmi_edge_network_moments_mol", _ptr(h), _ld(h), d, K, _ptr(pf), _ld(pf),
+                  _ptr(_i32vec(dst_ptr, "dst_ptr")), _ptr(_i32vec(src, "src", pf.shape[0])), n_dst, _ptr(mp),
+                  mp.numel() - 1, int(max_mol_atoms), _ptr(t), _ld(t), _stream())
+        return t
     _lib.call("gcmi_edge_network_moments", _ptr(h), _ld(h), d, K, _ptr(pf), _ld(pf), _ptr(_i32vec(dst_ptr, "dst_ptr")),
               _ptr(_i32vec(src, "src", pf.shape[0])), n_dst, _ptr(t), _ld(t), _stream())
     return t

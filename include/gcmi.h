@@ -384,6 +384,15 @@ int gcmi_edge_network_sum(const float* d_g, int64_t ldg, int32_t n_hidden, int32
 int gcmi_edge_network_moments(const float* d_h, int64_t ldh, int32_t n_hidden, int32_t n_pair_feat,
                               const float* d_pair_feat, int64_t ldp, const int32_t* d_dst_ptr, const int32_t* d_src,
                               int32_t n_dst, float* d_t, int64_t ldt, void* stream);
+/* ... with the molecules of the batch given (d_mol_ptr [n_mols + 1]: atoms of molecule m are the rows
+ *   [d_mol_ptr[m], d_mol_ptr[m+1]) -- the CSR of default_generator's atom_split, graph_models.py:1197-1247): a
+ *   molecule's state rows are staged once in LDS and serve all its pairs.  Same T; pairs that leave their molecule are
+ *   still right (read from memory).  max_mol_atoms: atoms of the largest molecule if the caller knows it (sizes the
+ *   LDS: more workgroups per CU), else 0.  d_mol_ptr == NULL: gcmi_edge_network_moments.                          */
+int gcmi_edge_network_moments_mol(const float* d_h, int64_t ldh, int32_t n_hidden, int32_t n_pair_feat,
+                                  const float* d_pair_feat, int64_t ldp, const int32_t* d_dst_ptr, const int32_t* d_src,
+                                  int32_t n_dst, const int32_t* d_mol_ptr, int32_t n_mols, int32_t max_mol_atoms,
+                                  float* d_t, int64_t ldt, void* stream);
 /* Backward of the same pieces (the training step of MPNNModel, models/graph_models.py:1045-1247; forward
  * formulas models/layers.py:3755-3887).  gru_gates_bwd: dzp = dz z(1-z), drp = dhr h r(1-r), dh = dhr r;
  * gru_out_bwd: dz = dout (x - tanh hpre), dhpre = dout (1-z)(1-tanh^2), dx = dout z; lstm_cell_bwd: dz (rows x 4H,

@@ -72,3 +72,48 @@ def test_message_passing_steps_and_set2set_against_oracle(G):
     q = gather([h_gpu, atom_split])
     q_ref = MO.set_gather(h_ref.numpy(), atom_split, 4, len(mols), gather.U.detach(), gather.b.detach())
     assert rel(q.cpu().numpy(), q_ref.numpy()) < TOL
+
+
+def test_edge_moments_molecule_kernel_equals_the_per_atom_kernel(monkeypatch):
+    """gcmi_edge_network_moments_mol (a molecule's state rows staged in LDS) against gcmi_edge_network_moments on the
+    same pair lists: ragged molecules, one larger than the LDS budget (rows from memory), pairs that leave their
+    molecule (must still be right), both pair-feature widths' instantiations."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, torch
+from deepchem_amd import ops
+dev = torch.device("cuda:0")
+rng = np.random.RandomState(0)
+for K, d in ((8, 100), (14, 64), (3, 128)):
+    sizes = [1, 5, 29, 2, 17, 150 if d == 100 else 40, 9]
+    n = sum(sizes)
+    mol_ptr = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    dst, src = [], []
+    for m, s in enumerate(sizes):
+        a0 = mol_ptr[m]
+        for i in range(s):
+            for j in range(s):
+                if rng.rand() < 0.8:
+                    dst.append(a0 + i); src.append(a0 + j)
+    # a few pairs that leave their molecule
+    for _ in range(20):
+        dst.append(int(rng.randint(n))); src.append(int(rng.randint(n)))
+    order = np.argsort(np.asarray(dst), kind="stable")
+    dst, src = np.asarray(dst)[order], np.asarray(src)[order]
+    dst_ptr = np.concatenate([[0], np.cumsum(np.bincount(dst, minlength=n))]).astype(np.int32)
+    h = torch.randn(n, d, device=dev)
+    pf = torch.rand(len(dst), K, device=dev)
+    a = ops.edge_network_moments(h, pf, torch.from_numpy(dst_ptr).to(dev), torch.from_numpy(src.astype(np.int32)).to(dev))
+    for biggest in (0, max(sizes)):
+        b = ops.edge_network_moments(h, pf, torch.from_numpy(dst_ptr).to(dev), torch.from_numpy(src.astype(np.int32)).to(dev),
+                                     torch.from_numpy(mol_ptr).to(dev), biggest)
+        err = float((a - b).abs().max() / a.abs().max())
+        assert err <= 1e-6, (K, d, biggest, err)
+print("ok")
+'''
+    env = dict(os.environ, GCMI_EDGE_MOMENTS_MOL="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

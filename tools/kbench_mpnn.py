@@ -89,7 +89,10 @@ def main():
     # the message kernel alone, both directions
     d, K = 100, 8
     pf = inputs[1]
-    plan = PairPlan(inputs[3], pf, n_atoms, dev)
+    from deepchem_amd.models.torch_models.weave_layers import _csr_from_sorted
+    split = inputs[2].cpu().numpy() if torch.is_tensor(inputs[2]) else np.asarray(inputs[2])
+    mol_ptr = torch.from_numpy(_csr_from_sorted(np.asarray(split, np.int64), B, "atom_split")).to(dev)
+    plan = PairPlan(inputs[3], pf, n_atoms, dev, mol_ptr, int(np.bincount(np.asarray(split, np.int64)).max()))
     h = torch.randn(n_atoms, d, device=dev) * 0.3
     alg = n_pairs * (K * 4 + d * 4) + n_atoms * (K + 1) * d * 4
 
@@ -103,10 +106,15 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / iters * 1e3
-    us = timed(lambda: ops.edge_network_moments(h, plan.pf, plan.dst_ptr, plan.src))
+    us = timed(lambda: ops.edge_network_moments(h, plan.pf, plan.dst_ptr, plan.src, plan.mol_ptr, plan.max_mol_atoms))
     res["edge_moments_forward"] = {"us": round(us, 1), "algorithmic_GBps": round(alg / us / 1e3, 1)}
-    us = timed(lambda: ops.edge_network_moments(h, plan.pf_t, plan.src_ptr, plan.dst_of_sorted))
+    us = timed(lambda: ops.edge_network_moments(h, plan.pf_t, plan.src_ptr, plan.dst_of_sorted, plan.mol_ptr, plan.max_mol_atoms))
     res["edge_moments_backward"] = {"us": round(us, 1), "algorithmic_GBps": round(alg / us / 1e3, 1)}
+    us = timed(lambda: ops.edge_network_moments(h, plan.pf, plan.dst_ptr, plan.src))
+    res["edge_moments_forward_per_atom_kernel"] = {"us": round(us, 1)}
+    a_new = ops.edge_network_moments(h, plan.pf, plan.dst_ptr, plan.src, plan.mol_ptr, plan.max_mol_atoms)
+    a_old = ops.edge_network_moments(h, plan.pf, plan.dst_ptr, plan.src)
+    res["edge_moments_kernels_max_rel_diff"] = float((a_new - a_old).abs().max() / a_old.abs().max())
     res["reference_pair_matrix_GB_per_round"] = round(n_pairs * d * d * 4 / 1e9, 2)
     # CPU oracle on a smaller sample
     from oracle.mpnn_oracle import MPNNOracle
