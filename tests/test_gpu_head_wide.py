@@ -14,22 +14,26 @@ from tests.test_gpu_scale import _check, _native_step, _oracle_step
 pytestmark = pytest.mark.gpu
 
 CASES = [
-    # mode, tasks, classes, molecules
-    ("classification", 20, 2, 75),    # 40 outputs: padded to 48 columns; 75 = 2 x 32 + 11 molecules
-    ("classification", 100, 2, 40),   # 200 outputs
-    ("classification", 128, 2, 33),   # 256 outputs: the most; a last tile of one molecule
-    ("classification", 15, 3, 50),    # 45 outputs, three classes: the general loss loop
-    ("regression", 33, 1, 50),        # one output per task, odd count
-    ("regression", 200, 1, 37),       # more tasks than one round of the loss phase (128)
-    ("classification", 130, 2, 40),   # 260 outputs: beyond the kernels, the separate launches
+    # mode, tasks, classes, molecules, seed of the molecules
+    # (seeds: no dense pre-activation within 3e-6 of zero in the float64 oracle.  With seed 95 the first case has one
+    # at -5e-7 of a typical 0.76: the default kernels keep it negative like the oracle, the separate-launch forward --
+    # GCMI_FUSED_FWD=0, exact mode -- rounds it positive, its ReLU passes a gradient and one column of dense.weight is
+    # 2e-3 off: a flipped route as in tests/test_gpu_scale.py, not an error of either)
+    ("classification", 20, 2, 75, 98),    # 40 outputs: padded to 48 columns; 75 = 2 x 32 + 11 molecules
+    ("classification", 100, 2, 40, 140),  # 200 outputs
+    ("classification", 128, 2, 33, 161),  # 256 outputs: the most; a last tile of one molecule
+    ("classification", 15, 3, 50, 65),    # 45 outputs, three classes: the general loss loop
+    ("regression", 33, 1, 50, 83),        # one output per task, odd count
+    ("regression", 200, 1, 37, 237),      # more tasks than one round of the loss phase (128)
+    ("classification", 130, 2, 40, 170),  # 260 outputs: beyond the kernels, the separate launches
 ]
 
 
-@pytest.mark.parametrize("mode,tasks,classes,n", CASES)
-def test_wide_head_meets_the_oracle(mode, tasks, classes, n):
+@pytest.mark.parametrize("mode,tasks,classes,n,seed", CASES)
+def test_wide_head_meets_the_oracle(mode, tasks, classes, n, seed):
     from oracle import graphconv_oracle as O
     from deepchem_amd.utils.synthetic import synthetic_labels, synthetic_molecules
-    packed = synthetic_molecules(n, seed=tasks + n, max_atoms=40)
+    packed = synthetic_molecules(n, seed=seed, max_atoms=40)
     rng = np.random.RandomState(tasks)
     if mode == "classification":
         y = rng.randint(0, classes, size=(n, tasks)).astype(np.float64)
