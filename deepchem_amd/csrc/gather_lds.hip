@@ -228,6 +228,9 @@ struct MaxOp {
   uint8_t* __restrict__ arg;
   static constexpr bool kExtraTile = false;
   static constexpr int kEPP = 4;
+  // measured at 1.2 M atoms, 64 columns (us per launch): 256 threads 131 / 137, 512: 151 / 156, 1 024: 137 / 137 (the
+  // gather-sum is the other way round: 179 / 127 / 149 for 76 columns; the GraphPool backward 166 / 126 / 141)
+  static constexpr int kThreads = 256;
   // the folded BatchNorm vectors live in LDS: a global load in the compute phase would make the
   // compiler wait for the LDS-DMA in flight as well
   using State = NoState;
@@ -550,6 +553,7 @@ struct SumOpH {
   using State = NoState;
   static constexpr bool kExtraTile = false;
   static constexpr int kEPP = 8;
+  static constexpr int kThreads = 256;  // measured (64 columns, 1.2 M atoms): 58.6 us against 74.4 at 512 and 93.4 at 1 024
   __device__ __forceinline__ bool skip(int) const { return false; }
   template <int WT>
   __device__ __forceinline__ void init(float*, int, State&) const {}
@@ -796,6 +800,7 @@ struct MaxBwdOpH {
   using State = NoState;
   static constexpr bool kExtraTile = false;
   static constexpr int kEPP = 8;
+  static constexpr int kThreads = 256;  // measured: 84.4 us against 92.6 at 512 and 119 at 1 024
   __device__ __forceinline__ bool skip(int n_feat) const {
     return only_if_gamma != nullptr && !bn_pool_ill_conditioned(only_if_gamma, only_if_beta, n_feat);
   }
@@ -1240,10 +1245,17 @@ static int launch_wt(const gcmi_graph* g, const WinPlan& p, const char* x, int64
   return GCMI_OK;
 }
 
+// threads per workgroup an op asks for (kThreads) unless GCMI_WIN_THREADS says otherwise; 512 when it has no preference
+template <class Op>
+static constexpr auto op_threads(int) -> decltype(Op::kThreads) { return Op::kThreads; }
+template <class Op>
+static constexpr int op_threads(long) { return 512; }
+
 template <int LPR, bool AUX, class Op>
 static int launch_lpr(const gcmi_graph* g, const WinPlan& p, const char* x, int64_t ldx, const uint8_t* aux,
                       const Op& op, hipStream_t st, const char* what, int which) {
-  static const int wt = env_int("GCMI_WIN_THREADS", 512);
+  static const int wt_env = env_int("GCMI_WIN_THREADS", 0);
+  const int wt = wt_env ? wt_env : op_threads<Op>(0);
   if constexpr (Op::kExtraTile) {
     // fp32 tiles: one workgroup per CU by LDS, so make it a full one (1 024 threads: 292 us against 346 at 512).  bf16
     // tiles are half the size and two 512-thread workgroups share a CU: 288 us against 367 at 1 024 (SumAccMaxBwdOpH)
