@@ -158,6 +158,25 @@ __device__ __forceinline__ void stage(char* buf, const Layout& L, const WinMeta&
   }
 }
 
+// The rows of a SECOND matrix of the window (same slots, same row pitch in pieces) into a tile of their own: ops whose
+// compute phase would otherwise fetch them from HBM -- and wait, one in-order counter, for the next window's DMA with them.
+template <int WT, int LPR>
+__device__ __forceinline__ void stage_extra(char* dst, const Layout& L, const WinMeta& m, const char* __restrict__ x2,
+                                            int64_t ldx2) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int n16 = m.sb[kND] * LPR;
+  const unsigned base = lds_addr(dst);
+  for (int e0 = tid - lane; e0 < n16; e0 += WT) {
+    const int e = e0 + lane;
+    if (e < n16) {
+      const int slot = e / LPR;
+      const int c = e - slot * LPR;
+      glds16(x2 + (int64_t)row_of_slot(m, L.maxd, slot) * ldx2 + c * 16, base + e0 * 16);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- per-window compute phases
 // Rows this thread also needs from HBM in the compute phase (the old value of an accumulated output, the BatchNorm
 // input of the statistics) are requested for up to kPre elements up front, unconditionally from clamped addresses,
@@ -419,10 +438,17 @@ struct SumAccMaxBwdOp {
   float* __restrict__ dy;
   int64_t lddy;
   struct State {
-    char* extra;  // the third tile: [slot][LPR] float4
+    char* extra;  // the third tile of the window being computed: [slot][LPR] float4, the dXs rows on entry
   };
   static constexpr bool kExtraTile = true;
+  // The third tile is double-buffered and filled by the LDS-DMA with the window's dXs rows (stage_extra): read from HBM
+  // in the compute phase they waited, one in-order counter, for the NEXT window's DMA, so that no window's compute
+  // overlapped the next one's load (281 us at 96-atom windows against 181 at 192-atom ones: a fixed ~3.8 us per window).
+  static constexpr bool kExtraDma = true;
+  static constexpr int kExtraScale = 2;
   static constexpr int kEPP = 4;
+  __device__ __forceinline__ const char* extra_src() const { return reinterpret_cast<const char*>(dxs); }
+  __device__ __forceinline__ int64_t extra_ld_bytes() const { return lddxs * 4; }
   __device__ __forceinline__ bool skip(int) const { return false; }
   template <int WT>
   __device__ __forceinline__ void init(float*, int, State&) const {}
@@ -435,33 +461,21 @@ struct SumAccMaxBwdOp {
     const uint16_t* ent = reinterpret_cast<const uint16_t*>(buf + L.tile_bytes + L.aux_bytes);
     float4* t2 = reinterpret_cast<float4*>(st.extra);
     const int n16 = m.sb[kND] * LPR;
-    // ---- stage 1: dX of the window -> the third tile
-    for (int e0 = threadIdx.x; e0 < n16; e0 += kPre * WT) {
-      float4 old[kPre];
-#pragma unroll
-      for (int k = 0; k < kPre; ++k) {
-        const int e = e0 + k * WT < n16 ? e0 + k * WT : n16 - 1;
-        const int slot = e / LPR;
-        const int c = e - slot * LPR;
-        old[k] = *reinterpret_cast<const float4*>(dxs + (int64_t)row_of_slot(m, L.maxd, slot) * lddxs + c * 4);
+    // ---- stage 1: dX of the window = gather(dS) + dXs, in place in the third tile
+    for (int e = threadIdx.x; e < n16; e += WT) {
+      const int slot = e / LPR;
+      const int c = e - slot * LPR;
+      int d, row, eloc;
+      locate(m, L.maxd, slot, d, row, eloc);
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 0; j < d; ++j) {
+        const int sl = ent[eloc + j] & GCMI_WIN_MAX_SLOTS;
+        const float4 v = tile[sl * LPR + c];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
       }
-#pragma unroll
-      for (int k = 0; k < kPre; ++k) {
-        const int e = e0 + k * WT;
-        if (e >= n16) break;
-        const int slot = e / LPR;
-        const int c = e - slot * LPR;
-        int d, row, eloc;
-        locate(m, L.maxd, slot, d, row, eloc);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int j = 0; j < d; ++j) {
-          const int sl = ent[eloc + j] & GCMI_WIN_MAX_SLOTS;
-          const float4 v = tile[sl * LPR + c];
-          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        }
-        acc.x += old[k].x; acc.y += old[k].y; acc.z += old[k].z; acc.w += old[k].w;  // same order as SumOp<true>
-        t2[e] = acc;
-      }
+      const float4 old = t2[e];
+      acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;  // same order as SumOp<true>
+      t2[e] = acc;
     }
     __syncthreads();
     // ---- stage 2: the GraphPool backward over it
@@ -886,11 +900,18 @@ struct SumAccMaxBwdOpH {
   bf16_t* __restrict__ dy;
   int64_t lddy;
   struct State {
-    char* extra;  // the third tile: [slot][LPR][8] floats
+    char* extra;  // the third tile of the window being computed: [slot][LPR] pieces of 8 bf16, the dXs rows on entry
   };
   static constexpr bool kExtraTile = true;
-  static constexpr int kExtraScale = 2;  // the third tile is fp32: twice the bytes of the bf16 tile
+  // As SumAccMaxBwdOp: the third tile comes by LDS-DMA with the window, one per buffer.  It is a bf16 tile and dX is
+  // completed IN PLACE in it -- rounded to bf16 once, exactly what the two separate passes do when they write dX to
+  // HBM as a bf16 matrix between them -- so the LDS footprint stays that of the former single fp32 tile (two 512-thread
+  // workgroups per CU) and the compute phase reads nothing from HBM.
+  static constexpr bool kExtraDma = true;
+  static constexpr int kExtraScale = 2;
   static constexpr int kEPP = 8;
+  __device__ __forceinline__ const char* extra_src() const { return reinterpret_cast<const char*>(dxs); }
+  __device__ __forceinline__ int64_t extra_ld_bytes() const { return lddxs * 2; }
   __device__ __forceinline__ bool skip(int) const { return false; }
   template <int WT>
   __device__ __forceinline__ void init(float*, int, State&) const {}
@@ -900,40 +921,26 @@ struct SumAccMaxBwdOpH {
   __device__ __forceinline__ void run(const char* buf, const Layout& L, const WinMeta& m, const float*, State& st) const {
     const uint4* tile = reinterpret_cast<const uint4*>(buf);
     const uint16_t* ent = reinterpret_cast<const uint16_t*>(buf + L.tile_bytes + L.aux_bytes);
-    float4* t2 = reinterpret_cast<float4*>(st.extra);  // two float4 per piece
+    uint4* t2 = reinterpret_cast<uint4*>(st.extra);
     const int n16 = m.sb[kND] * LPR;
-    // ---- stage 1: dX of the window -> the third tile
-    for (int e0 = threadIdx.x; e0 < n16; e0 += kPre * WT) {
-      uint4 old[kPre];
+    // ---- stage 1: dX of the window = gather(dS) + dXs (fp32 sums), rounded into the third tile
+    for (int e = threadIdx.x; e < n16; e += WT) {
+      const int slot = e / LPR;
+      const int c = e - slot * LPR;
+      int d, row, eloc;
+      locate(m, L.maxd, slot, d, row, eloc);
+      float acc[8], v[8];
 #pragma unroll
-      for (int k = 0; k < kPre; ++k) {
-        const int e = e0 + k * WT < n16 ? e0 + k * WT : n16 - 1;
-        const int slot = e / LPR;
-        const int c = e - slot * LPR;
-        old[k] = *reinterpret_cast<const uint4*>(dxs + (int64_t)row_of_slot(m, L.maxd, slot) * lddxs + c * 8);
-      }
-#pragma unroll
-      for (int k = 0; k < kPre; ++k) {
-        const int e = e0 + k * WT;
-        if (e >= n16) break;
-        const int slot = e / LPR;
-        const int c = e - slot * LPR;
-        int d, row, eloc;
-        locate(m, L.maxd, slot, d, row, eloc);
-        float acc[8], v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] = 0.f;
-        for (int j = 0; j < d; ++j) {
-          widen8(tile[(ent[eloc + j] & GCMI_WIN_MAX_SLOTS) * LPR + c], v);
-#pragma unroll
-          for (int q = 0; q < 8; ++q) acc[q] += v[q];
-        }
-        widen8(old[k], v);
+      for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+      for (int j = 0; j < d; ++j) {
+        widen8(tile[(ent[eloc + j] & GCMI_WIN_MAX_SLOTS) * LPR + c], v);
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc[q] += v[q];
-        t2[2 * e] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        t2[2 * e + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
       }
+      widen8(t2[e], v);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] += v[q];
+      t2[e] = pack8(acc);
     }
     __syncthreads();
     // ---- stage 2: the GraphPool backward over it
@@ -942,22 +949,17 @@ struct SumAccMaxBwdOpH {
       const int c = e - slot * LPR;
       int d, row, eloc;
       locate(m, L.maxd, slot, d, row, eloc);
-      float4 g0 = t2[2 * e], g1 = t2[2 * e + 1];
       uint2 a = aux8(buf, L, e);
-      float acc[8];
-      {
-        const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      float acc[8], g[8];
+      widen8(t2[e], g);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] = aux_byte(a, q) == 0 ? g[q] : 0.f;
-      }
+      for (int q = 0; q < 8; ++q) acc[q] = aux_byte(a, q) == 0 ? g[q] : 0.f;
       for (int j = 0; j < d; ++j) {
         const int en = ent[eloc + j];
         const int sl = en & GCMI_WIN_MAX_SLOTS;
         const unsigned char want = (unsigned char)((en >> GCMI_WIN_SLOT_BITS) + 1);
-        g0 = t2[2 * (sl * LPR + c)];
-        g1 = t2[2 * (sl * LPR + c) + 1];
+        widen8(t2[sl * LPR + c], g);
         a = aux8(buf, L, sl * LPR + c);
-        const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc[q] += aux_byte(a, q) == want ? g[q] : 0.f;
       }
@@ -1082,6 +1084,12 @@ struct ReadoutOp {
   }
 };
 
+// ops whose third tile is filled by the DMA, one per window buffer (kExtraDma)
+template <class Op>
+static constexpr auto extra_dma(int) -> decltype(Op::kExtraDma) { return Op::kExtraDma; }
+template <class Op>
+static constexpr bool extra_dma(long) { return false; }
+
 template <int WT, int LPR, bool AUX, class Op>
 __global__ void __launch_bounds__(WT)
 win_kernel(const int32_t* __restrict__ meta, const uint16_t* __restrict__ edges, int n_norm, int n_win,
@@ -1096,6 +1104,7 @@ win_kernel(const int32_t* __restrict__ meta, const uint16_t* __restrict__ edges,
   if (op.skip(LPR * Op::kEPP)) return;  // uniform over the grid
   typename Op::State ost;
   if constexpr (Op::kExtraTile) ost.extra = smem + 2 * L.buf_bytes();  // behind the two window buffers
+  constexpr bool kXD = extra_dma<Op>(0);  // the third tile is per window, DMA-filled (two of them, like the buffers)
   op.template init<WT>(op_lds, LPR * Op::kEPP, ost);
   const int t = threadIdx.x;
   if ((int)blockIdx.x >= g_norm) {  // oversized windows: stage, wait, compute
@@ -1127,6 +1136,7 @@ win_kernel(const int32_t* __restrict__ meta, const uint16_t* __restrict__ edges,
   }
   __syncthreads();
   stage<WT, LPR, AUX, Op::kEPP>(smem, L, read_meta(ring[0]), x, ldx, aux, edges);
+  if constexpr (kXD) stage_extra<WT, LPR>(smem + 2 * bb, L, read_meta(ring[0]), op.extra_src(), op.extra_ld_bytes());
   int it = 0;
   for (;;) {
     wait_dma();
@@ -1136,8 +1146,13 @@ win_kernel(const int32_t* __restrict__ meta, const uint16_t* __restrict__ edges,
       ring[(it + 2) % 3][t] = metareg;  // read from the next round on
       if (w + 3 * G < n_norm) metareg = meta[widx(w + 3 * G) * GCMI_WIN_META_INTS + t];
     }
-    if (has_next)
+    if (has_next) {
       stage<WT, LPR, AUX, Op::kEPP>(smem + ((it + 1) & 1) * bb, L, read_meta(ring[(it + 1) % 3]), x, ldx, aux, edges);
+      if constexpr (kXD)
+        stage_extra<WT, LPR>(smem + 2 * bb + ((it + 1) & 1) * L.tile_bytes, L, read_meta(ring[(it + 1) % 3]), op.extra_src(),
+                             op.extra_ld_bytes());
+    }
+    if constexpr (kXD) ost.extra = smem + 2 * bb + (it & 1) * L.tile_bytes;
     op.template run<WT, LPR>(smem + (it & 1) * bb, L, read_meta(ring[it % 3]), op_lds, ost);
     if (!has_next) break;
     w += G;
@@ -1262,6 +1277,7 @@ static int launch_lpr(const gcmi_graph* g, const WinPlan& p, const char* x, int6
     static const int wt2 = env_int("GCMI_WIN_THREADS_TWO_STAGE", 0);
     const int want = wt2 ? wt2 : (Op::kEPP == 8 ? 512 : 1024);
     if (want == 1024) return launch_wt<1024, LPR, AUX, Op>(g, p, x, ldx, aux, op, st, what, which);
+    if (want == 768) return launch_wt<768, LPR, AUX, Op>(g, p, x, ldx, aux, op, st, what, which);
     if (want == 512) return launch_wt<512, LPR, AUX, Op>(g, p, x, ldx, aux, op, st, what, which);
   }
   if (wt == 1024) return launch_wt<1024, LPR, AUX, Op>(g, p, x, ldx, aux, op, st, what, which);
@@ -1483,7 +1499,7 @@ int win_gather_max_sum_h(const gcmi_graph* g, const bf16_t* d_x, int64_t ldx, in
 bool win_two_stage_usable(const gcmi_graph* g, int n_feat) {
   if (!win_has_width(n_feat) || !win_usable(g, n_feat, true)) return false;
   const WinPlan p = make_plan(g, n_feat, 4);
-  return p.shmem + (size_t)p.L.tile_bytes <= (size_t)kLdsPerCU;
+  return p.shmem + (size_t)2 * p.L.tile_bytes <= (size_t)kLdsPerCU;  // two third tiles (SumAccMaxBwdOp::kExtraScale)
 }
 
 // d_dxs holds the self part of dX on entry; on return d_dy holds the GraphPool backward of the complete dX.  The

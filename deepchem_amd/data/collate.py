@@ -12,6 +12,7 @@ The result is a ``DeviceBatch``: what ``_GraphConvTorchModel.forward`` accepts i
 place of the reference's 14-tensor input list.
 """
 import ctypes
+import os
 from typing import Optional
 
 import numpy as np
@@ -20,6 +21,9 @@ import torch
 from deepchem_amd import _lib
 from deepchem_amd.graph import BatchGraph
 from deepchem_amd.utils.synthetic import PackedMols
+
+# atoms per molecule window of the LDS-staged kernels (gcmi_collate_plans; GCMI_WIN_CAP overrides: tools/ sweeps)
+DEFAULT_WIN_CAP = int(os.environ.get("GCMI_WIN_CAP", "96"))
 
 
 class DeviceBatch:
@@ -118,7 +122,7 @@ class HostBatch:
 
 def collate_host(packed: PackedMols, sel: Optional[np.ndarray], max_deg: int = 10,
                  pad_features_to: int = 4, ring: Optional[PinnedRing] = None,
-                 win_cap: int = 96, pin: Optional[bool] = None) -> HostBatch:
+                 win_cap: int = DEFAULT_WIN_CAP, pin: Optional[bool] = None) -> HostBatch:
     """Run the native collation into one host arena (no GPU involved)."""
     if sel is None:
         sel = np.arange(packed.n_mols, dtype=np.int64)
@@ -174,7 +178,7 @@ def collate_host(packed: PackedMols, sel: Optional[np.ndarray], max_deg: int = 1
 def collate_to_device(packed: PackedMols, sel: Optional[np.ndarray], device: torch.device,
                       n_samples: Optional[int] = None, max_deg: int = 10,
                       pad_features_to: int = 4, ring: Optional[PinnedRing] = None,
-                      win_cap: int = 96) -> DeviceBatch:
+                      win_cap: int = DEFAULT_WIN_CAP) -> DeviceBatch:
     hb = collate_host(packed, sel, max_deg, pad_features_to, ring, win_cap)
     dev_arena = hb.arena.to(device, non_blocking=True)
     if ring is not None:

@@ -9,6 +9,7 @@ host does the serial pass over per-molecule degree histograms (``gcmi_collate_pl
 writes the arena on the device -- the same bytes ``gcmi_collate_plans`` writes (tests/test_resident.py).
 """
 import ctypes
+import os
 from typing import Optional
 
 import numpy as np
@@ -18,6 +19,9 @@ from deepchem_amd import _lib
 from deepchem_amd.data.collate import DeviceBatch, HostBatch, PinnedRing
 from deepchem_amd.graph import BatchGraph
 from deepchem_amd.utils.synthetic import PackedMols
+
+# atoms per molecule window of the LDS-staged kernels (gcmi_collate_plans; GCMI_WIN_CAP overrides: tools/ sweeps)
+DEFAULT_WIN_CAP = int(os.environ.get("GCMI_WIN_CAP", "96"))
 
 ND = _lib.GCMI_MAX_DEG + 1
 
@@ -66,7 +70,7 @@ class BatchPlan:
 
 
 def plan_batch(mol_hist: np.ndarray, atom_ptr: np.ndarray, sel: np.ndarray, n_feat: int, ld: int, max_deg: int = 10,
-               win_cap: int = 96, staging: Optional[torch.Tensor] = None) -> BatchPlan:
+               win_cap: int = DEFAULT_WIN_CAP, staging: Optional[torch.Tensor] = None) -> BatchPlan:
     sel = np.ascontiguousarray(sel, np.int64)
     n_sel = int(sel.shape[0])
     if n_sel and (sel.min() < 0 or sel.max() >= mol_hist.shape[0]):
@@ -119,7 +123,7 @@ class ResidentMolSet:
         return int(packed.n_atoms) * (per_atom + 8 + 4) + int(packed.adj_idx.shape[0]) * 5
 
     def collate(self, sel: np.ndarray, n_samples: Optional[int] = None, ring: Optional[PinnedRing] = None,
-                win_cap: int = 96) -> DeviceBatch:
+                win_cap: int = DEFAULT_WIN_CAP) -> DeviceBatch:
         """The batch of molecules ``sel`` (in order, repeats allowed), built on the current stream."""
         n_sel = int(np.shape(sel)[0])
         words = int(_lib.load().gcmi_collate_plan_words(n_sel))
