@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for t in 1024 768 1024 768; do
-  bash tools/prof_step.sh r03_y_t$t GCMI_WIN_THREADS_TWO_STAGE=$t
-  grep "SumAccMaxBwdOp" gpurun_out/r03_y_t${t}_timeline.txt | head -1 | cut -c1-130
+for v in 0 1 2 3; do
+  if [ $v -eq 0 ]; then BENCH_ARGS="--storage bf16+grads" bash tools/prof_step.sh r03_y_p$v; else BENCH_ARGS="--storage bf16+grads" bash tools/prof_step.sh r03_y_p$v GCMI_FWD_H_PER_CU=$v; fi
+  grep "fwd_hd_kernel" gpurun_out/r03_y_p${v}_timeline.txt | awk '{printf "%s ", $5}'; echo
 done
